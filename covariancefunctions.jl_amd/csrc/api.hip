@@ -1,0 +1,620 @@
+// api.hip — C-ABI entry points of libcovgram.so (include/covgram.h): context / points handles,
+// kernel-parameter construction, and the dense, dense-instantiate and gradient MVM drivers.
+// Structured MVMs live in toeplitz.hip and structured.hip.
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dense_mvm.hpp"
+#include "grad_mvm.hpp"
+
+namespace covgram {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compiled dimension set
+// ------------------------------------------------------------------------------------------------
+const int kDims[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+const int kNumDims = (int)(sizeof(kDims) / sizeof(kDims[0]));
+
+int pad_dim(int d) {
+    for (int i = 0; i < kNumDims; ++i)
+        if (kDims[i] >= d) return kDims[i];
+    return -1;
+}
+
+// per-family launchers (dense_fam.hip / grad_fam.hip, one translation unit per family)
+#define CG_DECL(n)                                            \
+    int launch_dense_family_##n(const DenseArgs&, int dtype); \
+    int launch_grad_family_##n(const GradArgs&, int dtype);
+CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
+#undef CG_DECL
+
+dense_launch_fn dense_launcher(int family) {
+    static const dense_launch_fn t[COVGRAM_NFAMILY] = {
+        launch_dense_family_0, launch_dense_family_1, launch_dense_family_2, launch_dense_family_3, launch_dense_family_4,
+        launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8};
+    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+}
+grad_launch_fn grad_launcher(int family) {
+    static const grad_launch_fn t[COVGRAM_NFAMILY] = {
+        launch_grad_family_0, launch_grad_family_1, launch_grad_family_2, launch_grad_family_3, launch_grad_family_4,
+        launch_grad_family_5, launch_grad_family_6, launch_grad_family_7, launch_grad_family_8};
+    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel parameters.  MaternP tables follow src/stationary.jl:117-191 (coefficients :184-191,
+// normalisation :157, derivatives at zero :172-182 — derived from the power series, not SymEngine).
+// ------------------------------------------------------------------------------------------------
+static long double factl(int n) {
+    long double f = 1;
+    for (int i = 2; i <= n; ++i) f *= i;
+    return f;
+}
+
+// normalised polynomial h[m], m = 0..q:  H_q(r) = exp(-r) sum_m h[m] r^m,  H_q(0) = 1
+static void maternp_poly(int q, long double* h) {
+    const long double nrm = factl(2 * q) / factl(q);
+    for (int m = 0; m <= q; ++m) {
+        // coefficient of (2r)^m: (2q-m)! / (m! (q-m)!)
+        const long double c = factl(2 * q - m) / (factl(m) * factl(q - m));
+        h[m] = c * powl(2.0L, m) / nrm;
+    }
+}
+
+// d_i = d^i/ds^i MaternP_p(s) at s = 0 (i = 1..p): the r^(2i) series coefficient of exp(-r) q_p(r) times (2p+1)^i i!
+static void maternp_derivs0(int p, long double* d /* d[1..p] */) {
+    long double h[MAXP + 1];
+    maternp_poly(p, h);
+    for (int i = 1; i <= p; ++i) {
+        long double coef = 0;
+        for (int m = 0; m <= std::min(p, 2 * i); ++m) {
+            const int k = 2 * i - m;
+            coef += h[m] * (((k & 1) ? -1.0L : 1.0L) / factl(k));
+        }
+        d[i] = coef * powl((long double)(2 * p + 1), i) * factl(i);
+    }
+}
+
+int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out) {
+    CG_REQUIRE(k != nullptr, COVGRAM_EINVAL, "kernel is NULL");
+    CG_REQUIRE(k->family >= 0 && k->family < COVGRAM_NFAMILY, COVGRAM_EUNSUPPORTED, "unknown kernel family %d", k->family);
+    const bool dotfam = (k->family == COVGRAM_DOT || k->family == COVGRAM_EXPDOT);
+    const int trait = dotfam ? COVGRAM_DOTPRODUCT : COVGRAM_ISOTROPIC;
+    CG_REQUIRE(k->trait == trait, COVGRAM_EINVAL, "kernel trait %d does not match family %d (input_trait would be %d)",
+               k->trait, k->family, trait);
+    CG_REQUIRE(k->power >= 1, COVGRAM_EINVAL, "Power exponent must be >= 1 (got %d)", k->power);
+    CG_REQUIRE(k->lengthscale > 0, COVGRAM_EINVAL, "DomainError: l = %g is non-positive", k->lengthscale);
+    CG_REQUIRE(!(dotfam && k->lengthscale != 1.0), COVGRAM_EINVAL, "Lengthscale applies to isotropic kernels only");
+    memset(out, 0, sizeof(*out));
+    out->k = *k;
+    KParams<double>& kp = out->kp;
+    const double inv_l = 1.0 / k->lengthscale;
+    kp.scale = k->scale;
+    kp.power = k->power;
+    kp.p = 0;
+    kp.gamma = dotfam ? 1.0 : inv_l;
+    kp.c0 = 0;
+    out->eq_folded = false;
+    const double LOG2E = 1.4426950408889634074;
+    switch (k->family) {
+        case COVGRAM_EQ:
+            kp.c0 = -0.5 * LOG2E;  // exp(-s/2) = exp2(c0 s)
+            if (!for_gradient) {     // dense path: fold sqrt(log2(e)/2) into the coordinate pre-scale
+                kp.gamma = inv_l * sqrt(0.5 * LOG2E);
+                out->eq_folded = true;
+            }
+            break;
+        case COVGRAM_RQ:
+            CG_REQUIRE(k->param > 0, COVGRAM_EINVAL, "DomainError: alpha not positive");
+            kp.param = k->param;
+            kp.c0 = 1.0 / (2.0 * k->param);
+            break;
+        case COVGRAM_GAMMAEXP:
+            CG_REQUIRE(k->param >= 0 && k->param <= 2, COVGRAM_EINVAL, "DomainError: gamma not in [0,2]");
+            kp.param = 0.5 * k->param;
+            break;
+        case COVGRAM_IMQ:
+            kp.param = k->param * k->param;
+            break;
+        case COVGRAM_MATERNP: {
+            CG_REQUIRE(k->p >= 0, COVGRAM_EINVAL, "DomainError: p = %d is negative", k->p);
+            CG_REQUIRE(k->p <= MAXP, COVGRAM_EUNSUPPORTED, "MaternP order %d exceeds the compiled maximum %d", k->p, MAXP);
+            const int p = k->p;
+            kp.p = p;
+            kp.mp_c = 2.0 * p + 1.0;
+            long double h[MAXP + 1], d[MAXP + 1];
+            maternp_poly(p, h);
+            for (int m = 0; m <= p; ++m) kp.h0[m] = (double)h[m];
+            if (p >= 1) { maternp_poly(p - 1, h); for (int m = 0; m <= p - 1; ++m) kp.h1[m] = (double)h[m]; }
+            if (p >= 2) { maternp_poly(p - 2, h); for (int m = 0; m <= p - 2; ++m) kp.h2[m] = (double)h[m]; }
+            kp.ty[0] = 1.0;
+            if (p >= 1) {
+                maternp_derivs0(p, d);
+                for (int i = 1; i <= p; ++i) kp.ty[i] = (double)(d[i] / factl(i));
+                kp.mp_d1 = (double)d[1];
+                kp.mp_d2 = (p >= 2) ? (double)d[2] : 0.0;
+                const double eps = (dtype == COVGRAM_F64) ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+                kp.mp_bound = pow(eps, 1.0 / p);     // src/stationary.jl:135
+            } else {
+                kp.mp_bound = 0.0;                   // eps^(1/0) = 0: never taken
+            }
+            break;
+        }
+        default: break;
+    }
+    kp.gamma2 = kp.gamma * kp.gamma;
+    return COVGRAM_OK;
+}
+
+int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out) {
+    Workspace& w = ctx->ws[slot];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            CG_CHECK_HIP(hipFree(w.ptr));
+            w.ptr = nullptr; w.bytes = 0;
+        }
+        size_t want = std::max(bytes, (size_t)1 << 20);
+        want = (want + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&w.ptr, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return COVGRAM_ENOMEM; }
+        w.bytes = want;
+    }
+    *out = w.ptr;
+    return COVGRAM_OK;
+}
+
+// dense instantiation: generic over family via a uniform switch (HBM-write-bound, n*m*sizeof(T) out)
+template <typename T>
+__device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
+    T v;
+    switch (family) {
+        case COVGRAM_EQ: v = Phi<COVGRAM_EQ, T, false>::eval(s, kp); break;
+        case COVGRAM_EXP: v = Phi<COVGRAM_EXP, T, false>::eval(s, kp); break;
+        case COVGRAM_RQ: v = Phi<COVGRAM_RQ, T, false>::eval(s, kp); break;
+        case COVGRAM_GAMMAEXP: v = Phi<COVGRAM_GAMMAEXP, T, false>::eval(s, kp); break;
+        case COVGRAM_CAUCHY: v = Phi<COVGRAM_CAUCHY, T, false>::eval(s, kp); break;
+        case COVGRAM_IMQ: v = Phi<COVGRAM_IMQ, T, false>::eval(s, kp); break;
+        case COVGRAM_MATERNP: v = Phi<COVGRAM_MATERNP, T, false>::eval(s, kp); break;
+        case COVGRAM_DOT: v = s; break;
+        default: v = Phi<COVGRAM_EXPDOT, T, false>::eval(s, kp); break;
+    }
+    if (kp.power != 1) v = ipow(v, kp.power);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void matrix_kernel(const T* __restrict__ X, int64_t n, const T* __restrict__ Y, int64_t m,
+                                                     int32_t d, T* __restrict__ out, int64_t ldo, int family, T scale,
+                                                     const KParams<T> kp) {
+    // block = 256 rows × 1 column strip of 16 columns; lanes along rows -> coalesced column-major stores
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t jb = (int64_t)blockIdx.y * 16;
+    if (i >= n) return;
+    const bool iso = (family != COVGRAM_DOT && family != COVGRAM_EXPDOT);
+    const T* xi = X + i * (int64_t)d;
+    for (int64_t j = jb; j < jb + 16 && j < m; ++j) {
+        const T* yj = Y + j * (int64_t)d;
+        T s = (T)0;
+        for (int l = 0; l < d; ++l) {
+            if (iso) { T r = (xi[l] - yj[l]) * kp.gamma; s = cg_fma(r, r, s); }
+            else s = cg_fma(xi[l], yj[l], s);
+        }
+        out[i + j * ldo] = scale * phi_any<T>(family, s, kp);
+    }
+}
+
+// staging helpers for loc == HOST ------------------------------------------------------------------
+struct Staged {
+    void* dev = nullptr;
+    void* host = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace covgram
+
+using namespace covgram;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int covgram_version(void) { return COVGRAM_VERSION; }
+const char* covgram_last_error(void) { return g_err; }
+
+int covgram_device_count(int* count) {
+    CG_REQUIRE(count != nullptr, COVGRAM_EINVAL, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+    *count = c;
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_create(covgram_ctx** out, int device_id, void* hip_stream) {
+    CG_REQUIRE(out != nullptr, COVGRAM_EINVAL, "ctx out pointer is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (hipGetDeviceCount: %s) — libcovgram has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return COVGRAM_ENODEVICE;
+    }
+    CG_REQUIRE(device_id >= 0 && device_id < count, COVGRAM_EINVAL, "device_id %d out of range [0,%d)", device_id, count);
+    CG_CHECK_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CG_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libcovgram is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+        return COVGRAM_ENODEVICE;
+    }
+    covgram_ctx* c = new covgram_ctx();
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(se)); return COVGRAM_EHIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_destroy(covgram_ctx* ctx) {
+    if (!ctx) return COVGRAM_OK;
+    CG_REQUIRE(ctx->live_handles == 0, COVGRAM_EINVAL, "ctx destroyed with %d live handles", ctx->live_handles);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream) {
+    CG_REQUIRE(ctx != nullptr, COVGRAM_EINVAL, "ctx is NULL");
+    CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+    else {
+        CG_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream) {
+    CG_REQUIRE(ctx && hip_stream, COVGRAM_EINVAL, "NULL argument");
+    *hip_stream = (void*)ctx->stream;
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
+    CG_REQUIRE(ctx && key, COVGRAM_EINVAL, "NULL argument");
+    if (!strcmp(key, "dense_variant")) ctx->dense_variant = value;
+    else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
+    else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
+    else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
+    else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
+    return COVGRAM_OK;
+}
+
+int covgram_sync(covgram_ctx* ctx) {
+    CG_REQUIRE(ctx != nullptr, COVGRAM_EINVAL, "ctx is NULL");
+    CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return COVGRAM_OK;
+}
+
+int covgram_points_create(covgram_ctx* ctx, covgram_points** out, const void* x, int64_t n, int32_t d, int32_t dtype,
+                          int32_t loc) {
+    CG_REQUIRE(ctx && out, COVGRAM_EINVAL, "NULL argument");
+    CG_REQUIRE(n >= 0 && d >= 1, COVGRAM_EINVAL, "points: need n >= 0 and d >= 1 (got n=%lld d=%d)", (long long)n, d);
+    CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
+    CG_REQUIRE(x != nullptr || n == 0, COVGRAM_EINVAL, "points pointer is NULL");
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    covgram_points* p = new covgram_points();
+    p->ctx = ctx; p->n = n; p->d = d; p->dtype = dtype;
+    if (loc == COVGRAM_DEVICE) { p->dptr = const_cast<void*>(x); p->owns = false; }
+    else {
+        const size_t bytes = (size_t)n * d * dtype_size(dtype);
+        if (bytes) {
+            hipError_t e = hipMalloc(&p->dptr, bytes);
+            if (e != hipSuccess) { delete p; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return COVGRAM_ENOMEM; }
+            e = hipMemcpyAsync(p->dptr, x, bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(p->dptr); delete p; set_error("H2D copy failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+        }
+        p->owns = true;
+    }
+    ctx->live_handles++;
+    *out = p;
+    return COVGRAM_OK;
+}
+
+int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t count, covgram_points** out) {
+    CG_REQUIRE(parent && out, COVGRAM_EINVAL, "NULL argument");
+    CG_REQUIRE(first >= 0 && count >= 0 && first + count <= parent->n, COVGRAM_EINVAL,
+               "slice [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)parent->n);
+    covgram_points* p = new covgram_points(*parent);
+    p->owns = false;
+    p->n = count;
+    p->dptr = (char*)parent->dptr + (size_t)first * parent->d * dtype_size(parent->dtype);
+    parent->ctx->live_handles++;
+    *out = p;
+    return COVGRAM_OK;
+}
+
+int covgram_points_destroy(covgram_points* p) {
+    if (!p) return COVGRAM_OK;
+    if (p->owns && p->dptr) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->dptr); }
+    p->ctx->live_handles--;
+    delete p;
+    return COVGRAM_OK;
+}
+
+int covgram_points_info(const covgram_points* p, int64_t* n, int32_t* d, int32_t* dtype) {
+    CG_REQUIRE(p != nullptr, COVGRAM_EINVAL, "points is NULL");
+    if (n) *n = p->n;
+    if (d) *d = p->d;
+    if (dtype) *dtype = p->dtype;
+    return COVGRAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_pair(const covgram_ctx* ctx, const covgram_points* X, const covgram_points* Y) {
+    CG_REQUIRE(ctx && X && Y, COVGRAM_EINVAL, "NULL argument");
+    CG_REQUIRE(X->ctx == ctx && Y->ctx == ctx, COVGRAM_EINVAL, "points belong to a different ctx");
+    CG_REQUIRE(X->dtype == Y->dtype, COVGRAM_EINVAL, "x and y have different dtypes");
+    CG_REQUIRE(X->d == Y->d, COVGRAM_EINVAL, "DimensionMismatch: inputs have to have the same length: %d, %d", X->d, Y->d);
+    return COVGRAM_OK;
+}
+
+// choose the J split: enough workgroups to fill the chip, chunks aligned to the inner accumulation block
+static void choose_split(const covgram_ctx* ctx, int64_t rowblocks, int64_t m, int64_t align, int64_t* jchunk, int* jsplit) {
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 8;
+    int64_t js = ctx->jsplit > 0 ? ctx->jsplit : (target + rowblocks - 1) / std::max<int64_t>(rowblocks, 1);
+    const int64_t maxsplit = std::max<int64_t>(1, m / (2 * align));
+    js = std::max<int64_t>(1, std::min(js, maxsplit));
+    int64_t jc = (m + js - 1) / js;
+    jc = ((jc + align - 1) / align) * align;
+    if (jc <= 0) jc = align;
+    js = std::max<int64_t>(1, (m + jc - 1) / jc);
+    *jchunk = jc;
+    *jsplit = (int)js;
+}
+
+int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc) {
+    int rc = check_pair(ctx, X, Y);
+    if (rc) return rc;
+    CG_REQUIRE(nrhs >= 1, COVGRAM_EINVAL, "nrhs must be >= 1");
+    const int64_t n = X->n, m = Y->n;
+    CG_REQUIRE(lda >= m && ldy >= n, COVGRAM_EINVAL, "DimensionMismatch: lda=%lld < m=%lld or ldy=%lld < n=%lld",
+               (long long)lda, (long long)m, (long long)ldy, (long long)n);
+    CG_REQUIRE((a != nullptr || m == 0) && (y != nullptr || n == 0), COVGRAM_EINVAL, "a or y is NULL");
+    const int dtype = X->dtype;
+    const size_t ts = dtype_size(dtype);
+    HostKernel hk;
+    rc = make_host_kernel(k, dtype, false, &hk);
+    if (rc) return rc;
+    const int D = pad_dim(X->d);
+    CG_REQUIRE(D > 0, COVGRAM_EUNSUPPORTED, "dense_mvm: d = %d exceeds the largest compiled dimension %d", X->d, kDims[kNumDims - 1]);
+    dense_launch_fn launch = dense_launcher(k->family);
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return COVGRAM_OK;
+
+    // host staging ---------------------------------------------------------------------------------
+    const void* a_dev = a;
+    void* y_dev = y;
+    int64_t lda_d = lda, ldy_d = ldy;
+    if (loc == COVGRAM_HOST) {
+        void *sa, *sy;
+        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * nrhs * ts, &sa); if (rc) return rc;
+        rc = ws_reserve(ctx, 3, (size_t)n * nrhs * ts, &sy); if (rc) return rc;
+        if (m > 0)
+            CG_CHECK_HIP(hipMemcpy2DAsync(sa, (size_t)m * ts, a, (size_t)lda * ts, (size_t)m * ts, nrhs, hipMemcpyHostToDevice, ctx->stream));
+        if (beta != 0.0)
+            CG_CHECK_HIP(hipMemcpy2DAsync(sy, (size_t)n * ts, y, (size_t)ldy * ts, (size_t)n * ts, nrhs, hipMemcpyHostToDevice, ctx->stream));
+        a_dev = sa; y_dev = sy; lda_d = m; ldy_d = n;
+    }
+
+    const double alpha_eff = alpha * hk.kp.scale;
+    const int R = rows_per_lane_for(D, dtype);
+    const int64_t rows_per_wg = (int64_t)DENSE_THREADS * R;
+    const int64_t rowblocks = (n + rows_per_wg - 1) / rows_per_wg;
+    const int64_t npad = rowblocks * rows_per_wg;
+
+    for (int c0 = 0; c0 < nrhs; c0 += 4) {
+        const int nr = std::min(4, nrhs - c0);
+        const int NRpad = (nr == 1) ? 1 : 4;
+        const char* a_c = (const char*)a_dev + (size_t)c0 * lda_d * ts;
+        char* y_c = (char*)y_dev + (size_t)c0 * ldy_d * ts;
+        if (m == 0) {  // empty sum: y <- beta * y
+            int64_t jc; int js;
+            (void)jc; (void)js;
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                                   (const float*)nullptr, npad, NRpad, 0, (float*)y_c, n, ldy_d, nr, 0.0f, (float)beta);
+            else
+                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                                   (const double*)nullptr, npad, NRpad, 0, (double*)y_c, n, ldy_d, nr, 0.0, beta);
+            continue;
+        }
+        void* P;
+        rc = ws_reserve(ctx, 0, (size_t)m * (D + NRpad) * ts, &P); if (rc) return rc;
+        if (dtype == COVGRAM_F32)
+            hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, (float)hk.kp.gamma);
+        else
+            hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, hk.kp.gamma);
+        int64_t jchunk; int jsplit;
+        choose_split(ctx, rowblocks, m, DENSE_INNER, &jchunk, &jsplit);
+        DenseArgs da;
+        da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
+        da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;
+        da.variant = (int)ctx->dense_variant; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
+        if (jsplit == 1) da.out = y_c;
+        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
+        rc = launch(da, dtype); if (rc) return rc;
+        if (jsplit > 1) {
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                                   (const float*)da.out, npad, NRpad, jsplit, (float*)y_c, n, ldy_d, nr, (float)alpha_eff, (float)beta);
+            else
+                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                                   (const double*)da.out, npad, NRpad, jsplit, (double*)y_c, n, ldy_d, nr, alpha_eff, beta);
+        }
+    }
+    CG_CHECK_HIP(hipGetLastError());
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpy2DAsync(y, (size_t)ldy * ts, y_dev, (size_t)n * ts, (size_t)n * ts, nrhs, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return COVGRAM_OK;
+}
+
+int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, void* out,
+                   int64_t ldo, int32_t loc) {
+    int rc = check_pair(ctx, X, Y);
+    if (rc) return rc;
+    const int64_t n = X->n, m = Y->n;
+    CG_REQUIRE(ldo >= n, COVGRAM_EINVAL, "ldo=%lld < n=%lld", (long long)ldo, (long long)n);
+    CG_REQUIRE(out != nullptr || n * m == 0, COVGRAM_EINVAL, "out is NULL");
+    const int dtype = X->dtype;
+    const size_t ts = dtype_size(dtype);
+    HostKernel hk;
+    rc = make_host_kernel(k, dtype, true, &hk);   // gamma = 1/l, unfolded EQ
+    if (rc) return rc;
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (n == 0 || m == 0) return COVGRAM_OK;
+    void* o = out;
+    int64_t ld = ldo;
+    if (loc == COVGRAM_HOST) { rc = ws_reserve(ctx, 3, (size_t)n * m * ts, &o); if (rc) return rc; ld = n; }
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((m + 15) / 16));
+    if (dtype == COVGRAM_F32)
+        hipLaunchKernelGGL(matrix_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, (const float*)Y->dptr, m,
+                           X->d, (float*)o, ld, k->family, (float)hk.kp.scale, cast_params<float>(hk.kp));
+    else
+        hipLaunchKernelGGL(matrix_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)X->dptr, n, (const double*)Y->dptr, m,
+                           X->d, (double*)o, ld, k->family, hk.kp.scale, cast_params<double>(hk.kp));
+    CG_CHECK_HIP(hipGetLastError());
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ldo * ts, o, (size_t)n * ts, (size_t)n * ts, m, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return COVGRAM_OK;
+}
+
+int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                     void* y, double alpha, double beta, int32_t loc) {
+    int rc = check_pair(ctx, X, Y);
+    if (rc) return rc;
+    const int64_t n = X->n, m = Y->n;
+    const int d = X->d;
+    CG_REQUIRE((a != nullptr || m == 0) && (y != nullptr || n == 0), COVGRAM_EINVAL, "a or y is NULL");
+    const int dtype = X->dtype;
+    const size_t ts = dtype_size(dtype);
+    HostKernel hk;
+    rc = make_host_kernel(k, dtype, true, &hk);
+    if (rc) return rc;
+    const int D = pad_dim(d);
+    CG_REQUIRE(D > 0, COVGRAM_EUNSUPPORTED, "grad_mvm: d = %d exceeds the largest compiled dimension %d", d, kDims[kNumDims - 1]);
+    grad_launch_fn launch = grad_launcher(k->family);
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return COVGRAM_OK;
+
+    const void* a_dev = a;
+    void* y_dev = y;
+    if (loc == COVGRAM_HOST) {
+        void *sa, *sy;
+        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * d * ts, &sa); if (rc) return rc;
+        rc = ws_reserve(ctx, 3, (size_t)n * d * ts, &sy); if (rc) return rc;
+        if (m > 0) CG_CHECK_HIP(hipMemcpyAsync(sa, a, (size_t)m * d * ts, hipMemcpyHostToDevice, ctx->stream));
+        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(sy, y, (size_t)n * d * ts, hipMemcpyHostToDevice, ctx->stream));
+        a_dev = sa; y_dev = sy;
+    }
+    const bool iso = (k->trait == COVGRAM_ISOTROPIC);
+    // isotropic: b = -2 gamma^2 (psi' a + 2 psi'' r'(r'.a));  dot product: b = k1 a + k2 y (x.a)
+    const double alpha_eff = alpha * hk.kp.scale * (iso ? -2.0 * hk.kp.gamma2 : 1.0);
+    const int64_t rowblocks = (n + GRAD_THREADS - 1) / GRAD_THREADS;
+    const int64_t npad = rowblocks * GRAD_THREADS;
+
+    if (m == 0) {
+        if (dtype == COVGRAM_F32)
+            hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const float*)nullptr,
+                               npad, D, 0, (float*)y_dev, n, d, 0.0f, (float)beta);
+        else
+            hipLaunchKernelGGL(grad_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)nullptr,
+                               npad, D, 0, (double*)y_dev, n, d, 0.0, beta);
+    } else {
+        void* P;
+        rc = ws_reserve(ctx, 0, (size_t)m * 2 * D * ts, &P); if (rc) return rc;
+        const int64_t pe = m * (int64_t)D;
+        if (dtype == COVGRAM_F32)
+            hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma);
+        else
+            hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma);
+        int64_t jchunk; int jsplit;
+        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
+        GradArgs ga;
+        ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit;
+        ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
+        if (jsplit == 1) ga.out = y_dev;
+        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * D * npad * ts, &ga.out); if (rc) return rc; }
+        rc = launch(ga, dtype); if (rc) return rc;
+        if (jsplit > 1) {
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const float*)ga.out,
+                                   npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta);
+            else
+                hipLaunchKernelGGL(grad_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)ga.out,
+                                   npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta);
+        }
+    }
+    CG_CHECK_HIP(hipGetLastError());
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)n * d * ts, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return COVGRAM_OK;
+}
+
+// debugging / test hook: the double-precision parameter block the device kernels receive.
+// out[0..8] = gamma, gamma2, scale, param, c0, mp_c, mp_bound, mp_d1, mp_d2; then h0, h1, h2, ty (9 each).
+int covgram_debug_kernel_params(const covgram_kernel* k, int32_t dtype, int32_t for_gradient, double* out45) {
+    HostKernel hk;
+    int rc = make_host_kernel(k, dtype, for_gradient != 0, &hk);
+    if (rc) return rc;
+    CG_REQUIRE(out45 != nullptr, COVGRAM_EINVAL, "out is NULL");
+    const KParams<double>& p = hk.kp;
+    double* o = out45;
+    *o++ = p.gamma; *o++ = p.gamma2; *o++ = p.scale; *o++ = p.param; *o++ = p.c0; *o++ = p.mp_c; *o++ = p.mp_bound; *o++ = p.mp_d1; *o++ = p.mp_d2;
+    for (int i = 0; i <= MAXP; ++i) *o++ = p.h0[i];
+    for (int i = 0; i <= MAXP; ++i) *o++ = p.h1[i];
+    for (int i = 0; i <= MAXP; ++i) *o++ = p.h2[i];
+    for (int i = 0; i <= MAXP; ++i) *o++ = p.ty[i];
+    return COVGRAM_OK;
+}
+
+}  // extern "C"

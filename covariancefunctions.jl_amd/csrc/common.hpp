@@ -1,0 +1,148 @@
+// common.hpp — host-side plumbing shared by every translation unit of libcovgram.so.
+// gfx950 only; no CPU compute path exists in this library (include/covgram.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/covgram.h"
+
+namespace covgram {
+
+void set_error(const char* fmt, ...);
+
+#define CG_CHECK_HIP(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            ::covgram::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                                 __LINE__);                                                         \
+            return COVGRAM_EHIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+#define CG_REQUIRE(cond, code, ...)              \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::covgram::set_error(__VA_ARGS__);   \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Device-side kernel parameters (passed by value in the kernarg segment -> scalar loads).
+// The host fills the double version from covgram_kernel; kernels receive the T version.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXP = COVGRAM_MATERNP_MAX_P;
+
+template <typename T>
+struct KParams {
+    T gamma;        // coordinate pre-scale applied to x and y before differences / dots
+    T gamma2;       // gamma^2 (chain-rule factor for the gradient kernel)
+    T scale;        // Constant multiplier
+    T param;        // RQ alpha | gammaExp gamma/2 | IMQ c^2 (pre-scaled)
+    T c0;           // EQ: exponent factor for exp2 (unfolded path); RQ: 1/(2 alpha)
+    T mp_c;         // MaternP: 2p+1
+    T mp_bound;     // MaternP: eps(T)^(1/p) Taylor guard (src/stationary.jl:135-136)
+    T mp_d1, mp_d2; // MaternP: first / second derivative at zero
+    T h0[MAXP + 1]; // MaternP: normalised polynomial of H_p      (value)
+    T h1[MAXP + 1]; //          H_{p-1}                           (phi')
+    T h2[MAXP + 1]; //          H_{p-2}                           (phi'')
+    T ty[MAXP + 1]; // MaternP: Taylor coefficients d_i / i!  (ty[0] = 1)
+    int32_t p;      // MaternP order
+    int32_t power;  // Power exponent
+};
+
+struct HostKernel {
+    covgram_kernel k;
+    KParams<double> kp;   // un-typed master copy
+    bool eq_folded;       // dense path folds -log2(e)/2 into gamma for EQ
+};
+
+// Validates `k` and fills the parameter block.  `for_gradient` keeps gamma = 1/l (no log2e fold).
+int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out);
+
+template <typename T>
+inline KParams<T> cast_params(const KParams<double>& s) {
+    KParams<T> d;
+    d.gamma = (T)s.gamma; d.gamma2 = (T)s.gamma2; d.scale = (T)s.scale; d.param = (T)s.param;
+    d.c0 = (T)s.c0; d.mp_c = (T)s.mp_c; d.mp_bound = (T)s.mp_bound; d.mp_d1 = (T)s.mp_d1; d.mp_d2 = (T)s.mp_d2;
+    for (int i = 0; i <= MAXP; ++i) { d.h0[i] = (T)s.h0[i]; d.h1[i] = (T)s.h1[i]; d.h2[i] = (T)s.h2[i]; d.ty[i] = (T)s.ty[i]; }
+    d.p = s.p; d.power = s.power;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace covgram
+
+struct covgram_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    covgram::Workspace ws[4];  // 0: packed tile stream, 1: split-J partials, 2/3: host staging (device copies of a / y)
+    // options
+    int64_t dense_variant = 0;   // 0 scalar-cache broadcast (SMEM), 1 LDS-staged tiles
+    int64_t rows_per_lane = 0;   // 0 = auto
+    int64_t jsplit = 0;          // 0 = auto
+    int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
+    int num_cus = 256;
+    int live_handles = 0;
+};
+
+struct covgram_points {
+    covgram_ctx* ctx = nullptr;
+    void* dptr = nullptr;  // device pointer, point-major n×d
+    int64_t n = 0;
+    int32_t d = 0;
+    int32_t dtype = 0;
+    bool owns = false;
+};
+
+namespace covgram {
+
+int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out);
+inline size_t dtype_size(int dtype) { return dtype == COVGRAM_F64 ? 8 : 4; }
+
+// dispatch tables implemented in the per-family translation units -------------------------------
+struct DenseArgs {
+    const void* X; int64_t n; int32_t d;   // rows (raw user layout, stride d)
+    const void* P; int64_t m;              // packed [m][D + NRHS] stream
+    void* out;                             // partials [jsplit][NRHS][npad] or final y when jsplit == 1
+    int64_t npad; int64_t ldy;
+    int32_t nrhs; int32_t Dpad; int32_t NRpad;
+    int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
+    double alpha, beta;
+    const HostKernel* hk;
+    hipStream_t stream;
+};
+typedef int (*dense_launch_fn)(const DenseArgs&, int dtype);
+dense_launch_fn dense_launcher(int family);
+
+struct GradArgs {
+    const void* X; int64_t n; int32_t d;
+    const void* P; int64_t m;              // packed [m][2*D] stream: y_j (scaled) then a_j
+    void* out; int64_t npad;               // partials [jsplit][npad][D] or final
+    int32_t Dpad; int64_t jchunk; int32_t jsplit;
+    double alpha, beta;
+    const HostKernel* hk;
+    hipStream_t stream;
+};
+typedef int (*grad_launch_fn)(const GradArgs&, int dtype);
+grad_launch_fn grad_launcher(int family);
+
+int pad_dim(int d);          // next compiled D >= d, or -1
+extern const int kDims[];    // compiled D list
+extern const int kNumDims;
+
+}  // namespace covgram

@@ -1,0 +1,219 @@
+// profiles.hpp — device functors for the scalar kernel profiles phi(s) and (phi, phi', phi'').
+// One functor per covgram_family; T = float uses bare gfx950 transcendental instructions
+// (v_exp_f32, v_log_f32, v_sqrt_f32, v_rcp_f32, v_rsq_f32 — 1 ulp), T = double uses the device libm.
+// Reference definitions: src/stationary.jl:42,53,60,71,132-158,224,235; src/mercer.jl:9,22;
+// src/algebra.jl:61-62 (Power); src/transformation.jl:19 (Lengthscale, folded into the coordinate
+// pre-scale gamma = 1/l by the host); derivatives: closed forms of src/gradient.jl:584-600.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace covgram {
+
+// ---- math shims --------------------------------------------------------------------------------
+__device__ __forceinline__ float cg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double cg_exp2(double x) { return exp2(x); }
+__device__ __forceinline__ float cg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ double cg_exp(double x) { return exp(x); }
+__device__ __forceinline__ float cg_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ double cg_log2(double x) { return log2(x); }
+__device__ __forceinline__ float cg_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double cg_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float cg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double cg_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float cg_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double cg_rsqrt(double x) { return 1.0 / sqrt(x); }
+// u^e for u > 0 (u == 0 handled by callers where it can occur)
+__device__ __forceinline__ float cg_pow(float u, float e) { return cg_exp2(e * cg_log2(u)); }
+__device__ __forceinline__ double cg_pow(double u, double e) { return pow(u, e); }
+template <typename T>
+__device__ __forceinline__ T cg_fma(T a, T b, T c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float cg_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T horner(const T* h, int deg, T r) {
+    T acc = h[deg];
+    for (int m = deg - 1; m >= 0; --m) acc = cg_fma(acc, r, h[m]);
+    return acc;
+}
+
+// integer power by repeated multiplication (uniform exponent)
+template <typename T>
+__device__ __forceinline__ T ipow(T v, int q) {
+    T r = v;
+    for (int i = 1; i < q; ++i) r *= v;
+    return r;
+}
+
+// ---- value functors: s is already divided by l^2 (and, for folded EQ, times log2(e)/2) ---------
+template <int FAM, typename T, bool FOLDED>
+struct Phi;
+
+template <typename T, bool FOLDED>
+struct Phi<COVGRAM_EQ, T, FOLDED> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        if constexpr (FOLDED) return cg_exp2(-s);       // one v_exp_f32 with a free neg modifier
+        else return cg_exp2(s * kp.c0);                 // c0 = -log2(e)/2
+    }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_EXP, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(-cg_sqrt(s)); }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_RQ, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        T u = cg_fma(s, kp.c0, (T)1);                   // 1 + s/(2 alpha)
+        return cg_pow(u, -kp.param);
+    }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_GAMMAEXP, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        // s^(gamma/2); s == 0 -> 0 (gamma > 0) — log2(0) = -inf, exp2(-inf) = 0
+        T t = (kp.param == (T)0) ? (T)1 : cg_pow(s, kp.param);
+        return cg_exp((T)-0.5 * t);
+    }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_CAUCHY, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_rcp((T)1 + s); }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_IMQ, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) { return cg_rsqrt(s + kp.param); }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_MATERNP, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        T r = cg_sqrt(kp.mp_c * s);
+        T v = horner(kp.h0, kp.p, r) * cg_exp(-r);
+        T t = horner(kp.ty, kp.p, s);                   // Taylor branch (src/stationary.jl:139-146)
+        return (s < kp.mp_bound) ? t : v;
+    }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_DOT, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return s; }
+};
+template <typename T, bool F>
+struct Phi<COVGRAM_EXPDOT, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(s); }
+};
+
+template <int FAM, typename T, bool FOLDED, bool POW>
+__device__ __forceinline__ T phi_value(T s, const KParams<T>& kp) {
+    T v = Phi<FAM, T, FOLDED>::eval(s, kp);
+    if constexpr (POW) v = ipow(v, kp.power);
+    return v;   // Constant scale is folded into alpha by the host
+}
+
+// ---- (phi, phi', phi'') w.r.t. the pre-scaled argument s' = gamma^2 s ---------------------------
+template <int FAM, typename T>
+struct DPhi;
+
+template <typename T>
+struct DPhi<COVGRAM_EQ, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        v = cg_exp2(s * kp.c0); d1 = (T)-0.5 * v; d2 = (T)0.25 * v;
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_EXP, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
+        T rt = cg_sqrt(s); v = cg_exp(-rt);
+        T ir = cg_rcp(rt);                               // s == 0: inf, like the reference's ForwardDiff
+        d1 = (T)-0.5 * v * ir;
+        d2 = (T)0.25 * v * (ir * ir + ir * ir * ir);
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_RQ, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        T a = kp.param;
+        T u = cg_fma(s, kp.c0, (T)1);
+        T iu = cg_rcp(u);
+        v = cg_pow(u, -a);
+        d1 = (T)-0.5 * v * iu;
+        d2 = (a + (T)1) * ((T)0.5 * kp.c0) * v * iu * iu;   // (a+1)/(4a) u^(-a-2)
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_GAMMAEXP, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        T g = kp.param;                                   // gamma / 2
+        T sg = (g == (T)0) ? (T)1 : cg_pow(s, g);
+        T is = cg_rcp(s);
+        v = cg_exp((T)-0.5 * sg);
+        T hg = (T)0.5 * g;
+        d1 = -hg * sg * is * v;
+        d2 = v * (hg * hg * sg * sg * is * is - hg * (g - (T)1) * sg * is * is);
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_CAUCHY, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
+        v = cg_rcp((T)1 + s); d1 = -v * v; d2 = (T)2 * v * v * v;
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_IMQ, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        T iu = cg_rcp(s + kp.param);
+        v = cg_rsqrt(s + kp.param); d1 = (T)-0.5 * v * iu; d2 = (T)0.75 * v * iu * iu;
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_MATERNP, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        const int p = kp.p;
+        T r = cg_sqrt(kp.mp_c * s);
+        T e = cg_exp(-r);
+        v = horner(kp.h0, p, r) * e;
+        if (p == 0) {                                     // Exp profile (singular at 0)
+            T ir = cg_rcp(r);
+            d1 = (T)-0.5 * e * ir; d2 = (T)0.25 * e * (ir * ir + ir * ir * ir);
+            return;
+        }
+        d1 = kp.mp_d1 * horner(kp.h1, p - 1, r) * e;      // d/dr[r^nu K_nu] = -r^nu K_{nu-1}
+        if (p >= 2) d2 = kp.mp_d2 * horner(kp.h2, p - 2, r) * e;
+        else d2 = -kp.mp_d1 * e * kp.mp_c * (T)0.5 * cg_rcp(r);
+        if (s < kp.mp_bound) {                            // polynomial branch, differentiated termwise
+            v = horner(kp.ty, p, s);
+            T t1 = (T)0, t2 = (T)0;
+            for (int i = p; i >= 1; --i) t1 = cg_fma(t1, s, kp.ty[i] * (T)i);
+            for (int i = p; i >= 2; --i) t2 = cg_fma(t2, s, kp.ty[i] * (T)(i * (i - 1)));
+            d1 = t1; d2 = t2;
+        }
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_DOT, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
+        v = s; d1 = (T)1; d2 = (T)0;
+    }
+};
+template <typename T>
+struct DPhi<COVGRAM_EXPDOT, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
+        v = cg_exp(s); d1 = v; d2 = v;
+    }
+};
+
+template <int FAM, typename T>
+__device__ __forceinline__ void phi_derivs(T s, const KParams<T>& kp, T& d1, T& d2) {
+    T v;
+    DPhi<FAM, T>::eval(s, kp, v, d1, d2);
+    const int q = kp.power;
+    if (q != 1) {  // (phi^q)' , (phi^q)'' — uniform branch, once per n² block (O(d) work follows)
+        T vq2 = (q >= 2) ? ((q == 2) ? (T)1 : ipow(v, q - 2)) : (T)0;
+        T vq1 = vq2 * v;
+        if (q < 2) vq1 = (T)1;
+        T n2 = (T)(q * (q - 1)) * vq2 * d1 * d1 + (T)q * vq1 * d2;
+        d1 = (T)q * vq1 * d1;
+        d2 = n2;
+    }
+}
+
+}  // namespace covgram

@@ -1,0 +1,219 @@
+// structured.hip — Kronecker and low-rank MVMs.
+//
+// Kronecker: gramian(::SeparableProduct, ::LazyGrid, ::LazyGrid) = kronecker(G_1, ..., G_q)
+// (src/algebra.jl:91-95) and kronecker(G) = gramian(k.k, x, y) ⊗ B for SeparableKernel
+// (src/separable.jl:33-42); the MVM is KroneckerProducts 1.1.1 (third party, source not in the
+// reference tree) — restated from the identity it implements: with a viewed as a c_1×...×c_q tensor
+// (first factor = slowest index), (F_1 ⊗ ... ⊗ F_q) a = a ×_1 F_1 ×_2 F_2 ... ×_q F_q (mode products).
+// Each mode product is a batched small GEMM  Out[b] (r_k × post) = F_k (r_k × c_k) · T[b] (c_k × post).
+//
+// Low rank: gramian(k::FiniteBasis, x, y) = LazyMatrixProduct(U, V') (src/mercer.jl:61-70) whose
+// mul! applies the factors right to left (src/lazy_linear_algebra.jl:78-85): y = α U (Vᵀ a) + β y.
+// For a vector right-hand side both products are GEMVs, i.e. HBM-streaming of U and V.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace covgram {
+
+// C[b][i][j] = sum_k F[i + k*ldf] * B[b][k][j];  B, C row-major per batch: B[b] is (K × N) with row
+// stride N, C[b] is (M × N).  32×32 output tile per workgroup, K staged through LDS in slabs of 32.
+template <typename T>
+__global__ __launch_bounds__(256) void mode_product_kernel(const T* __restrict__ F, int64_t ldf, int64_t M, int64_t K,
+                                                           const T* __restrict__ B, T* __restrict__ C, int64_t N) {
+    __shared__ T sF[32][33];
+    __shared__ T sB[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 × 8
+    const int64_t b = blockIdx.z;
+    const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+    const T* Bb = B + b * K * N;
+    T* Cb = C + b * M * N;
+    T acc[4] = {0, 0, 0, 0};
+    for (int64_t k0 = 0; k0 < K; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            // sF[i][k] = F[i0+i, k0+k]  (column-major F: consecutive tx walk k -> stride ldf; small factors, L2-resident)
+            const int64_t i = i0 + r, k = k0 + tx;
+            sF[r][tx] = (i < M && k < K) ? F[i + k * ldf] : (T)0;
+            const int64_t kk = k0 + r, j = j0 + tx;
+            sB[r][tx] = (kk < K && j < N) ? Bb[kk * N + j] : (T)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const T bv = sB[k][tx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(sF[ty + 8 * q][k], bv, acc[q]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = i0 + ty + 8 * q, j = j0 + tx;
+        if (i < M && j < N) Cb[i * N + j] = acc[q];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ t, T* __restrict__ y, int64_t n, T alpha, T beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T v = alpha * t[i];
+    if (beta != (T)0) v = __builtin_fma(beta, y[i], v);
+    y[i] = v;
+}
+
+// z[k] (+)= sum_{j in slab} V[j + k*ldv] a[j]; one workgroup per (column k, row slab); deterministic two-stage sum
+template <typename T>
+__global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ V, int64_t ldv, int64_t m, const T* __restrict__ a,
+                                                          T* __restrict__ zpart, int nslab) {
+    const int k = blockIdx.x, sl = blockIdx.y;
+    const int64_t per = (m + nslab - 1) / nslab;
+    const int64_t j0 = sl * per, j1 = std::min<int64_t>(m, j0 + per);
+    const T* col = V + (int64_t)k * ldv;
+    T s = (T)0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) s = __builtin_fma(col[j], a[j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ T ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) zpart[(int64_t)sl * gridDim.x + k] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// y[i] = alpha * sum_k U[i + k*ldu] * (sum_slab zpart[slab][k]) + beta * y[i]
+template <typename T>
+__global__ __launch_bounds__(256) void lowrank_uz_kernel(const T* __restrict__ U, int64_t ldu, int64_t n, int64_t r,
+                                                         const T* __restrict__ zpart, int nslab, T* __restrict__ y, T alpha, T beta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* z = reinterpret_cast<T*>(smem);
+    for (int64_t k = threadIdx.x; k < r; k += 256) {
+        T s = (T)0;
+        for (int sl = 0; sl < nslab; ++sl) s += zpart[(int64_t)sl * r + k];
+        z[k] = s;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    T s = (T)0;
+    for (int64_t k = 0; k < r; ++k) s = __builtin_fma(U[i + k * ldu], z[k], s);
+    T v = alpha * s;
+    if (beta != (T)0) v = __builtin_fma(beta, y[i], v);
+    y[i] = v;
+}
+
+template <typename T>
+static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols, const int64_t* lds,
+                    int q, const T* a_dev, T* y_dev, T alpha, T beta, T* bufA, T* bufB) {
+    // current tensor dims: first the already-multiplied modes (rows), then the remaining (cols)
+    int64_t cur = 1;
+    for (int i = 0; i < q; ++i) cur *= cols[i];
+    const T* src = a_dev;
+    T* dst = bufA;
+    for (int k = 0; k < q; ++k) {
+        int64_t pre = 1, post = 1;
+        for (int i = 0; i < k; ++i) pre *= rows[i];
+        for (int i = k + 1; i < q; ++i) post *= cols[i];
+        const int64_t M = rows[k], K = cols[k];
+        dim3 grid((unsigned)((post + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)pre);
+        hipLaunchKernelGGL(mode_product_kernel<T>, grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst, post);
+        src = dst;
+        dst = (dst == bufA) ? bufB : bufA;
+    }
+    int64_t nout = 1;
+    for (int i = 0; i < q; ++i) nout *= rows[i];
+    hipLaunchKernelGGL(axpby_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, ctx->stream, src, y_dev, nout, alpha, beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("kron_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+}  // namespace covgram
+
+using namespace covgram;
+
+extern "C" {
+
+int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols, const int64_t* lds,
+                     int32_t q, int32_t dtype, const void* a, void* y, double alpha, double beta, int32_t loc) {
+    CG_REQUIRE(ctx && factors && rows && cols && lds && a && y, COVGRAM_EINVAL, "NULL argument");
+    CG_REQUIRE(q >= 1 && q <= 16, COVGRAM_EINVAL, "kron: need 1 <= q <= 16 factors");
+    CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
+    const size_t ts = dtype_size(dtype);
+    int64_t nin = 1, nout = 1, maxel = 1;
+    for (int i = 0; i < q; ++i) {
+        CG_REQUIRE(rows[i] >= 1 && cols[i] >= 1 && lds[i] >= rows[i], COVGRAM_EINVAL, "kron: bad factor %d shape", i);
+        nin *= cols[i]; nout *= rows[i];
+    }
+    {   // largest intermediate tensor
+        int64_t cur = nin;
+        maxel = cur;
+        for (int k = 0; k < q; ++k) { cur = cur / cols[k] * rows[k]; maxel = std::max(maxel, cur); }
+    }
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    // workspace: [bufA | bufB | staged a | staged y | staged factors]
+    size_t fbytes = 0;
+    if (loc == COVGRAM_HOST) for (int i = 0; i < q; ++i) fbytes += (size_t)rows[i] * cols[i] * ts;
+    const size_t need = 2 * (size_t)maxel * ts + ((loc == COVGRAM_HOST) ? ((size_t)nin + nout) * ts + fbytes : 0) + 1024;
+    void* w; int rc = ws_reserve(ctx, 1, need, &w); if (rc) return rc;
+    char* base = (char*)w;
+    void* bufA = base; void* bufB = base + (size_t)maxel * ts;
+    const void* a_dev = a; void* y_dev = y;
+    const void* fdev[16]; int64_t ldd[16];
+    for (int i = 0; i < q; ++i) { fdev[i] = factors[i]; ldd[i] = lds[i]; }
+    if (loc == COVGRAM_HOST) {
+        char* p = base + 2 * (size_t)maxel * ts;
+        CG_CHECK_HIP(hipMemcpyAsync(p, a, (size_t)nin * ts, hipMemcpyHostToDevice, ctx->stream)); a_dev = p; p += (size_t)nin * ts;
+        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(p, y, (size_t)nout * ts, hipMemcpyHostToDevice, ctx->stream));
+        y_dev = p; p += (size_t)nout * ts;
+        for (int i = 0; i < q; ++i) {
+            CG_CHECK_HIP(hipMemcpy2DAsync(p, (size_t)rows[i] * ts, factors[i], (size_t)lds[i] * ts, (size_t)rows[i] * ts, cols[i], hipMemcpyHostToDevice, ctx->stream));
+            fdev[i] = p; ldd[i] = rows[i]; p += (size_t)rows[i] * cols[i] * ts;
+        }
+    }
+    if (dtype == COVGRAM_F32) rc = kron_run<float>(ctx, fdev, rows, cols, ldd, q, (const float*)a_dev, (float*)y_dev, (float)alpha, (float)beta, (float*)bufA, (float*)bufB);
+    else rc = kron_run<double>(ctx, fdev, rows, cols, ldd, q, (const double*)a_dev, (double*)y_dev, alpha, beta, (double*)bufA, (double*)bufB);
+    if (rc) return rc;
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)nout * ts, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return COVGRAM_OK;
+}
+
+int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void* V, int64_t ldv, int64_t n, int64_t m, int64_t r,
+                        int32_t dtype, const void* a, void* y, double alpha, double beta, int32_t loc) {
+    CG_REQUIRE(ctx && U && V && a && y, COVGRAM_EINVAL, "NULL argument");
+    CG_REQUIRE(n >= 1 && m >= 1 && r >= 1 && ldu >= n && ldv >= m, COVGRAM_EINVAL, "lowrank: bad shape");
+    CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
+    CG_REQUIRE(r <= 8192, COVGRAM_EUNSUPPORTED, "lowrank: r = %lld exceeds 8192", (long long)r);
+    const size_t ts = dtype_size(dtype);
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    const int nslab = (int)std::max<int64_t>(1, std::min<int64_t>(64, m / 16384));
+    size_t need = (size_t)nslab * r * ts + 256;
+    if (loc == COVGRAM_HOST) need += ((size_t)n * r + (size_t)m * r + m + n) * ts;
+    void* w; int rc = ws_reserve(ctx, 1, need, &w); if (rc) return rc;
+    char* p = (char*)w;
+    void* zpart = p; p += (((size_t)nslab * r * ts) + 255) & ~(size_t)255;
+    const void *Ud = U, *Vd = V, *ad = a; void* yd = y; int64_t ldud = ldu, ldvd = ldv;
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpy2DAsync(p, (size_t)n * ts, U, (size_t)ldu * ts, (size_t)n * ts, r, hipMemcpyHostToDevice, ctx->stream)); Ud = p; ldud = n; p += (size_t)n * r * ts;
+        CG_CHECK_HIP(hipMemcpy2DAsync(p, (size_t)m * ts, V, (size_t)ldv * ts, (size_t)m * ts, r, hipMemcpyHostToDevice, ctx->stream)); Vd = p; ldvd = m; p += (size_t)m * r * ts;
+        CG_CHECK_HIP(hipMemcpyAsync(p, a, (size_t)m * ts, hipMemcpyHostToDevice, ctx->stream)); ad = p; p += (size_t)m * ts;
+        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(p, y, (size_t)n * ts, hipMemcpyHostToDevice, ctx->stream));
+        yd = p;
+    }
+    if (dtype == COVGRAM_F32) {
+        hipLaunchKernelGGL(lowrank_vta_kernel<float>, dim3((unsigned)r, (unsigned)nslab), dim3(256), 0, ctx->stream, (const float*)Vd, ldvd, m, (const float*)ad, (float*)zpart, nslab);
+        hipLaunchKernelGGL(lowrank_uz_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)r * ts, ctx->stream, (const float*)Ud, ldud, n, r, (const float*)zpart, nslab, (float*)yd, (float)alpha, (float)beta);
+    } else {
+        hipLaunchKernelGGL(lowrank_vta_kernel<double>, dim3((unsigned)r, (unsigned)nslab), dim3(256), 0, ctx->stream, (const double*)Vd, ldvd, m, (const double*)ad, (double*)zpart, nslab);
+        hipLaunchKernelGGL(lowrank_uz_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)r * ts, ctx->stream, (const double*)Ud, ldud, n, r, (const double*)zpart, nslab, (double*)yd, alpha, beta);
+    }
+    CG_CHECK_HIP(hipGetLastError());
+    if (loc == COVGRAM_HOST) {
+        CG_CHECK_HIP(hipMemcpyAsync(y, yd, (size_t)n * ts, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return COVGRAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+/* covgram.h — C ABI of libcovgram.so, the MI355X (gfx950) lazy-Gramian MVM engine.
+ *
+ * Drop-in boundary for ONE hot path of SebastianAment/CovarianceFunctions.jl (v0.3.5):
+ *     mul!(b, gramian(k, x[, y]), a, α, β)
+ * and its structured siblings.  The reference is pure Julia with no FFI of its own, so the
+ * boundary is the set of Julia methods listed below; a Julia shim (`ccall`) or the Python
+ * `ctypes` binding in covariancefunctions.jl_amd/covgram/_ffi.py binds exactly these symbols.
+ * Citations are file:line relative to the reference repository root.
+ *
+ *   covgram_mvm            replaces  LinearAlgebra.mul!(y::AbstractVector, G::Gramian, x, α, β)   src/gramian.jl:78-87
+ *                          and       LinearAlgebra.mul!(Y::AbstractMatrix, G::Gramian, X, α, β)   src/gramian.jl:89-99
+ *                          and       Base.:*(G::Gramian, a)                                       src/gramian.jl:66-75
+ *   covgram_matrix         replaces  Base.Matrix(G::Gramian) / Matrix!                            src/gramian.jl:102-114
+ *   covgram_grad_mvm       replaces  BlockFactorizations.blockmul!(y, G::Gramian, x, α, β)        src/gramian.jl:241-257
+ *                          with the  GradientKernelElement mul! (isotropic / dot-product)         src/gradient.jl:86-92, 109-115
+ *   covgram_toeplitz_*     replaces  mul!(y, ::SymmetricToeplitz/Toeplitz/Circulant, a, α, β) of ToeplitzMatrices 0.7.1 as
+ *                          constructed by gramian(k, x::StepRangeLen, y::StepRangeLen)            src/gramian.jl:167-189
+ *   covgram_kron_mvm       replaces  mul!(y, ::KroneckerProduct, a) of KroneckerProducts 1.1.1 as constructed at
+ *                                                                                                 src/algebra.jl:91-95, src/separable.jl:33-42
+ *   covgram_lowrank_mvm    replaces  mul!(y, L::LazyMatrixProduct(U, V'), a, α, β)                src/lazy_linear_algebra.jl:78-85
+ *                          as built by gramian(k::FiniteBasis, x, y)                              src/mercer.jl:61-70
+ *   covgram_kernel         encodes   the kernel value k together with input_trait(k)              src/properties.jl:31-45
+ *
+ * Conventions (same as the reference's at that boundary):
+ *   - the caller owns every buffer it passes; handles own only what the library allocated;
+ *   - points are point-major: d contiguous scalars per point (Julia d×n column-major matrix ==
+ *     Vector of d-vectors, src/gramian.jl:2,154-155);
+ *   - flat block vectors of the gradient Gramian are point-major (block i = entries i*d..i*d+d-1);
+ *   - matrices (right-hand sides, dense factors) are column-major with an explicit leading dimension;
+ *   - beta == 0 means the previous contents of y are NOT read (NaN-safe, src/gramian.jl:80,90,245);
+ *   - every function returns 0 on success and a negative covgram_status on failure; no exception
+ *     crosses the ABI; covgram_last_error() gives a thread-local message;
+ *   - unlike the reference (which runs @inbounds), dimension mismatches are reported as errors;
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device.
+ */
+#ifndef COVGRAM_H
+#define COVGRAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVGRAM_VERSION 100 /* 0.1.0 */
+
+typedef enum covgram_status {
+    COVGRAM_OK = 0,
+    COVGRAM_EINVAL = -1,       /* bad argument / dimension mismatch */
+    COVGRAM_EUNSUPPORTED = -2, /* kernel family / dimension / dtype outside the compiled set */
+    COVGRAM_EHIP = -3,         /* HIP / rocFFT runtime failure (message in covgram_last_error) */
+    COVGRAM_ENODEVICE = -4,    /* no gfx950 device visible: the product path fails loudly */
+    COVGRAM_ENOMEM = -5
+} covgram_status;
+
+/* Scalar profile phi(s); s = |x-y|^2 (isotropic) or x.y (dot product). */
+typedef enum covgram_family {
+    COVGRAM_EQ = 0,       /* exp(-s/2)                         src/stationary.jl:37-42   */
+    COVGRAM_EXP = 1,      /* exp(-sqrt(s))                     src/stationary.jl:56-60   */
+    COVGRAM_RQ = 2,       /* (1 + s/(2 alpha))^-alpha          src/stationary.jl:45-53   */
+    COVGRAM_GAMMAEXP = 3, /* exp(-s^(gamma/2)/2)               src/stationary.jl:63-71   */
+    COVGRAM_CAUCHY = 4,   /* 1/(1+s)                           src/stationary.jl:221-224 */
+    COVGRAM_IMQ = 5,      /* 1/sqrt(s + c^2)                   src/stationary.jl:231-235 */
+    COVGRAM_MATERNP = 6,  /* Matern nu = p + 1/2, 0 <= p <= 8  src/stationary.jl:117-158 */
+    COVGRAM_DOT = 7,      /* s                                 src/mercer.jl:6-9         */
+    COVGRAM_EXPDOT = 8,   /* exp(s)                            src/mercer.jl:19-22       */
+    COVGRAM_NFAMILY = 9
+} covgram_family;
+
+/* input_trait(k), src/properties.jl:31-45.  Only the two traits with a device path are encoded;
+ * GenericInput kernels never reach the library (the host falls back exactly as gramian.jl:78-87). */
+typedef enum covgram_trait { COVGRAM_ISOTROPIC = 1, COVGRAM_DOTPRODUCT = 2 } covgram_trait;
+
+typedef enum covgram_dtype { COVGRAM_F32 = 0, COVGRAM_F64 = 1 } covgram_dtype;
+typedef enum covgram_loc { COVGRAM_HOST = 0, COVGRAM_DEVICE = 1 } covgram_loc;
+
+#define COVGRAM_MATERNP_MAX_P 8
+
+typedef struct covgram_kernel {
+    int32_t family;     /* covgram_family */
+    int32_t trait;      /* covgram_trait; must agree with the family (checked) */
+    int32_t p;          /* MaternP order */
+    int32_t power;      /* Power(k, p) exponent, >= 1 (src/algebra.jl:50-63); 1 = none */
+    double param;       /* RQ alpha | gammaExp gamma | IMQ c */
+    double lengthscale; /* Lengthscale(k, l): s <- s/l^2, isotropic only (src/transformation.jl:6-19); 1 = none */
+    double scale;       /* Constant(c) * k (src/algebra.jl:23-25); 1 = none */
+} covgram_kernel;
+
+typedef struct covgram_ctx covgram_ctx;           /* one device + one stream + workspace + rocFFT plans */
+typedef struct covgram_points covgram_points;     /* device-resident point set (stays resident across MVMs) */
+typedef struct covgram_toeplitz covgram_toeplitz; /* cached circulant spectrum + plans */
+
+int covgram_version(void);
+const char* covgram_last_error(void);
+int covgram_device_count(int* count);
+
+/* hip_stream: a hipStream_t the caller owns (e.g. torch's current stream), or NULL for a library-owned one. */
+int covgram_ctx_create(covgram_ctx** ctx, int device_id, void* hip_stream);
+int covgram_ctx_destroy(covgram_ctx* ctx);
+int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream);
+int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
+/* tuning / A-B knobs, e.g. "dense_variant" (0 = scalar-cache broadcast, 1 = LDS-staged), "rows_per_lane", "jsplit". */
+int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
+int covgram_sync(covgram_ctx* ctx);
+
+/* x: n points of dimension d, point-major.  loc == HOST: copied to the device; loc == DEVICE: borrowed
+ * (the caller keeps it alive and unchanged while the handle lives). */
+int covgram_points_create(covgram_ctx* ctx, covgram_points** out, const void* x, int64_t n, int32_t d,
+                          int32_t dtype, int32_t loc);
+/* rows [first, first+count) of an existing handle (row shard for multi-GPU); borrows the parent's memory. */
+int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t count, covgram_points** out);
+int covgram_points_destroy(covgram_points* pts);
+int covgram_points_info(const covgram_points* pts, int64_t* n, int32_t* d, int32_t* dtype);
+
+/* y <- alpha * G(k; X, Y) * a + beta * y.   G is n×m (n = |X|, m = |Y|); a is m×nrhs (lda >= m),
+ * y is n×nrhs (ldy >= n), column-major; dtype is that of the points.  loc applies to a and y. */
+int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y,
+                const void* a, int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta,
+                int32_t loc);
+
+/* out[i + j*ldo] = k(x_i, y_j): dense instantiation of the n×m Gramian (column-major). */
+int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y,
+                   void* out, int64_t ldo, int32_t loc);
+
+/* Gradient-kernel Gramian (nd × md): y <- alpha * G a + beta * y with flat point-major block vectors
+ * a (length m*d) and y (length n*d). */
+int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,
+                     const covgram_points* Y, const void* a, void* y, double alpha, double beta, int32_t loc);
+
+/* Toeplitz T[i,j] = vc[i-j] (i >= j), vr[j-i] (i < j); vr == NULL: symmetric (vr = vc, m = n).
+ * circulant != 0: T[i,j] = vc[(i-j) mod n] (vr must be NULL).  The spectrum of the circulant embedding
+ * (N = next power of two >= n+m-1, real-to-complex rocFFT) is computed once here and cached. */
+int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void* vc, const void* vr, int64_t n,
+                            int64_t m, int32_t dtype, int32_t loc, int32_t circulant);
+int covgram_toeplitz_mvm(covgram_toeplitz* T, const void* a, void* y, double alpha, double beta, int32_t loc);
+int covgram_toeplitz_destroy(covgram_toeplitz* T);
+
+/* y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) a + beta * y, standard Kronecker order (F_1 = slowest index).
+ * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc). */
+int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols,
+                     const int64_t* lds, int32_t q, int32_t dtype, const void* a, void* y, double alpha,
+                     double beta, int32_t loc);
+
+/* y <- alpha * U (V' a) + beta * y;  U: n×r (ldu), V: m×r (ldv), column-major. */
+int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void* V, int64_t ldv, int64_t n,
+                        int64_t m, int64_t r, int32_t dtype, const void* a, void* y, double alpha, double beta,
+                        int32_t loc);
+
+/* Test hook: the double-precision parameter block handed to the device kernels for `k`
+ * (out45[0..8] = gamma, gamma^2, scale, param, c0, 2p+1, Taylor bound, d1, d2; then the MaternP tables
+ * H_p, H_{p-1}, H_{p-2} and Taylor coefficients, 9 doubles each).  Needs no device. */
+int covgram_debug_kernel_params(const covgram_kernel* k, int32_t dtype, int32_t for_gradient, double* out45);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVGRAM_H */

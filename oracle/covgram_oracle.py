@@ -1,0 +1,460 @@
+"""CPU oracle for the lazy-Gramian MVM hot path of CovarianceFunctions.jl (reference v0.3.5).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (`covariancefunctions.jl_amd/`)
+imports this file; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg may.  It is a plain numpy float64 (or float32 on request)
+restatement of the reference algorithm; every function cites the reference
+`file:line` (relative to /root/reference) it follows.
+
+PARITY PIN STATUS ("parity unpinned" in the strict sense of the task statement):
+the reference is pure Julia, Julia is not installed in the build container, and the
+reference ships NO golden vectors (all of its tests use unseeded randn and assert
+relations such as `G*a ≈ Matrix(G)*a`).  The oracle is therefore pinned by
+  (1) the reference's own test *relations*, re-asserted in tests/test_oracle.py;
+  (2) closed-form known answers (k(0)=1, MaternP(0)=exp(-r), EQ block = k(I - r r'));
+  (3) an independent 50-digit mpmath evaluation of the same definitions
+      (oracle/make_golden.py, committed together with the vectors it wrote).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from fractions import Fraction
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# kernel description (mirrors include/covgram.h :: covgram_kernel)
+# ----------------------------------------------------------------------------------------
+EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT = range(9)
+FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT"]
+ISOTROPIC, DOTPRODUCT = 1, 2
+
+
+@dataclass(frozen=True)
+class Kernel:
+    """family/trait/p/power/param/lengthscale/scale — same fields as the C struct."""
+    family: int
+    p: int = 0            # MaternP order (stationary.jl:117-121)
+    power: int = 1        # Power exponent (algebra.jl:50-63); 1 = none
+    param: float = 0.0    # RQ alpha (stationary.jl:45-53) | gammaExp gamma (:63-71) | IMQ c (:231-235)
+    lengthscale: float = 1.0  # Lengthscale(k, l): s <- s / l^2 (transformation.jl:6-19)
+    scale: float = 1.0    # Constant(c) * k (algebra.jl:23-25, stationary.jl:15-32)
+
+    @property
+    def trait(self) -> int:
+        # properties.jl:39-43: IsotropicKernel -> IsotropicInput, Dot/ExponentialDot -> DotProductInput,
+        # Power inherits the trait of its base kernel.
+        return DOTPRODUCT if self.family in (DOT, EXPDOT) else ISOTROPIC
+
+
+# ----------------------------------------------------------------------------------------
+# MaternP tables (stationary.jl:117-191)
+# ----------------------------------------------------------------------------------------
+MATERNP_MAX_P = 8
+
+
+def maternp_coefficients(p: int):
+    """stationary.jl:184-191: reverse([binomial(p,i) * (factorial(p+i) ÷ factorial(p)) for i in 1:p]).
+    Entry k (0-based) multiplies (2r)^k; the (2r)^p coefficient is the implicit 1."""
+    fp = math.factorial(p)
+    c = [Fraction(math.comb(p, i) * (math.factorial(p + i) // fp)) for i in range(1, p + 1)]
+    return list(reversed(c))
+
+
+def maternp_norm(p: int) -> int:
+    """stationary.jl:157: factorial(2p) ÷ factorial(p)."""
+    return math.factorial(2 * p) // math.factorial(p)
+
+
+def maternp_poly(p: int):
+    """Normalised polynomial q_p(r) = sum_m h[m] r^m with MaternP_p(s) = exp(-r) q_p(r), r = sqrt((2p+1)s).
+    (Expanded form of stationary.jl:147-157.)"""
+    c = maternp_coefficients(p) + [Fraction(1)]
+    nrm = maternp_norm(p)
+    return [c[m] * (2 ** m) / nrm for m in range(p + 1)]
+
+
+def _exp_neg_series(order: int):
+    return [Fraction((-1) ** k, math.factorial(k)) for k in range(order + 1)]
+
+
+def maternp_derivatives_at_zero(p: int):
+    """stationary.jl:172-182 (SymEngine there): d_i = d^i/d(r²)^i MaternP(r², p) at r² = 0, i = 1..p.
+    Derived here exactly with rationals from the power series of exp(-r) q_p(r): the odd powers of r
+    below r^(2p+1) cancel, and the r^(2i) coefficient times (2p+1)^i is d_i / i!."""
+    h = maternp_poly(p)
+    e = _exp_neg_series(2 * p)
+    c = 2 * p + 1
+    d = []
+    for i in range(1, p + 1):
+        coef = sum(h[m] * e[2 * i - m] for m in range(0, min(p, 2 * i) + 1))
+        d.append(coef * c ** i * math.factorial(i))
+    # sanity: odd coefficients vanish
+    for odd in range(1, 2 * p, 2):
+        assert sum(h[m] * e[odd - m] for m in range(0, min(p, odd) + 1)) == 0
+    return d
+
+
+def _eps(dtype) -> float:
+    return float(np.finfo(dtype).eps)
+
+
+# ----------------------------------------------------------------------------------------
+# scalar profiles phi(s), s = r² (isotropic) or x·y (dot product)
+# ----------------------------------------------------------------------------------------
+def _maternp(s, p: int, dtype):
+    """stationary.jl:132-158, including the Taylor guard `r² < eps(T)^(1/p)` (:136-146)."""
+    s = np.asarray(s, dtype=np.float64)
+    c = 2 * p + 1
+    r = np.sqrt(c * s)
+    coef = [float(v) for v in maternp_coefficients(p)]
+    y = np.zeros_like(s)
+    ri = np.ones_like(s)
+    for i in range(p):
+        y = y + coef[i] * ri
+        ri = ri * (2 * r)
+    y = y + ri
+    y = y * (np.exp(-r) / maternp_norm(p))
+    if p >= 1:
+        bound = _eps(dtype) ** (1.0 / p)
+        d = [float(v) for v in maternp_derivatives_at_zero(p)]
+        t = np.ones_like(s)
+        si = s.copy()
+        for i in range(1, p + 1):
+            t = t + d[i - 1] * si / math.factorial(i)
+            si = si * s
+        y = np.where(s < bound, t, y)
+    return y
+
+
+def profile(k: Kernel, s, dtype=np.float64):
+    """phi(s) for every family in scope.  `dtype` only selects eps(T) for the MaternP guard."""
+    s = np.asarray(s, dtype=np.float64)
+    if k.trait == ISOTROPIC and k.lengthscale != 1.0:
+        s = s / (k.lengthscale ** 2)                 # transformation.jl:19
+    f = k.family
+    if f == EQ:
+        v = np.exp(-s / 2)                           # stationary.jl:42
+    elif f == EXP:
+        v = np.exp(-np.sqrt(s))                      # stationary.jl:60
+    elif f == RQ:
+        v = (1 + s / (2 * k.param)) ** (-k.param)    # stationary.jl:53
+    elif f == GAMMAEXP:
+        v = np.exp(-(s ** (k.param / 2)) / 2)        # stationary.jl:71
+    elif f == CAUCHY:
+        v = 1.0 / (1 + s)                            # stationary.jl:224
+    elif f == IMQ:
+        v = 1.0 / np.sqrt(s + k.param ** 2)          # stationary.jl:235
+    elif f == MATERNP:
+        v = _maternp(s, k.p, dtype)                  # stationary.jl:132-158
+    elif f == DOT:
+        v = s                                        # mercer.jl:9
+    elif f == EXPDOT:
+        v = np.exp(s)                                # mercer.jl:22
+    else:
+        raise ValueError(f"unknown family {f}")
+    if k.power != 1:
+        v = v ** k.power                             # algebra.jl:61-62
+    if k.scale != 1.0:
+        v = k.scale * v                              # algebra.jl:17 with Constant (stationary.jl:30-32)
+    return v
+
+
+def _maternp_H(q: int, r):
+    h = [float(v) for v in maternp_poly(q)]
+    acc = np.zeros_like(r)
+    for m in range(q, -1, -1):
+        acc = acc * r + h[m]
+    return acc * np.exp(-r)
+
+
+def profile_derivatives(k: Kernel, s, dtype=np.float64):
+    """(phi, phi', phi'') w.r.t. s.  The reference obtains phi', phi'' by nested ForwardDiff
+    (gradient.jl:584-600); these are the closed forms of the same functions.
+    MaternP uses d/dr[r^nu K_nu] = -r^nu K_{nu-1}: phi_p' = d1 * H_{p-1}(r), phi_p'' = d2 * H_{p-2}(r)
+    at the same r = sqrt((2p+1)s), and the polynomial (Taylor) branch below eps^(1/p) exactly as
+    ForwardDiff differentiates stationary.jl:139-146."""
+    s = np.asarray(s, dtype=np.float64)
+    inner = 1.0
+    if k.trait == ISOTROPIC and k.lengthscale != 1.0:
+        inner = 1.0 / (k.lengthscale ** 2)
+        s = s * inner
+    f = k.family
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if f == EQ:
+            v = np.exp(-s / 2); d1 = -v / 2; d2 = v / 4
+        elif f == EXP:
+            rt = np.sqrt(s); v = np.exp(-rt)
+            d1 = -v / (2 * rt); d2 = v * (1 / (4 * s) + 1 / (4 * s * rt))
+        elif f == RQ:
+            a = k.param; u = 1 + s / (2 * a)
+            v = u ** (-a); d1 = -0.5 * u ** (-a - 1); d2 = (a + 1) / (4 * a) * u ** (-a - 2)
+        elif f == GAMMAEXP:
+            g = k.param / 2
+            v = np.exp(-(s ** g) / 2)
+            d1 = -(g / 2) * s ** (g - 1) * v
+            d2 = v * ((g / 2) ** 2 * s ** (2 * g - 2) - (g / 2) * (g - 1) * s ** (g - 2))
+        elif f == CAUCHY:
+            u = 1 + s; v = 1 / u; d1 = -1 / u ** 2; d2 = 2 / u ** 3
+        elif f == IMQ:
+            u = s + k.param ** 2
+            v = u ** -0.5; d1 = -0.5 * u ** -1.5; d2 = 0.75 * u ** -2.5
+        elif f == MATERNP:
+            p = k.p
+            v = _maternp(s, p, dtype)
+            c = 2 * p + 1
+            r = np.sqrt(c * s)
+            if p == 0:
+                d1 = -np.exp(-r) / (2 * r)
+                d2 = np.exp(-r) * (1 / (4 * s) + 1 / (4 * s * r))
+            else:
+                dz = [float(x) for x in maternp_derivatives_at_zero(p)]
+                d1 = dz[0] * _maternp_H(p - 1, r)
+                if p >= 2:
+                    d2 = dz[1] * _maternp_H(p - 2, r)
+                else:  # p == 1: phi' = d1 exp(-r) -> phi'' = -d1 exp(-r) c / (2 r)
+                    d2 = -dz[0] * np.exp(-r) * c / (2 * r)
+                bound = _eps(dtype) ** (1.0 / p)
+                t1 = np.zeros_like(s); t2 = np.zeros_like(s)
+                for i in range(1, p + 1):
+                    ci = dz[i - 1] / math.factorial(i)
+                    t1 = t1 + ci * i * s ** (i - 1)
+                    if i >= 2:
+                        t2 = t2 + ci * i * (i - 1) * s ** (i - 2)
+                d1 = np.where(s < bound, t1, d1)
+                d2 = np.where(s < bound, t2, d2)
+        elif f == DOT:
+            v = s; d1 = np.ones_like(s); d2 = np.zeros_like(s)
+        elif f == EXPDOT:
+            v = np.exp(s); d1 = v; d2 = v
+        else:
+            raise ValueError(f"unknown family {f}")
+        d1 = d1 * inner
+        d2 = d2 * inner * inner
+        if k.power != 1:
+            q = k.power
+            # (phi^q)' = q phi^(q-1) phi' ; (phi^q)'' = q(q-1) phi^(q-2) phi'^2 + q phi^(q-1) phi''
+            vq2 = v ** (q - 2) if q >= 2 else np.zeros_like(v)
+            d2 = q * (q - 1) * vq2 * d1 * d1 + q * v ** (q - 1) * d2
+            d1 = q * v ** (q - 1) * d1
+            v = v ** q
+        if k.scale != 1.0:
+            v = k.scale * v; d1 = k.scale * d1; d2 = k.scale * d2
+    return v, d1, d2
+
+
+# ----------------------------------------------------------------------------------------
+# points: (n, d) C-contiguous array == Julia's d×n column-major matrix / vector of d-vectors
+# ----------------------------------------------------------------------------------------
+def as_points(x):
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    return x
+
+
+def pair_arg(k: Kernel, X, Y):
+    """s[i,j]: euclidean2 by DIRECT differences (util.jl:40-47) or dot(x,y) (mercer.jl:3)."""
+    X = as_points(X).astype(np.float64); Y = as_points(Y).astype(np.float64)
+    if X.shape[1] != Y.shape[1]:
+        raise ValueError("DimensionMismatch: inputs have to have the same length")  # util.jl:41
+    if k.trait == ISOTROPIC:
+        s = np.zeros((X.shape[0], Y.shape[0]))
+        for l in range(X.shape[1]):
+            diff = X[:, l][:, None] - Y[:, l][None, :]
+            s += diff * diff
+        return s
+    return X @ Y.T
+
+
+def matrix(k: Kernel, X, Y=None, dtype=np.float64):
+    """Matrix(G) (gramian.jl:102-114): G[i,j] = k(x[i], y[j]) (gramian.jl:37-40)."""
+    Y = X if Y is None else Y
+    return profile(k, pair_arg(k, X, Y), dtype)
+
+
+def mul(y, k: Kernel, X, Y, a, alpha=1.0, beta=0.0, dtype=np.float64, chunk=2048):
+    """mul!(y, G, a, α, β) for vector or matrix right-hand sides (gramian.jl:78-99).
+    β == 0 ⇒ previous contents of y (NaN included) are discarded (gramian.jl:80,90)."""
+    X = as_points(X); Y = as_points(X if Y is None else Y)
+    a = np.asarray(a, dtype=np.float64)
+    n = X.shape[0]
+    out = np.zeros((n,) + a.shape[1:], dtype=np.float64)
+    if beta != 0:
+        out += beta * np.asarray(y, dtype=np.float64)
+    for i0 in range(0, n, chunk):
+        G = matrix(k, X[i0:i0 + chunk], Y, dtype)
+        out[i0:i0 + chunk] += alpha * (G @ a)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# GradientKernel (gradient.jl:7-24) block MVM
+# ----------------------------------------------------------------------------------------
+def grad_block(k: Kernel, x, y, dtype=np.float64):
+    """Dense d×d block ∂x∂y' k(x,y) = K * I (gradient.jl:58: Matrix(K) = K * I(d))."""
+    x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    d = x.shape[0]
+    if k.trait == ISOTROPIC:
+        r = x - y
+        _, k1, k2 = profile_derivatives(k, float(r @ r), dtype)
+        return -2 * (k1 * np.eye(d) + 2 * k2 * np.outer(r, r))     # gradient.jl:86-92
+    _, k1, k2 = profile_derivatives(k, float(x @ y), dtype)
+    return k1 * np.eye(d) + k2 * np.outer(y, x)                     # gradient.jl:109-115
+
+
+def grad_mul(yv, k: Kernel, X, Y, a, alpha=1.0, beta=0.0, dtype=np.float64, chunk=256):
+    """blockmul!(y, G, x, α, β) (gramian.jl:241-253) with the per-block mul! of
+    gradient.jl:86-92 (IsotropicInput) / :109-115 (DotProductInput).
+    Flat vectors are point-major: block i = entries i*d .. (i+1)*d-1 (BlockFactorizations strided)."""
+    X = as_points(X).astype(np.float64); Y = as_points(X if Y is None else Y).astype(np.float64)
+    n, d = X.shape; m = Y.shape[0]
+    A = np.asarray(a, dtype=np.float64).reshape(m, d)
+    out = np.zeros((n, d))
+    if beta != 0:
+        out += beta * np.asarray(yv, dtype=np.float64).reshape(n, d)
+    for i0 in range(0, n, chunk):
+        Xi = X[i0:i0 + chunk]
+        if k.trait == ISOTROPIC:
+            R = Xi[:, None, :] - Y[None, :, :]                     # r = difference(x, y)
+            s = np.einsum("ijl,ijl->ij", R, R)                     # r² = sum(abs2, r)
+            _, k1, k2 = profile_derivatives(k, s, dtype)           # derivative_laplacian
+            ra = np.einsum("ijl,jl->ij", R, A)                     # dot_r_a = r'a
+            blk = -2 * (k1[:, :, None] * A[None] + 2 * (k2 * ra)[:, :, None] * R)
+            if blk.size and not np.all(np.isfinite(blk)):
+                pass  # non-differentiable profiles at s = 0 propagate NaN/Inf like the reference
+            out[i0:i0 + chunk] += alpha * blk.sum(axis=1)
+        else:
+            s = Xi @ Y.T                                           # d² = dot(x, y)
+            _, k1, k2 = profile_derivatives(k, s, dtype)
+            xa = Xi @ A.T                                          # dot_x_a = x'a
+            out[i0:i0 + chunk] += alpha * (k1 @ A + (k2 * xa) @ Y)
+    return out.reshape(-1)
+
+
+def grad_matrix(k: Kernel, X, Y=None, dtype=np.float64):
+    X = as_points(X); Y = as_points(X if Y is None else Y)
+    n, d = X.shape; m = Y.shape[0]
+    M = np.zeros((n * d, m * d))
+    for i in range(n):
+        for j in range(m):
+            M[i * d:(i + 1) * d, j * d:(j + 1) * d] = grad_block(k, X[i], Y[j], dtype)
+    return M
+
+
+# ----------------------------------------------------------------------------------------
+# Toeplitz (gramian.jl:167-189; MVM is ToeplitzMatrices 0.7.1 — restated from its published
+# algorithm: circulant embedding + FFT)
+# ----------------------------------------------------------------------------------------
+def srange(start, stop, length):
+    """Julia's range(start, stop, length) as (start, step, length)."""
+    step = (stop - start) / (length - 1) if length > 1 else 0.0
+    return (float(start), float(step), int(length))
+
+
+def srange_points(rg):
+    x0, h, n = rg
+    return x0 + h * np.arange(n, dtype=np.float64)
+
+
+def toeplitz_vectors(k: Kernel, xr, yr=None, periodic=False, dtype=np.float64):
+    """vc (first column) and vr (first row) as gramian.jl:172-189 forms them:
+    x === y: vc = k.(x[1], x) → SymmetricToeplitz; same step: vc = k.(x, y[1]), vr = k.(x[1], y)."""
+    x = srange_points(xr)
+    if yr is None or yr == xr:
+        vc = profile(k, (x[0] - x) ** 2 if k.trait == ISOTROPIC else x[0] * x, dtype)
+        return vc, None
+    y = srange_points(yr)
+    if abs(xr[1] - yr[1]) > 0:
+        raise ValueError("different step: reference falls back to a plain Gramian (gramian.jl:180-182)")
+    vc = profile(k, (x - y[0]) ** 2, dtype)
+    vr = profile(k, (x[0] - y) ** 2, dtype)
+    return vc, vr
+
+
+def toeplitz_dense(vc, vr=None, circulant=False):
+    vc = np.asarray(vc, dtype=np.float64)
+    n = vc.shape[0]
+    if circulant:
+        idx = (np.arange(n)[:, None] - np.arange(n)[None, :]) % n
+        return vc[idx]
+    vr = vc if vr is None else np.asarray(vr, dtype=np.float64)
+    m = vr.shape[0]
+    i = np.arange(n)[:, None]; j = np.arange(m)[None, :]
+    return np.where(i >= j, vc[np.clip(i - j, 0, n - 1)], vr[np.clip(j - i, 0, m - 1)])
+
+
+def toeplitz_mul(y, vc, vr, a, alpha=1.0, beta=0.0, circulant=False):
+    """y ← α T a + β y by circulant embedding of size N ≥ n+m-1 (any such N gives the exact product)."""
+    vc = np.asarray(vc, dtype=np.float64); a = np.asarray(a, dtype=np.float64)
+    n = vc.shape[0]
+    if circulant:
+        t = np.fft.irfft(np.fft.rfft(vc) * np.fft.rfft(a), n)
+    else:
+        vr_ = vc if vr is None else np.asarray(vr, dtype=np.float64)
+        m = vr_.shape[0]
+        N = 1 << int(math.ceil(math.log2(max(n + m - 1, 2))))
+        c = np.zeros(N)
+        c[:n] = vc
+        if m > 1:
+            c[N - (m - 1):] = vr_[1:][::-1]
+        ap = np.zeros(N); ap[:m] = a
+        t = np.fft.irfft(np.fft.rfft(c) * np.fft.rfft(ap), N)[:n]
+    out = alpha * t
+    if beta != 0:
+        out = out + beta * np.asarray(y, dtype=np.float64)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# Kronecker (algebra.jl:91-95, separable.jl:33-35, lazy_grid.jl:20-38; MVM is KroneckerProducts 1.1.1,
+# restated from the identity (A ⊗ B) vec(V) = vec(B V Aᵀ) with column-major vec)
+# ----------------------------------------------------------------------------------------
+def lazy_grid_points(axes, rowmajor=False):
+    """LazyGrid enumeration: default (lazy_grid.jl:20-38) the FIRST axis varies fastest;
+    rowmajor=True (lazy_grid.jl:40-58) the LAST axis varies fastest."""
+    axes = [np.asarray(a, dtype=np.float64) for a in axes]
+    mesh = np.meshgrid(*axes, indexing="ij")
+    order = "C" if rowmajor else "F"
+    return np.stack([g.reshape(-1, order=order) for g in mesh], axis=1)
+
+
+def kron_dense(factors):
+    """Matrix(kronecker(G1, ..., Gq)) = G1 ⊗ ... ⊗ Gq, the standard Kronecker product (first factor =
+    slowest index), which is what algebra.jl:94 and separable.jl:34 build.
+    NOTE (reference quirk, kept): LazyGrid's default enumeration (lazy_grid.jl:20-38) makes the FIRST
+    axis the fastest index, so for non-identical factors kronecker(G1..Gq) equals the dense Gramian on
+    the ROW-major enumeration (lazy_grid.jl:40-58), not the default one.  The reference's only test
+    (test/algebra.jl:70-89) uses identical factors, where both orders coincide."""
+    out = np.asarray(factors[0], dtype=np.float64)
+    for f in factors[1:]:
+        out = np.kron(out, np.asarray(f, dtype=np.float64))
+    return out
+
+
+def kron_mul(y, factors, a, alpha=1.0, beta=0.0):
+    """(F1 ⊗ F2 ⊗ ... ⊗ Fq) a by successive mode products; standard Kronecker order
+    (F1 index slowest).  a has length prod(cols)."""
+    fs = [np.asarray(f, dtype=np.float64) for f in factors]
+    cols = [f.shape[1] for f in fs]
+    t = np.asarray(a, dtype=np.float64).reshape(cols)        # C-order: first factor slowest
+    for ax, f in enumerate(fs):
+        t = np.moveaxis(np.tensordot(f, t, axes=([1], [ax])), 0, ax)
+    out = alpha * t.reshape(-1)
+    if beta != 0:
+        out = out + beta * np.asarray(y, dtype=np.float64)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# Low rank (mercer.jl:53-70, lazy_linear_algebra.jl:78-85)
+# ----------------------------------------------------------------------------------------
+def lowrank_mul(y, U, V, a, alpha=1.0, beta=0.0):
+    """LazyMatrixProduct(U, V') * a = U (V' a), right-to-left (lazy_linear_algebra.jl:78-85)."""
+    z = np.asarray(V, dtype=np.float64).T @ np.asarray(a, dtype=np.float64)
+    z = np.asarray(U, dtype=np.float64) @ z
+    out = alpha * z
+    if beta != 0:
+        out = out + beta * np.asarray(y, dtype=np.float64)
+    return out
