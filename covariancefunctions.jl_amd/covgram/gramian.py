@@ -1,0 +1,653 @@
+"""`gramian` / `Gramian` / `mul!` — the host-side mirror of src/gramian.jl for the device engine.
+
+Layout conventions (the reference's):
+  * a point set is a tensor of shape (n, d) (C-contiguous) — the same memory as Julia's d×n matrix whose
+    columns are the points (src/gramian.jl:2,154-155); a 1-D tensor is n scalar points;
+  * block vectors of multi-output Gramians are flat and point-major;
+  * matrix right-hand sides have shape (m, p).
+torch is used for device memory and streams only; every product below runs in libcovgram.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi
+from . import kernels as K
+
+# ----------------------------------------------------------------------------------------------
+# context handling: one covgram_ctx per device, bound to torch's current stream at call time
+# ----------------------------------------------------------------------------------------------
+_CTX = {}
+
+
+class _Ctx:
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.handle = _ffi._P()
+        self._stream = torch.cuda.current_stream(device).cuda_stream
+        _ffi.check(_ffi.lib().covgram_ctx_create(C.byref(self.handle), device.index, _ffi._P(self._stream)))
+
+    def bind_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream:
+            _ffi.check(_ffi.lib().covgram_ctx_set_stream(self.handle, _ffi._P(s)))
+            self._stream = s
+        return self.handle
+
+    def set_option(self, key: str, value: int):
+        _ffi.check(_ffi.lib().covgram_ctx_set_option(self.handle, key.encode(), int(value)))
+
+
+def get_ctx(device=None) -> _Ctx:
+    """The library context for `device` (default: torch's current CUDA/HIP device).  Raises if the
+    shared library is missing or no gfx950 device is visible — there is no CPU fallback."""
+    lib = _ffi.lib()
+    if device is None or (isinstance(device, torch.device) and device.type != "cuda"):
+        n = C.c_int(0)
+        lib.covgram_device_count(C.byref(n))
+        if n.value <= 0 or not torch.cuda.is_available():
+            raise _ffi.NoDevice(_ffi.ENODEVICE, "no HIP device visible — covgram has no CPU fallback")
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device.index not in _CTX:
+        _CTX[device.index] = _Ctx(device)
+    return _CTX[device.index]
+
+
+def set_option(key: str, value: int, device=None):
+    get_ctx(device).set_option(key, value)
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return _ffi.F32
+    if dt == torch.float64:
+        return _ffi.F64
+    raise TypeError(f"covgram supports float32/float64 points, got {dt}")
+
+
+# ----------------------------------------------------------------------------------------------
+# inputs: ranges, grids, point tensors
+# ----------------------------------------------------------------------------------------------
+class StepRangeLen:
+    """Julia's `range(start, stop, length)` / StepRangeLen: the trigger for Toeplitz structure
+    (src/gramian.jl:167-189)."""
+
+    def __init__(self, start, step, length, dtype=torch.float64):
+        self.start, self.step, self.length, self.dtype = float(start), float(step), int(length), dtype
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.tensor("cpu")[i]
+        if i < 0:
+            i += self.length
+        return self.start + self.step * i
+
+    def __add__(self, c):   # x .+ c keeps the step (test/gramian.jl:169)
+        return StepRangeLen(self.start + float(c), self.step, self.length, self.dtype)
+
+    def tensor(self, device):
+        idx = torch.arange(self.length, dtype=torch.float64, device=device)
+        return (self.start + self.step * idx).to(self.dtype)
+
+
+def srange(start, stop, length, dtype=torch.float64) -> StepRangeLen:
+    """range(start, stop, length)."""
+    step = (float(stop) - float(start)) / (length - 1) if length > 1 else 0.0
+    return StepRangeLen(start, step, length, dtype)
+
+
+class LazyGrid:
+    """Lazy Cartesian grid (src/lazy_grid.jl:3-38); default enumeration: FIRST axis varies fastest."""
+
+    def __init__(self, *args):
+        if len(args) == 2 and isinstance(args[1], int) and not isinstance(args[0], (int, float)):
+            args = tuple([args[0]] * args[1])                 # LazyGrid(x, d) = Fill(x, d)  (lazy_grid.jl:11)
+        self.args = tuple(args)
+
+    def __len__(self):
+        return int(np.prod([len(a) for a in self.args]))
+
+    def ndims(self):
+        return len(self.args)
+
+    def points(self, device, dtype=torch.float64, rowmajor=False):
+        axes = [(a.tensor(device) if isinstance(a, StepRangeLen) else torch.as_tensor(a, device=device)).to(dtype).reshape(-1)
+                for a in self.args]
+        mesh = torch.meshgrid(*axes, indexing="ij")
+        if rowmajor:       # lazy_grid.jl:40-58
+            cols = [g.reshape(-1) for g in mesh]
+        else:              # lazy_grid.jl:20-38: first axis fastest == Fortran-order flattening
+            cols = [g.permute(*reversed(range(g.dim()))).reshape(-1) for g in mesh]
+        return torch.stack(cols, dim=1).contiguous()
+
+
+def _as_points(x, device=None, dtype=None) -> torch.Tensor:
+    if isinstance(x, StepRangeLen):
+        dev = device if device is not None else get_ctx().device
+        t = x.tensor(dev)
+    elif isinstance(x, LazyGrid):
+        dev = device if device is not None else get_ctx().device
+        t = x.points(dev)
+    elif isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.as_tensor(np.asarray(x))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    if dtype is not None:
+        t = t.to(dtype)
+    if t.dim() == 1:
+        t = t.reshape(-1, 1)
+    if t.dim() != 2:
+        raise _ffi.DimensionMismatch(_ffi.EINVAL, f"points must be (n,) or (n, d), got shape {tuple(t.shape)}")
+    if t.device.type != "cuda":
+        t = t.to(device if device is not None else get_ctx().device)
+    return t.contiguous()
+
+
+class _Points:
+    """Device-resident point set + its covgram_points handle (borrowing the tensor's memory)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+        self.ctx = get_ctx(t.device)
+        self.handle = _ffi._P()
+        _ffi.check(_ffi.lib().covgram_points_create(self.ctx.handle, C.byref(self.handle), _ffi._P(t.data_ptr()), t.shape[0],
+                                                    t.shape[1], _dtype_code(t.dtype), _ffi.DEVICE))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _ffi.lib().covgram_points_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _vec_arg(a: torch.Tensor, n: int, dtype, device, what: str) -> torch.Tensor:
+    if not isinstance(a, torch.Tensor):
+        a = torch.as_tensor(np.asarray(a))
+    if a.shape[0] != n:
+        raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: {what} has length {a.shape[0]}, expected {n}")
+    return a.to(device=device, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# lazy operators
+# ----------------------------------------------------------------------------------------------
+class LazyOperator:
+    """Common surface of every lazily represented matrix: shape, `@`, `mul_` (= mul!), `to_dense()`."""
+
+    shape = (0, 0)
+    dtype = torch.float64
+    device = None
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        raise NotImplementedError
+
+    def __matmul__(self, a):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        y = torch.empty((self.shape[0],) + tuple(a.shape[1:]), dtype=self.dtype, device=self.device)
+        return self.mul_(y, a, 1.0, 0.0)                      # src/gramian.jl:66-75: zeros + mul!
+
+    def to_dense(self):
+        eye = torch.eye(self.shape[1], dtype=self.dtype, device=self.device)
+        return self @ eye
+
+    def __add__(self, D):
+        return LazyMatrixSum(self, D)                         # src/gramian.jl:55-60
+
+    __radd__ = __add__
+
+
+def mul_(y, A: LazyOperator, a, alpha=1.0, beta=0.0):
+    """LinearAlgebra.mul!(y, A, a, α, β): y ← α A a + β y, returns y."""
+    return A.mul_(y, a, alpha, beta)
+
+
+class Gramian(LazyOperator):
+    """Lazy kernel matrix holding (k, x, y) (src/gramian.jl:10-21); O(1) construction, O(n m d) `mul!`."""
+
+    def __init__(self, k, x, y=None):
+        self.k = k
+        self.x = _as_points(x)
+        if y is None or y is x:
+            self.y = self.x
+        else:
+            self.y = _as_points(y, device=self.x.device, dtype=self.x.dtype)
+        if self.x.shape[1] != self.y.shape[1]:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"inputs have to have the same length: {self.x.shape[1]}, {self.y.shape[1]}")
+        self.dtype = self.x.dtype                              # gramian_eltype: T follows the data (src/gramian.jl:30-33)
+        self.device = self.x.device
+        self.shape = (self.x.shape[0], self.y.shape[0])
+        self._px = _Points(self.x)
+        self._py = self._px if self.y is self.x else _Points(self.y)
+
+    # -- structure ------------------------------------------------------------------------------
+    @property
+    def T(self):
+        return Gramian(self.k, self.y, self.x)                 # src/gramian.jl:116-117
+
+    adjoint = T
+
+    def issymmetric(self):
+        return self.x is self.y or (self.x.shape == self.y.shape and bool(torch.equal(self.x, self.y)))   # :132
+
+    def isposdef(self):
+        return isinstance(self.k, (K.MercerKernel, K.MultiKernel)) and self.issymmetric()               # :135-137
+
+    def _spec(self):
+        return K.require_device_spec(self.k)
+
+    # -- products ---------------------------------------------------------------------------------
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        """src/gramian.jl:78-99.  β == 0 ⇒ y's previous contents (NaN included) are ignored."""
+        n, m = self.shape
+        a = _vec_arg(a, m, self.dtype, self.device, "a")
+        if y.shape[0] != n or y.dtype != self.dtype or tuple(y.shape[1:]) != tuple(a.shape[1:]):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}, expected ({n}, ...) of {self.dtype}")
+        spec = self._spec()
+        ctx = self._px.ctx.bind_stream()
+        lib = _ffi.lib()
+        if a.dim() == 1:
+            a_c = a.contiguous()
+            y_c = y if y.is_contiguous() else y.contiguous()
+            _ffi.check(lib.covgram_mvm(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(a_c.data_ptr()), max(m, 1),
+                                       _ffi._P(y_c.data_ptr()), max(n, 1), 1, float(alpha), float(beta), _ffi.DEVICE))
+            if y_c is not y:
+                y.copy_(y_c)
+            return y
+        p = a.shape[1]
+        a_cm = a.t().contiguous()                              # (p, m) row-major == m×p column-major
+        direct = y.t().is_contiguous()
+        y_cm = y.t() if direct else y.t().contiguous()
+        _ffi.check(lib.covgram_mvm(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(a_cm.data_ptr()), max(m, 1),
+                                   _ffi._P(y_cm.data_ptr()), max(n, 1), p, float(alpha), float(beta), _ffi.DEVICE))
+        if not direct:
+            y.copy_(y_cm.t())
+        return y
+
+    def to_dense(self):
+        """Matrix(G) (src/gramian.jl:102-114) on the device."""
+        n, m = self.shape
+        buf = torch.empty((m, n), dtype=self.dtype, device=self.device)   # column-major n×m
+        if n * m:
+            spec = self._spec()
+            ctx = self._px.ctx.bind_stream()
+            _ffi.check(_ffi.lib().covgram_matrix(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(buf.data_ptr()), n, _ffi.DEVICE))
+        return buf.t()
+
+    def __getitem__(self, ij):
+        """G[i, j] = k(x[i], y[j]) and sub-block indexing (src/gramian.jl:37-52), evaluated on the device."""
+        i, j = ij
+        xi = self.x[i] if not isinstance(i, int) else self.x[i:i + 1]
+        yj = self.y[j] if not isinstance(j, int) else self.y[j:j + 1]
+        sub = Gramian(self.k, xi.reshape(-1, self.x.shape[1]), yj.reshape(-1, self.y.shape[1])).to_dense()
+        if isinstance(i, int) and isinstance(j, int):
+            return sub[0, 0]
+        if isinstance(i, int):
+            return sub[0]
+        if isinstance(j, int):
+            return sub[:, 0]
+        return sub
+
+
+class BlockGramian(LazyOperator):
+    """Gramian of a GradientKernel: the lazy (n d)×(m d) BlockFactorization of src/gramian.jl:120-123 whose
+    `mul!` is blockmul! (src/gramian.jl:241-257) with the O(d) block product of src/gradient.jl:86-115."""
+
+    def __init__(self, g: K.GradientKernel, x, y=None):
+        self.g = g
+        self.inner = Gramian(g.k, x, y)
+        n, m = self.inner.shape
+        d = self.inner.x.shape[1]
+        self.d = d
+        self.shape = (n * d, m * d)
+        self.dtype, self.device = self.inner.dtype, self.inner.device
+
+    def issymmetric(self):
+        return self.inner.issymmetric()
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        spec = K.require_device_spec(self.g.k)   # GenericInput gradient kernels have no device path
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        if a.dim() != 1:
+            for c in range(a.shape[1]):                        # block solvers feed columns one at a time
+                yc = y[:, c].contiguous()
+                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
+                y[:, c] = yc
+            return y
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
+        a_c = a.contiguous()
+        y_c = y if y.is_contiguous() else y.contiguous()
+        ctx = self.inner._px.ctx.bind_stream()
+        _ffi.check(_ffi.lib().covgram_grad_mvm(ctx, C.byref(spec), self.inner._px.handle, self.inner._py.handle, _ffi._P(a_c.data_ptr()),
+                                               _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
+        if y_c is not y:
+            y.copy_(y_c)
+        return y
+
+
+class _ToeplitzBase(LazyOperator):
+    def __init__(self, vc: torch.Tensor, vr: Optional[torch.Tensor], circulant: bool):
+        self.vc = vc.contiguous()
+        self.vr = None if vr is None else vr.contiguous()
+        self.circulant = circulant
+        n = vc.shape[0]
+        m = n if vr is None else vr.shape[0]
+        self.shape = (n, m)
+        self.dtype, self.device = vc.dtype, vc.device
+        self._ctx = get_ctx(vc.device)
+        self.handle = _ffi._P()
+        _ffi.check(_ffi.lib().covgram_toeplitz_create(self._ctx.bind_stream(), C.byref(self.handle), _ffi._P(self.vc.data_ptr()),
+                                                      _ffi._P(self.vr.data_ptr()) if self.vr is not None else None, n, m,
+                                                      _dtype_code(self.dtype), _ffi.DEVICE, 1 if circulant else 0))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _ffi.lib().covgram_toeplitz_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        if a.dim() != 1:
+            for c in range(a.shape[1]):
+                yc = y[:, c].contiguous()
+                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
+                y[:, c] = yc
+            return y
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
+        a_c = a.contiguous()
+        y_c = y if y.is_contiguous() else y.contiguous()
+        self._ctx.bind_stream()
+        _ffi.check(_ffi.lib().covgram_toeplitz_mvm(self.handle, _ffi._P(a_c.data_ptr()), _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
+        if y_c is not y:
+            y.copy_(y_c)
+        return y
+
+    def to_dense(self):
+        n, m = self.shape
+        i = torch.arange(n, device=self.device)[:, None]
+        j = torch.arange(m, device=self.device)[None, :]
+        if self.circulant:
+            return self.vc[(i - j) % n]
+        vr = self.vc if self.vr is None else self.vr
+        return torch.where(i >= j, self.vc[(i - j).clamp(min=0)], vr[(j - i).clamp(min=0)])
+
+
+class SymmetricToeplitz(_ToeplitzBase):
+    def __init__(self, vc):
+        super().__init__(vc, None, False)
+
+
+class Toeplitz(_ToeplitzBase):
+    def __init__(self, vc, vr):
+        super().__init__(vc, vr, False)
+
+
+class Circulant(_ToeplitzBase):
+    def __init__(self, vc):
+        super().__init__(vc, None, True)
+
+
+class KroneckerProduct(LazyOperator):
+    """kronecker(F_1, ..., F_q) (KroneckerProducts 1.1.1): standard order, F_1 = slowest index.  Factors are
+    lazy Gramians or dense matrices; lazy factors are instantiated once on the device (they are the small
+    per-axis matrices, cf. README.md:205-210) and the MVM runs as mode products in libcovgram."""
+
+    def __init__(self, *factors):
+        self.factors = list(factors)
+        rows = [f.shape[0] for f in self.factors]
+        cols = [f.shape[1] for f in self.factors]
+        self.shape = (int(np.prod(rows)), int(np.prod(cols)))
+        f0 = self.factors[0]
+        self.dtype = f0.dtype
+        self.device = f0.device
+        self._dense = None
+
+    def _dense_factors(self):
+        if self._dense is None:
+            out = []
+            for f in self.factors:
+                D = f.to_dense() if isinstance(f, LazyOperator) else f
+                out.append(D.to(self.dtype).t().contiguous())    # (cols, rows) row-major == column-major rows×cols
+            self._dense = out
+        return self._dense
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        if a.dim() != 1:
+            for c in range(a.shape[1]):
+                yc = y[:, c].contiguous()
+                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
+                y[:, c] = yc
+            return y
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
+        fs = self._dense_factors()
+        q = len(fs)
+        ptrs = (_ffi._P * q)(*[_ffi._P(f.data_ptr()) for f in fs])
+        rows = (C.c_int64 * q)(*[f.shape[1] for f in fs])
+        cols = (C.c_int64 * q)(*[f.shape[0] for f in fs])
+        lds = (C.c_int64 * q)(*[f.shape[1] for f in fs])
+        a_c = a.contiguous()
+        y_c = y if y.is_contiguous() else y.contiguous()
+        ctx = get_ctx(self.device).bind_stream()
+        _ffi.check(_ffi.lib().covgram_kron_mvm(ctx, ptrs, rows, cols, lds, q, _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()),
+                                               _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
+        if y_c is not y:
+            y.copy_(y_c)
+        return y
+
+    def to_dense(self):
+        out = None
+        for f in self.factors:
+            D = f.to_dense() if isinstance(f, LazyOperator) else f
+            D = D.contiguous()
+            out = D if out is None else torch.kron(out, D)
+        return out
+
+
+def kronecker(*factors):
+    if len(factors) == 1 and isinstance(factors[0], SeparableGramian):
+        return factors[0].kronecker()
+    return KroneckerProduct(*factors)
+
+
+class SeparableGramian(LazyOperator):
+    """Gramian of a SeparableKernel: mul! = kronecker(G) = gramian(k.k, x, y) ⊗ B (src/separable.jl:33-42)."""
+
+    def __init__(self, s: K.SeparableKernel, x, y=None):
+        self.s = s
+        self.inner = Gramian(s.k, x, y)
+        self.dtype, self.device = self.inner.dtype, self.inner.device
+        self.B = torch.as_tensor(s.B, dtype=self.dtype, device=self.device)
+        n, m = self.inner.shape
+        self.shape = (n * self.B.shape[0], m * self.B.shape[1])
+        self._kron = None
+
+    def kronecker(self):
+        if self._kron is None:
+            self._kron = KroneckerProduct(self.inner, self.B)
+        return self._kron
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        return self.kronecker().mul_(y, a, alpha, beta)
+
+    def to_dense(self):
+        return self.kronecker().to_dense()
+
+
+class LazyMatrixProduct(LazyOperator):
+    """LazyMatrixProduct(U, V') — the low-rank Gramian of a FiniteBasis kernel (src/mercer.jl:61-70);
+    mul! applies the factors right to left (src/lazy_linear_algebra.jl:78-85): y = α U (Vᵀ a) + β y."""
+
+    def __init__(self, U: torch.Tensor, V: torch.Tensor):
+        # U: (n, r), V: (m, r) in torch indexing; stored column-major for the library
+        self.U, self.V = U, V
+        self.shape = (U.shape[0], V.shape[0])
+        self.dtype, self.device = U.dtype, U.device
+        self._Ucm = U.t().contiguous()
+        self._Vcm = self._Ucm if V is U else V.t().contiguous()
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        if a.dim() != 1:
+            for c in range(a.shape[1]):
+                yc = y[:, c].contiguous()
+                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
+                y[:, c] = yc
+            return y
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
+        n, m = self.shape
+        r = self.U.shape[1]
+        a_c = a.contiguous()
+        y_c = y if y.is_contiguous() else y.contiguous()
+        ctx = get_ctx(self.device).bind_stream()
+        _ffi.check(_ffi.lib().covgram_lowrank_mvm(ctx, _ffi._P(self._Ucm.data_ptr()), n, _ffi._P(self._Vcm.data_ptr()), m, n, m, r,
+                                                  _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()), _ffi._P(y_c.data_ptr()),
+                                                  float(alpha), float(beta), _ffi.DEVICE))
+        if y_c is not y:
+            y.copy_(y_c)
+        return y
+
+    def to_dense(self):
+        return self.U @ self.V.t()
+
+
+class LazyMatrixSum(LazyOperator):
+    """D + G kept lazy (src/gramian.jl:55-60, src/lazy_linear_algebra.jl:91-133): mul! accumulates the
+    terms with β = 1 after the first."""
+
+    def __init__(self, *args):
+        self.args = []
+        for a in args:
+            self.args.extend(a.args if isinstance(a, LazyMatrixSum) else [a])
+        lazy = [a for a in self.args if isinstance(a, LazyOperator)][0]
+        self.shape, self.dtype, self.device = lazy.shape, lazy.dtype, lazy.device
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        first = True
+        for A in self.args:
+            b = beta if first else 1.0
+            if isinstance(A, LazyOperator):
+                A.mul_(y, a, alpha, b)
+            else:   # Diagonal given as a 1-D tensor, or a dense matrix
+                A = torch.as_tensor(A, dtype=self.dtype, device=self.device)
+                t = (A * a if a.dim() == 1 else A[:, None] * a) if A.dim() == 1 else A @ a
+                if b == 0:
+                    y.copy_(alpha * t)
+                else:
+                    y.mul_(b).add_(t, alpha=alpha)
+            first = False
+        return y
+
+
+class Fill(LazyOperator):
+    """gramian(k::Constant, x, y) = Fill(k.c, n, m) (src/stationary.jl:34)."""
+
+    def __init__(self, c, n, m, dtype, device):
+        self.c, self.shape, self.dtype, self.device = float(c), (n, m), dtype, device
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        s = a.sum(dim=0, keepdim=True) * (alpha * self.c)
+        if beta == 0:
+            y.copy_(s.expand_as(y) if a.dim() > 1 else s.expand(y.shape[0]))
+        else:
+            y.mul_(beta).add_(s.expand_as(y) if a.dim() > 1 else s.expand(y.shape[0]))
+        return y
+
+    def to_dense(self):
+        return torch.full(self.shape, self.c, dtype=self.dtype, device=self.device)
+
+
+# ----------------------------------------------------------------------------------------------
+# the smart pseudo-constructor (src/gramian.jl:139-189 and the specialisations listed in SURVEY §3.1)
+# ----------------------------------------------------------------------------------------------
+def _first_column(k, x: torch.Tensor, y0: torch.Tensor) -> torch.Tensor:
+    """k.(x, y0) for n points x against ONE point y0 — n kernel evaluations on the device."""
+    return Gramian(k, x, y0.reshape(1, -1)).to_dense()[:, 0].contiguous()
+
+
+def gramian(k, x=None, y=None, trait: Optional[K.InputTrait] = None):
+    """gramian(k, x[, y][, trait]) — picks the representation exactly as the reference does."""
+    if x is None:
+        raise TypeError("gramian(k, x[, y])")
+    if not isinstance(k, (K.AbstractKernel,)) and not callable(k):   # gramian(x, y) = Gramian(Dot(), x, y)  (:150-151)
+        return Gramian(K.Dot(), k, x)
+    periodic = isinstance(y, K.PeriodicInput) or isinstance(trait, K.PeriodicInput)
+    if isinstance(y, K.InputTrait):
+        trait, y = y, None
+    same = y is None or y is x
+
+    if isinstance(k, K.Constant):                               # src/stationary.jl:34
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        return Fill(k.c, px.shape[0], py.shape[0], px.dtype, px.device)
+
+    if isinstance(k, K.FiniteBasis):                            # src/mercer.jl:61-70
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        r = len(k.basis)
+        if px.shape[0] > r and py.shape[0] > r:
+            def basis(p):
+                arg = p[:, 0] if p.shape[1] == 1 else p
+                return torch.stack([torch.as_tensor(b(arg), dtype=p.dtype, device=p.device).reshape(-1) for b in k.basis], dim=1)
+            U = basis(px)
+            V = U if same else basis(py)
+            return LazyMatrixProduct(U, V)
+        raise _ffi.UnsupportedKernel(_ffi.EUNSUPPORTED, "FiniteBasis with fewer points than basis functions is a GenericInput Gramian (src/mercer.jl:68)")
+
+    if isinstance(k, K.GradientKernel):                         # src/gramian.jl:120-123
+        return BlockGramian(k, x, None if same else y)
+    if isinstance(k, K.SeparableKernel):
+        return SeparableGramian(k, x, None if same else y)
+
+    if isinstance(k, K.SeparableProduct) and isinstance(x, LazyGrid):   # src/algebra.jl:91-95
+        gy = x if same else y
+        if not isinstance(gy, LazyGrid) or len(gy.args) != len(x.args):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"length(X.args) = {len(x.args)} ≠ length(Y.args)")
+        if len(k.args) != len(x.args):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"SeparableProduct needs d = {len(x.args)} kernels but has r = {len(k.args)}")
+        return KroneckerProduct(*[gramian(ki, xi, None if yi is xi else yi) for ki, xi, yi in zip(k.args, x.args, gy.args)])
+
+    if isinstance(x, StepRangeLen) and (same or isinstance(y, StepRangeLen)):   # src/gramian.jl:167-189
+        tr = trait if trait is not None else K.input_trait(k)
+        dev = get_ctx().device
+        if periodic and isinstance(k, K.StationaryKernel):      # :186-189
+            xt = _as_points(x, dev)
+            return Circulant(_first_column(k, xt, xt[0]))
+        if isinstance(tr, (K.IsotropicInput, K.StationaryInput)) and K.device_spec(k) is not None:
+            xt = _as_points(x, dev)
+            if same:
+                return SymmetricToeplitz(_first_column(k, xt, xt[0]))          # k.(x[1], x)
+            if x.step == y.step and len(x) >= 1:
+                yt = _as_points(y, dev, xt.dtype)
+                vc = _first_column(k, xt, yt[0])                                  # k.(x, y[1])
+                vr = _first_column(k, yt, xt[0])                                  # k.(x[1], y)
+                return Toeplitz(vc, vr)
+        return Gramian(k, x, None if same else y)               # different step / GenericInput: plain Gramian
+
+    return Gramian(k, x, None if same else y)

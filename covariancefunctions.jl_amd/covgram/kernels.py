@@ -1,0 +1,485 @@
+"""Kernel structs and `input_trait` — the host-side mirror of the reference's kernel zoo for the hot path.
+
+Same names, argument meaning and error behaviour as CovarianceFunctions.jl (citations relative to the
+reference root).  A kernel object is a *description*; `device_spec(k)` lowers it to the C struct
+`covgram_kernel` that selects the HIP kernel, exactly the role `input_trait(k)` plays in the
+reference (src/properties.jl:31-63, README.md:90-99).  Calling a kernel, `k(x, y)`, evaluates the
+scalar definition on the host for single pairs (API parity with the Julia call operators); the MVM,
+`Matrix(G)` and Toeplitz/Kronecker constructions never use it — they run on the device.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+# ----------------------------------------------------------------------------------------------
+# input traits (src/properties.jl:31-37)
+# ----------------------------------------------------------------------------------------------
+
+
+class InputTrait:
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self).__name__)
+
+    def __repr__(self):
+        return type(self).__name__ + "()"
+
+
+class GenericInput(InputTrait): pass
+class IsotropicInput(InputTrait): pass            # dependent on |r|²
+class DotProductInput(InputTrait): pass           # dependent on x ⋅ y
+class StationaryInput(InputTrait): pass           # dependent on r
+class StationaryLinearFunctionalInput(InputTrait): pass   # dependent on c ⋅ r
+class PeriodicInput(InputTrait): pass
+
+
+class DomainError(ValueError):
+    pass
+
+
+def _dot(x, y):
+    return float(np.dot(np.atleast_1d(np.asarray(x, dtype=np.float64)), np.atleast_1d(np.asarray(y, dtype=np.float64))))
+
+
+def _euclidean2(x, y):
+    """src/util.jl:40-47 — direct differences, DimensionMismatch on unequal lengths."""
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64)); y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+    if x.shape != y.shape:
+        raise _ffi.DimensionMismatch(_ffi.EINVAL, f"inputs have to have the same length: {x.size}, {y.size}")
+    d = x - y
+    return float(np.dot(d, d))
+
+
+# ----------------------------------------------------------------------------------------------
+# type tree (src/CovarianceFunctions.jl:32-40)
+# ----------------------------------------------------------------------------------------------
+class AbstractKernel:
+    def __mul__(self, other):
+        if isinstance(other, (int, float)):
+            return Product((Constant(other), self))          # src/algebra.jl:24-25
+        if isinstance(other, AbstractKernel):
+            return Product((self, other))
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    def __add__(self, other):
+        if isinstance(other, (int, float)):
+            return Sum((self, Constant(other)))              # src/algebra.jl:46-47
+        if isinstance(other, AbstractKernel):
+            return Sum((self, other))
+        return NotImplemented
+
+    __radd__ = __add__
+
+    def __pow__(self, p):
+        return Power(self, p)                                # src/algebra.jl:63
+
+
+class MercerKernel(AbstractKernel): pass
+class StationaryKernel(MercerKernel): pass
+
+
+class IsotropicKernel(StationaryKernel):
+    """(k::IsotropicKernel)(x, y) = k(euclidean2(x, y)); one-argument form takes r² (src/stationary.jl:9-10)."""
+
+    def profile(self, s: float) -> float:
+        raise NotImplementedError
+
+    def __call__(self, *args):
+        if len(args) == 2:
+            return self.profile(_euclidean2(args[0], args[1]))
+        (a,) = args
+        if np.ndim(a) == 0:
+            return self.profile(float(a))                    # k(r²)
+        a = np.asarray(a, dtype=np.float64)
+        return self.profile(float(np.dot(a, a)))             # k(τ) = k(sum(abs2, τ))
+
+
+class MultiKernel(AbstractKernel): pass
+
+
+class Constant(IsotropicKernel):
+    """src/stationary.jl:15-34."""
+
+    def __init__(self, c, check: bool = True):
+        if check and not (c >= 0):
+            raise DomainError(f"Constant is not positive semi-definite: {c}")
+        self.c = float(c)
+
+    def profile(self, s):
+        return self.c
+
+    def __call__(self, *args):
+        return self.c
+
+
+class ExponentiatedQuadratic(IsotropicKernel):
+    def profile(self, s):
+        return math.exp(-s / 2)                              # src/stationary.jl:42
+
+
+EQ = ExponentiatedQuadratic
+
+
+class RationalQuadratic(IsotropicKernel):
+    def __init__(self, alpha):
+        if not alpha > 0:
+            raise DomainError("α not positive")             # src/stationary.jl:47
+        self.alpha = float(alpha)
+
+    def profile(self, s):
+        return (1 + s / (2 * self.alpha)) ** (-self.alpha)   # src/stationary.jl:53
+
+
+RQ = RationalQuadratic
+
+
+class Exponential(IsotropicKernel):
+    def profile(self, s):
+        return math.exp(-math.sqrt(s))                       # src/stationary.jl:60
+
+
+Exp = Exponential
+
+
+class GammaExponential(IsotropicKernel):
+    def __init__(self, gamma):
+        if not (0 <= gamma <= 2):
+            raise DomainError("γ not in [0,2]")             # src/stationary.jl:65
+        self.gamma = float(gamma)
+
+    def profile(self, s):
+        return math.exp(-(s ** (self.gamma / 2)) / 2)        # src/stationary.jl:71
+
+
+GammaExp = GammaExponential
+
+
+class Cauchy(IsotropicKernel):
+    def profile(self, s):
+        return 1.0 / (1.0 + s)                               # src/stationary.jl:224
+
+
+class InverseMultiQuadratic(IsotropicKernel):
+    def __init__(self, c):
+        self.c = float(c)
+
+    def profile(self, s):
+        return 1.0 / math.sqrt(s + self.c ** 2)              # src/stationary.jl:235
+
+
+def maternp_coefficients(p: int):
+    """src/stationary.jl:184-191 (reversed binomial(p,i) * (p+i)!/p!)."""
+    fp = math.factorial(p)
+    return [math.comb(p, i) * (math.factorial(p + i) // fp) for i in range(1, p + 1)][::-1]
+
+
+def maternp_derivatives_at_zero(p: int):
+    """src/stationary.jl:172-182 — SymEngine there; here from the exact power series of exp(-r) q_p(r)."""
+    from fractions import Fraction
+    c = [Fraction(v) for v in maternp_coefficients(p)] + [Fraction(1)]
+    nrm = math.factorial(2 * p) // math.factorial(p)
+    h = [c[m] * 2 ** m / nrm for m in range(p + 1)]
+    out = []
+    for i in range(1, p + 1):
+        coef = sum(h[m] * Fraction((-1) ** (2 * i - m), math.factorial(2 * i - m)) for m in range(0, min(p, 2 * i) + 1))
+        out.append(float(coef * (2 * p + 1) ** i * math.factorial(i)))
+    return out
+
+
+class MaternP(IsotropicKernel):
+    """Matern with ν = p + 1/2 (src/stationary.jl:117-158), including the Taylor guard near zero."""
+
+    def __init__(self, p):
+        if isinstance(p, Matern):
+            p = int(math.floor(p.nu))                        # src/stationary.jl:130
+        if p < 0:
+            raise DomainError(f"p = {p} is negative")        # src/stationary.jl:124
+        self.p = int(p)
+        self.coefficients = [float(v) for v in maternp_coefficients(self.p)]
+        self.derivatives = maternp_derivatives_at_zero(self.p)
+
+    def profile(self, s, eps=np.finfo(np.float64).eps):
+        p = self.p
+        if p >= 1 and s < eps ** (1.0 / p):                  # src/stationary.jl:135-146
+            y, si = 1.0, s
+            for i in range(1, p + 1):
+                y += self.derivatives[i - 1] * si / math.factorial(i)
+                si *= s
+            return y
+        r = math.sqrt((2 * p + 1) * s)
+        y, ri = 0.0, 1.0
+        for i in range(p):
+            y += self.coefficients[i] * ri
+            ri *= 2 * r
+        y += ri
+        return y * math.exp(-r) / (math.factorial(2 * p) // math.factorial(p))
+
+
+class Matern(IsotropicKernel):
+    """src/stationary.jl:87-114 (Bessel form) — GenericInput for the device: no compiled profile."""
+
+    def __init__(self, nu):
+        if not nu > 0:
+            raise DomainError(f"ν = {nu} is negative")
+        self.nu = float(nu)
+
+    def profile(self, s):
+        from scipy.special import gamma, kv
+        nu = self.nu
+        if s == 0:
+            return 1.0
+        r = math.sqrt(2 * nu * s)
+        return 2 ** (1 - nu) / gamma(nu) * r ** nu * kv(nu, r)
+
+
+class DotProductKernel(MercerKernel):
+    """(k::DotProductKernel)(x, y) = k(dot(x, y)) (src/mercer.jl:2-3)."""
+
+    def profile(self, s):
+        raise NotImplementedError
+
+    def __call__(self, *args):
+        if len(args) == 2:
+            return self.profile(_dot(args[0], args[1]))
+        return self.profile(float(args[0]))
+
+
+class Dot(DotProductKernel):
+    def profile(self, s):
+        return s                                             # src/mercer.jl:9
+
+
+class ExponentialDot(DotProductKernel):
+    def profile(self, s):
+        return math.exp(s)                                   # src/mercer.jl:22
+
+
+class FiniteBasis(MercerKernel):
+    """src/mercer.jl:41-70: k(x,y) = Σ_b b(x) b(y); basis functions are vectorised callables."""
+
+    def __init__(self, basis: Sequence):
+        if len(basis) < 1:
+            raise ValueError(f"basis is empty: length(basis) = {len(basis)}")
+        self.basis = list(basis)
+
+    def __call__(self, x, y):
+        return float(sum(b(x) * b(y) for b in self.basis))
+
+
+# ----------------------------------------------------------------------------------------------
+# algebra (src/algebra.jl) and Lengthscale (src/transformation.jl:6-19)
+# ----------------------------------------------------------------------------------------------
+def sum_and_product_input_trait(args):
+    """src/properties.jl:47-63: common trait of the non-Constant arguments, else GenericInput."""
+    non_const = [k for k in args if not isinstance(k, Constant)]
+    if not non_const:
+        return IsotropicInput()
+    trait = input_trait(non_const[0])
+    for k in non_const[1:]:
+        if input_trait(k) != trait:
+            return GenericInput()
+    return trait
+
+
+class Product(AbstractKernel):
+    def __init__(self, args):
+        self.args = tuple(args)
+        self.input_trait = sum_and_product_input_trait(self.args)
+
+    def __call__(self, *a):
+        out = 1.0
+        for k in self.args:
+            out *= k(*a)
+        return out
+
+
+class Sum(AbstractKernel):
+    def __init__(self, args):
+        self.args = tuple(args)
+        self.input_trait = sum_and_product_input_trait(self.args)
+
+    def __call__(self, *a):
+        return sum(k(*a) for k in self.args)
+
+
+class Power(AbstractKernel):
+    def __init__(self, k, p):
+        if int(p) != p:
+            raise TypeError("Power exponent must be an Int (src/algebra.jl:52)")
+        self.k, self.p = k, int(p)
+        self.input_trait = input_trait(k)
+
+    def __call__(self, *a):
+        return self.k(*a) ** self.p
+
+
+class Lengthscale(IsotropicKernel):
+    def __init__(self, k, l):
+        if not isinstance(k, IsotropicKernel):
+            raise TypeError("Lengthscale(k::IsotropicKernel, l)")
+        if np.ndim(l) != 0 and np.size(l) != 1:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, "lengthscale l has to has length 1")
+        l = float(np.asarray(l).reshape(()))
+        if not l > 0:
+            raise DomainError(f"l = {l} is non-positive")    # src/transformation.jl:10
+        self.k, self.l = k, l
+
+    def profile(self, s):
+        return self.k.profile(s / self.l ** 2)               # src/transformation.jl:19
+
+
+class SeparableProduct(AbstractKernel):
+    """src/algebra.jl:68-95: product kernel evaluating component kernels on separate input dimensions."""
+
+    def __init__(self, *args):
+        self.args = tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list)) else tuple(args)
+
+    def __call__(self, x, y):
+        x = np.atleast_1d(x); y = np.atleast_1d(y)
+        if len(x) != len(y):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"length(x) ({len(x)}) ≠ length(y) ({len(y)})")
+        if len(self.args) != len(x):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"SeparableProduct needs d = {len(x)} kernels but has r = {len(self.args)}")
+        out = 1.0
+        for ki, xi, yi in zip(self.args, x, y):
+            out *= ki(xi, yi)
+        return out
+
+
+def separable(op, *k):
+    """src/algebra.jl:140-143."""
+    import operator
+    if op in (operator.mul, "*"):
+        return SeparableProduct(*k)
+    if op in (operator.pow, "^", "**"):
+        kern, d = k
+        return SeparableProduct(*([kern] * int(d)))
+    raise NotImplementedError("separable(+, ...) has no structured Gramian in the reference either (src/algebra.jl:125-138)")
+
+
+class SeparableKernel(MultiKernel):
+    """SeparableKernel(B, k): matrix-valued kernel B * k(x, y) (src/separable.jl:2-16)."""
+
+    def __init__(self, B, k=None):
+        if isinstance(B, AbstractKernel):   # Separable(k, B) argument order used in test/separable.jl:13
+            B, k = k, B
+        self.B = np.asarray(B, dtype=np.float64)
+        self.k = k
+
+    def __call__(self, x, y):
+        return self.B * self.k(x, y)
+
+
+Separable = SeparableKernel
+
+
+class GradientKernel(MultiKernel):
+    """src/gradient.jl:7-24: the d×d block kernel ∂x ∂yᵀ k(x, y); carries input_trait(k)."""
+
+    def __init__(self, k, it: Optional[InputTrait] = None):
+        self.k = k
+        self.input_trait = input_trait(k) if it is None else it
+
+
+# ----------------------------------------------------------------------------------------------
+# input_trait (src/properties.jl:39-45, gradient.jl:16) — user-extensible like the reference
+# ----------------------------------------------------------------------------------------------
+_USER_TRAITS = {}
+
+
+def register_input_trait(obj_or_type, trait: InputTrait):
+    """Counterpart of defining `CovarianceFunctions.input_trait(::typeof(k)) = ...` (test/gramian.jl:163)."""
+    _USER_TRAITS[obj_or_type if isinstance(obj_or_type, type) else id(obj_or_type)] = trait
+
+
+def input_trait(k) -> InputTrait:
+    if id(k) in _USER_TRAITS:
+        return _USER_TRAITS[id(k)]
+    for t, tr in _USER_TRAITS.items():
+        if isinstance(t, type) and isinstance(k, t):
+            return tr
+    if isinstance(k, (Product, Sum, Power, GradientKernel)):
+        return k.input_trait
+    if isinstance(k, (Dot, ExponentialDot)):
+        return DotProductInput()
+    if isinstance(k, IsotropicKernel):
+        return IsotropicInput()
+    if isinstance(k, StationaryKernel):
+        return StationaryInput()
+    return GenericInput()
+
+
+def ismercer(k): return isinstance(k, MercerKernel) or (isinstance(k, (Product, Sum)) and all(ismercer(a) for a in k.args)) or (isinstance(k, Power) and ismercer(k.k))
+def isstationary(k): return isinstance(k, StationaryKernel) or (isinstance(k, (Product, Sum)) and all(isstationary(a) for a in k.args)) or (isinstance(k, Power) and isstationary(k.k))
+def isisotropic(k): return isinstance(k, IsotropicKernel) or (isinstance(k, (Product, Sum)) and all(isisotropic(a) for a in k.args)) or (isinstance(k, Power) and isisotropic(k.k))
+def isdot(k): return isinstance(k, (Dot, ExponentialDot)) or (isinstance(k, (Product, Sum)) and all(isdot(a) for a in k.args)) or (isinstance(k, Power) and isdot(k.k))
+
+
+# ----------------------------------------------------------------------------------------------
+# lowering to the C struct
+# ----------------------------------------------------------------------------------------------
+_BASE = {
+    ExponentiatedQuadratic: _ffi.EQ, Exponential: _ffi.EXP, RationalQuadratic: _ffi.RQ, GammaExponential: _ffi.GAMMAEXP,
+    Cauchy: _ffi.CAUCHY, InverseMultiQuadratic: _ffi.IMQ, MaternP: _ffi.MATERNP, Dot: _ffi.DOT, ExponentialDot: _ffi.EXPDOT,
+}
+
+
+def device_spec(k) -> Optional[_ffi.covgram_kernel]:
+    """covgram_kernel for `k`, or None if k has no device profile (GenericInput in the reference's terms).
+
+    Handles base profiles, Lengthscale nesting, Power (exponents multiply; (c·k)^p = c^p k^p) and
+    products with Constants (scale) — the compositions that keep the IsotropicInput / DotProductInput
+    trait of a single profile."""
+    scale, power, ls = 1.0, 1, 1.0
+    while True:
+        if isinstance(k, Product):
+            consts = [a for a in k.args if isinstance(a, Constant)]
+            rest = [a for a in k.args if not isinstance(a, Constant)]
+            if len(rest) != 1:
+                return None
+            for c in consts:
+                scale *= c.c ** power
+            k = rest[0]
+        elif isinstance(k, Power):
+            if k.p < 1:
+                return None
+            power *= k.p
+            k = k.k
+        elif isinstance(k, Lengthscale):
+            ls *= k.l
+            k = k.k
+        else:
+            break
+    fam = _BASE.get(type(k))
+    if fam is None:
+        return None
+    spec = _ffi.covgram_kernel()
+    spec.family = fam
+    spec.trait = _ffi.DOTPRODUCT if fam in (_ffi.DOT, _ffi.EXPDOT) else _ffi.ISOTROPIC
+    spec.p = getattr(k, "p", 0) if fam == _ffi.MATERNP else 0
+    spec.power = power
+    spec.param = {_ffi.RQ: getattr(k, "alpha", 0.0), _ffi.GAMMAEXP: getattr(k, "gamma", 0.0), _ffi.IMQ: getattr(k, "c", 0.0)}.get(fam, 0.0)
+    spec.lengthscale = ls
+    spec.scale = scale
+    if spec.trait == _ffi.DOTPRODUCT and ls != 1.0:
+        return None
+    return spec
+
+
+def require_device_spec(k) -> _ffi.covgram_kernel:
+    spec = device_spec(k)
+    if spec is None:
+        raise _ffi.UnsupportedKernel(
+            _ffi.EUNSUPPORTED,
+            f"{type(k).__name__} has input_trait {input_trait(k)!r} / no compiled device profile; the reference would run its "
+            "generic threaded loop (src/gramian.jl:78-87) here — this engine has no CPU fallback")
+    return spec

@@ -268,12 +268,8 @@ int covgram_ctx_create(covgram_ctx** out, int device_id, void* hip_stream) {
     covgram_ctx* c = new covgram_ctx();
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
-    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
-    else {
-        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (se != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(se)); return COVGRAM_EHIP; }
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)hip_stream;   // NULL = the device's default (null) stream, like any HIP API
+    c->own_stream = false;
     *out = c;
     return COVGRAM_OK;
 }
@@ -291,13 +287,9 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
 
 int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream) {
     CG_REQUIRE(ctx != nullptr, COVGRAM_EINVAL, "ctx is NULL");
-    CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
-    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
-    else {
-        CG_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // workspaces are reused across calls: order the new stream after everything queued on the old one
+    if ((hipStream_t)hip_stream != ctx->stream) CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
     return COVGRAM_OK;
 }
 

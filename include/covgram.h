@@ -94,7 +94,8 @@ int covgram_version(void);
 const char* covgram_last_error(void);
 int covgram_device_count(int* count);
 
-/* hip_stream: a hipStream_t the caller owns (e.g. torch's current stream), or NULL for a library-owned one. */
+/* hip_stream: the hipStream_t every kernel of this ctx is launched on (e.g. torch's current stream); NULL is the
+ * device's default (null) stream.  The library never creates streams of its own. */
 int covgram_ctx_create(covgram_ctx** ctx, int device_id, void* hip_stream);
 int covgram_ctx_destroy(covgram_ctx* ctx);
 int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream);

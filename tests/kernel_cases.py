@@ -1,0 +1,31 @@
+"""Shared kernel zoo for the parity tests: (name, covgram kernel factory, oracle Kernel)."""
+import covgram_oracle as o
+
+
+def cases(cg):
+    return [
+        ("EQ", cg.EQ(), o.Kernel(o.EQ)),
+        ("Exp", cg.Exp(), o.Kernel(o.EXP)),
+        ("RQ(1.0)", cg.RQ(1.0), o.Kernel(o.RQ, param=1.0)),
+        ("RQ(0.37)", cg.RQ(0.37), o.Kernel(o.RQ, param=0.37)),
+        ("gammaExp(1.5)", cg.GammaExp(1.5), o.Kernel(o.GAMMAEXP, param=1.5)),
+        ("Cauchy", cg.Cauchy(), o.Kernel(o.CAUCHY)),
+        ("IMQ(0.8)", cg.InverseMultiQuadratic(0.8), o.Kernel(o.IMQ, param=0.8)),
+        ("MaternP(0)", cg.MaternP(0), o.Kernel(o.MATERNP, p=0)),
+        ("MaternP(1)", cg.MaternP(1), o.Kernel(o.MATERNP, p=1)),
+        ("MaternP(2)", cg.MaternP(2), o.Kernel(o.MATERNP, p=2)),
+        ("MaternP(3)", cg.MaternP(3), o.Kernel(o.MATERNP, p=3)),
+        ("Lengthscale(EQ,0.7)", cg.Lengthscale(cg.EQ(), 0.7), o.Kernel(o.EQ, lengthscale=0.7)),
+        ("2.5*Lengthscale(MaternP(2),1.3)", 2.5 * cg.Lengthscale(cg.MaternP(2), 1.3), o.Kernel(o.MATERNP, p=2, lengthscale=1.3, scale=2.5)),
+        ("Dot()^3", cg.Dot() ** 3, o.Kernel(o.DOT, power=3)),
+        ("Dot()", cg.Dot(), o.Kernel(o.DOT)),
+        ("ExponentialDot", cg.ExponentialDot(), o.Kernel(o.EXPDOT)),
+        ("EQ^2", cg.EQ() ** 2, o.Kernel(o.EQ, power=2)),
+    ]
+
+
+# kernels whose phi', phi'' are finite at s = 0 (gradient Gramian well defined on the diagonal)
+def grad_cases(cg):
+    keep = {"EQ", "RQ(1.0)", "RQ(0.37)", "Cauchy", "IMQ(0.8)", "MaternP(2)", "MaternP(3)", "Lengthscale(EQ,0.7)",
+            "2.5*Lengthscale(MaternP(2),1.3)", "Dot()^3", "Dot()", "ExponentialDot", "EQ^2"}
+    return [c for c in cases(cg) if c[0] in keep]

@@ -1,0 +1,273 @@
+"""GPU parity: the HIP path (through the C ABI) against the fp64 oracle on seeded inputs.
+
+Tolerances (stated by BASELINE.json / SURVEY.md §8d): rel-err = ||b - b_ref||_2 / ||b_ref||_2 against the
+fp64 oracle: <= 1e-5 for fp32, <= 1e-12 for fp64 dense/gradient, <= 1e-10 for fp64 Toeplitz."""
+import numpy as np
+import pytest
+import torch
+
+import kernel_cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-5, torch.float64: 1e-12}
+
+
+def relerr(b, ref):
+    b = np.asarray(b, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    den = np.linalg.norm(ref)
+    return np.linalg.norm(b - ref) / (den if den > 0 else 1.0)
+
+
+def npdt(dt):
+    return np.float32 if dt == torch.float32 else np.float64
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 32])
+def test_dense_mvm_all_kernels(cg, oracle, dtype, d):
+    rng = np.random.default_rng(0xC0F + d)
+    n, m = 257, 129
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype))
+    Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+    a = rng.standard_normal(m).astype(npdt(dtype))
+    y0 = rng.standard_normal(n).astype(npdt(dtype))
+    Xd, Yd, ad = (torch.from_numpy(v).cuda() for v in (X, Y, a))
+    for name, k, ko in kernel_cases.cases(cg):
+        G = cg.gramian(k, Xd, Yd)
+        assert tuple(G.shape) == (n, m)
+        ref = oracle.mul(None, ko, X, Y, a, 1.0, 0.0, npdt(dtype))
+        b = (G @ ad).cpu().numpy()
+        assert relerr(b, ref) <= TOL[dtype], (name, d, relerr(b, ref))
+        # 5-argument mul!, beta != 0
+        alpha, beta = -0.7, 1.3
+        yd = torch.from_numpy(y0.copy()).cuda()
+        out = cg.mul_(yd, G, ad, alpha, beta)
+        assert out is yd
+        ref2 = oracle.mul(y0, ko, X, Y, a, alpha, beta, npdt(dtype))
+        assert relerr(yd.cpu().numpy(), ref2) <= TOL[dtype], (name, d)
+        # beta == 0 must ignore NaNs in y (src/gramian.jl:80)
+        yn = torch.full((n,), float("nan"), dtype=dtype, device="cuda")
+        cg.mul_(yn, G, ad, 1.0, 0.0)
+        assert relerr(yn.cpu().numpy(), ref) <= TOL[dtype], (name, d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_dense_matrix_rhs_and_matrix(cg, oracle, dtype):
+    """test/gramian.jl:55-72: G*a ≈ Matrix(G)*a, G*A ≈ Matrix(G)*A for an n×2n Gramian, p = 3 (and p = 6)."""
+    rng = np.random.default_rng(7)
+    n, d = 8, 1
+    x = rng.standard_normal(n).astype(npdt(dtype)); y = rng.standard_normal(2 * n).astype(npdt(dtype))
+    k, ko = cg.EQ(), oracle.Kernel(oracle.EQ)
+    G = cg.gramian(k, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    assert tuple(G.shape) == (n, 2 * n)
+    M = G.to_dense().cpu().numpy()
+    assert relerr(M, oracle.matrix(ko, x, y)) <= TOL[dtype]
+    for p in (3, 6):
+        A = rng.standard_normal((2 * n, p)).astype(npdt(dtype))
+        B = (G @ torch.from_numpy(A).cuda()).cpu().numpy()
+        assert B.shape == (n, p)
+        assert relerr(B, oracle.mul(None, ko, x, y, A)) <= TOL[dtype]
+        assert relerr(B, M.astype(np.float64) @ A) <= 10 * TOL[dtype]
+    # indexing (test/gramian.jl:75-95)
+    assert abs(float(G[2, 5]) - k(x[2], y[5])) <= 1e-6
+    sub = G[2:n - 1, 3:2 * n - 4].cpu().numpy()
+    assert relerr(sub, oracle.matrix(ko, x[2:n - 1], y[3:2 * n - 4])) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 700), (700, 1), (1023, 1025), (2049, 513)])
+def test_dense_ragged_shapes(cg, oracle, shape):
+    n, m = shape
+    rng = np.random.default_rng(n * 7919 + m)
+    X = rng.standard_normal((n, 3)); Y = rng.standard_normal((m, 3)); a = rng.standard_normal(m)
+    for dtype in (torch.float32, torch.float64):
+        G = cg.gramian(cg.MaternP(2), torch.from_numpy(X.astype(npdt(dtype))).cuda(), torch.from_numpy(Y.astype(npdt(dtype))).cuda())
+        b = (G @ torch.from_numpy(a.astype(npdt(dtype))).cuda()).cpu().numpy()
+        ref = oracle.mul(None, oracle.Kernel(oracle.MATERNP, p=2), X.astype(npdt(dtype)), Y.astype(npdt(dtype)), a.astype(npdt(dtype)), dtype=npdt(dtype))
+        assert relerr(b, ref) <= TOL[dtype], (shape, dtype)
+
+
+def test_config1_maternp2_d3_n4096_f64(cg, oracle):
+    """BASELINE.json configs[0]: MaternP(2), d=3, n=4096, fp64."""
+    rng = np.random.default_rng(0xC0F + 0)
+    X = rng.standard_normal((4096, 3)); a = rng.standard_normal(4096)
+    G = cg.gramian(cg.MaternP(2), torch.from_numpy(X).cuda())
+    assert G.issymmetric() and G.isposdef()
+    b = (G @ torch.from_numpy(a).cuda()).cpu().numpy()
+    ref = oracle.mul(None, oracle.Kernel(oracle.MATERNP, p=2), X, X, a)
+    assert relerr(b, ref) <= 1e-12
+
+
+def test_lds_variant_matches_scalar_variant(cg, oracle):
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((5000, 3)).astype(np.float32); a = rng.standard_normal(5000).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda())
+    ad = torch.from_numpy(a).cuda()
+    ref = oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a, dtype=np.float32)
+    try:
+        cg.set_option("dense_variant", 1)
+        b1 = (G @ ad).cpu().numpy()
+    finally:
+        cg.set_option("dense_variant", 0)
+    b0 = (G @ ad).cpu().numpy()
+    assert relerr(b1, ref) <= 1e-5 and relerr(b0, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [1, 5, 32])
+def test_gradient_mvm(cg, oracle, dtype, d):
+    """test/gradient.jl:26-53: mul!(Kab, K, a, α, β) ≈ α MK a + β b, K symmetric, for n ∈ {2, 33}."""
+    tol = 2e-5 if dtype == torch.float32 else 1e-12
+    for n in (2, 33):
+        rng = np.random.default_rng(100 * d + n)
+        X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype))
+        a = rng.standard_normal(n * d).astype(npdt(dtype)); b0 = rng.standard_normal(n * d).astype(npdt(dtype))
+        alpha, beta = rng.standard_normal(2)
+        Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+        for name, k, ko in kernel_cases.grad_cases(cg):
+            K = cg.gramian(cg.GradientKernel(k), Xd)
+            assert isinstance(K, cg.BlockGramian) and tuple(K.shape) == (n * d, n * d)
+            ref = oracle.grad_mul(b0, ko, X, X, a, alpha, beta, npdt(dtype))
+            bd = torch.from_numpy(b0.copy()).cuda()
+            cg.mul_(bd, K, ad, alpha, beta)
+            assert relerr(bd.cpu().numpy(), ref) <= tol, (name, d, n, relerr(bd.cpu().numpy(), ref))
+            # dense check against the explicit block matrix (Matrix(K) = K * I)
+            if n == 2 and d <= 5:
+                MK = oracle.grad_matrix(ko, X, X, npdt(dtype))
+                assert np.max(np.abs(MK - MK.T)) < 1e-10
+                assert relerr((K @ ad).cpu().numpy(), MK @ a.astype(np.float64)) <= 10 * tol
+
+
+def test_gradient_eq_block_closed_form(cg):
+    """EQ gradient block = k (I - r r') (SURVEY §3.3 known answer)."""
+    x = np.array([[0.3, -0.2, 0.5]]); y = np.array([[-0.1, 0.4, 0.2]])
+    K = cg.gramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    M = K.to_dense().cpu().numpy()
+    r = (x - y)[0]
+    assert np.allclose(M, np.exp(-r @ r / 2) * (np.eye(3) - np.outer(r, r)), rtol=1e-13, atol=1e-14)
+
+
+def test_config4_gradient_eq_d32_f64_subset(cg, oracle):
+    """BASELINE.json configs[3] shape (GradientKernel(EQ), d=32, fp64) at an oracle-sized n."""
+    rng = np.random.default_rng(0xC0F + 3)
+    n, d = 1024, 32
+    X = rng.standard_normal((n, d)); a = rng.standard_normal(n * d)
+    K = cg.gramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(X).cuda())
+    b = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
+    assert relerr(b, oracle.grad_mul(None, oracle.Kernel(oracle.EQ), X, X, a)) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_toeplitz(cg, oracle, dtype):
+    """test/gramian.jl:143-178."""
+    tol = 2e-5 if dtype == torch.float32 else 1e-10
+    for n in (32, 1000, 4096):
+        x = cg.srange(-1, 1, n, dtype)
+        for k, ko in ((cg.EQ(), oracle.Kernel(oracle.EQ)), (cg.Exp(), oracle.Kernel(oracle.EXP))):
+            G = cg.gramian(k, x)
+            assert isinstance(G, cg.SymmetricToeplitz) and tuple(G.shape) == (n, n)
+            xs = oracle.srange_points(oracle.srange(-1, 1, n))
+            a = np.random.default_rng(n).standard_normal(n).astype(npdt(dtype))
+            ref = oracle.matrix(ko, xs, xs) @ a.astype(np.float64)
+            b = (G @ torch.from_numpy(a).cuda()).cpu().numpy()
+            assert relerr(b, ref) <= tol, (n, relerr(b, ref))
+            if n == 32:
+                assert relerr(G.to_dense().cpu().numpy(), oracle.matrix(ko, xs, xs)) <= tol
+                # periodic boundary conditions -> Circulant
+                Cc = cg.gramian(k, x, cg.PeriodicInput())
+                assert isinstance(Cc, cg.Circulant)
+                vc, _ = oracle.toeplitz_vectors(ko, oracle.srange(-1, 1, n))
+                refc = oracle.toeplitz_dense(vc, circulant=True) @ a.astype(np.float64)
+                assert relerr((Cc @ torch.from_numpy(a).cuda()).cpu().numpy(), refc) <= tol
+                # shifted y with the same step -> non-symmetric Toeplitz
+                y = x + 0.37
+                Tn = cg.gramian(k, x, y)
+                assert isinstance(Tn, cg.Toeplitz)
+                ys = xs + 0.37
+                assert relerr((Tn @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.matrix(ko, xs, ys) @ a.astype(np.float64)) <= tol
+                # different step -> plain Gramian
+                assert isinstance(cg.gramian(k, x, cg.srange(-1, 1, n // 2, dtype)), cg.Gramian)
+            # alpha/beta
+            y0 = np.random.default_rng(n + 1).standard_normal(n).astype(npdt(dtype))
+            yd = torch.from_numpy(y0.copy()).cuda()
+            cg.mul_(yd, G, torch.from_numpy(a).cuda(), 0.3, -1.1)
+            assert relerr(yd.cpu().numpy(), 0.3 * ref - 1.1 * y0) <= tol
+
+
+def test_kronecker_and_separable(cg, oracle):
+    """test/algebra.jl:70-89, test/separable.jl:9-28 (+ the MVM the reference never asserts)."""
+    rng = np.random.default_rng(5)
+    n, d = 4, 3
+    x = rng.standard_normal(n); y = rng.standard_normal(2 * n)
+    gx, gy = cg.LazyGrid(torch.from_numpy(x), d), cg.LazyGrid(torch.from_numpy(y), d)
+    p3 = cg.separable("*", *(cg.EQ() for _ in range(d)))
+    G = cg.gramian(p3, gx, gy)
+    assert isinstance(G, cg.KroneckerProduct) and tuple(G.shape) == (n ** d, (2 * n) ** d)
+    ko = oracle.Kernel(oracle.EQ)
+    F = oracle.matrix(ko, x, y)
+    a = rng.standard_normal((2 * n) ** d)
+    ref = oracle.kron_mul(None, [F, F, F], a)
+    assert relerr((G @ torch.from_numpy(a).cuda()).cpu().numpy(), ref) <= 1e-12
+    assert relerr(G.to_dense().cpu().numpy(), oracle.kron_dense([F, F, F])) <= 1e-12
+    # EQ is separable in dimension: the Kronecker Gramian equals the isotropic Gramian on the grid points
+    Gx = cg.gramian(cg.EQ(), gx.points("cuda"), gy.points("cuda"))
+    assert relerr((Gx @ torch.from_numpy(a).cuda()).cpu().numpy(), ref) <= 1e-11
+    # non-identical factors: standard Kronecker order (first factor slowest)
+    f1 = rng.standard_normal((3, 5)); f2 = rng.standard_normal((4, 2)); f3 = rng.standard_normal((2, 6))
+    Kp = cg.kronecker(*(torch.from_numpy(f).cuda() for f in (f1, f2, f3)))
+    av = rng.standard_normal(5 * 2 * 6)
+    assert relerr((Kp @ torch.from_numpy(av).cuda()).cpu().numpy(), np.kron(np.kron(f1, f2), f3) @ av) <= 1e-12
+    # SeparableKernel: kronecker(K) = gramian(k, x) ⊗ B
+    B = rng.standard_normal((3, 3)); B = B.T @ B
+    xs = rng.standard_normal(3)
+    S = cg.gramian(cg.Separable(cg.EQ(), B), torch.from_numpy(xs).cuda())
+    assert tuple(S.shape) == (9, 9)
+    MK = np.kron(oracle.matrix(ko, xs, xs), B)
+    assert relerr(cg.kronecker(S).to_dense().cpu().numpy(), MK) <= 1e-12
+    v = rng.standard_normal(9)
+    assert relerr((S @ torch.from_numpy(v).cuda()).cpu().numpy(), MK @ v) <= 1e-12
+
+
+def test_lowrank_finite_basis(cg, oracle):
+    """test/mercer.jl:23-38."""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(16)
+    k = cg.FiniteBasis([torch.sin, torch.cos, lambda t: t])
+    G = cg.gramian(k, torch.from_numpy(x).cuda())
+    assert isinstance(G, cg.LazyMatrixProduct)
+    U = np.stack([np.sin(x), np.cos(x), x], axis=1)
+    assert relerr(G.to_dense().cpu().numpy(), U @ U.T) <= 1e-13
+    a = rng.standard_normal(16); y0 = rng.standard_normal(16)
+    yd = torch.from_numpy(y0.copy()).cuda()
+    cg.mul_(yd, G, torch.from_numpy(a).cuda(), 1.7, -0.4)
+    assert relerr(yd.cpu().numpy(), oracle.lowrank_mul(y0, U, U, a, 1.7, -0.4)) <= 1e-12
+    # larger, rectangular, fp32
+    n, m, r = 5000, 3000, 7
+    xs = rng.standard_normal(n).astype(np.float32); ys = rng.standard_normal(m).astype(np.float32)
+    fns = [lambda t, i=i: torch.cos(i * t) for i in range(r)]
+    G2 = cg.gramian(cg.FiniteBasis(fns), torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda())
+    Un = np.stack([np.cos(i * xs.astype(np.float64)) for i in range(r)], 1); Vn = np.stack([np.cos(i * ys.astype(np.float64)) for i in range(r)], 1)
+    av = rng.standard_normal(m).astype(np.float32)
+    assert relerr((G2 @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.lowrank_mul(None, Un, Vn, av)) <= 2e-5
+
+
+def test_errors_and_traits(cg):
+    x = torch.randn(10, 3, device="cuda", dtype=torch.float64)
+    with pytest.raises(cg.DimensionMismatch):
+        cg.gramian(cg.EQ(), x, torch.randn(10, 2, device="cuda", dtype=torch.float64))
+    G = cg.gramian(cg.EQ(), x)
+    with pytest.raises(cg.DimensionMismatch):
+        G @ torch.randn(11, device="cuda", dtype=torch.float64)
+    Gg = cg.gramian(lambda a, b: 1.0, x)       # GenericInput closure: no device path, no CPU fallback
+    with pytest.raises(cg.UnsupportedKernel):
+        Gg @ torch.randn(10, device="cuda", dtype=torch.float64)
+    assert isinstance(G + torch.ones(10, device="cuda", dtype=torch.float64), cg.LazyMatrixSum)
+
+
+def test_lazy_sum_with_diagonal(cg, oracle):
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((300, 2)); a = rng.standard_normal(300)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda())
+    S = G + 1e-2 * torch.ones(300, device="cuda", dtype=torch.float64)
+    b = (S @ torch.from_numpy(a).cuda()).cpu().numpy()
+    assert relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a) + 1e-2 * a) <= 1e-12
