@@ -47,27 +47,44 @@ class ShardedGramian:
             self.local = None
         self.shape = (self.n, self.m)
 
-    def matmul(self, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """b = G a, complete on every rank.  a: (m,) or (m, p), replicated."""
-        tail = tuple(a.shape[1:])
-        shard = torch.zeros((self.per,) + tail, dtype=a.dtype, device=a.device)
-        if self.local is not None:
-            rows = self.hi - self.lo
-            view = shard[:rows]
-            from .gramian import LazyOperator
-            if isinstance(self.local, LazyOperator):
-                self.local.mul_(view, a, 1.0, 0.0)
-            else:
-                view.copy_(self.local(a))
-        if self.world == 1:
-            full = shard
+    def _buffers(self, a: torch.Tensor):
+        key = (tuple(a.shape[1:]), a.dtype, a.device)
+        if getattr(self, "_buf_key", None) != key:
+            tail = tuple(a.shape[1:])
+            self._shard = torch.zeros((self.per,) + tail, dtype=a.dtype, device=a.device)
+            self._full = torch.empty((self.per * self.world,) + tail, dtype=a.dtype, device=a.device) if self.world > 1 else None
+            self._buf_key = key
+        return self._shard, self._full
+
+    def _local_into(self, view: torch.Tensor, a: torch.Tensor):
+        from .gramian import LazyOperator
+        if isinstance(self.local, LazyOperator):
+            self.local.mul_(view, a, 1.0, 0.0)
         else:
-            full = torch.empty((self.per * self.world,) + tail, dtype=a.dtype, device=a.device)
-            dist.all_gather_into_tensor(full, shard, group=self.group)     # the ONLY collective of the MVM
+            view.copy_(self.local(a))
+
+    def matmul(self, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """b = G a, complete on every rank.  a: (m,) or (m, p), replicated.  Buffers are allocated once and reused
+        (Krylov callers multiply with the same shapes every iteration)."""
+        rows = self.hi - self.lo
+        if self.world == 1:
+            if out is None:
+                out = torch.empty((self.n,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+            if self.local is not None:
+                self._local_into(out, a)
+            return out
+        shard, full = self._buffers(a)
+        if self.local is not None:
+            self._local_into(shard[:rows], a)
+        exact = (self.per * self.world == self.n)
+        target = out if (exact and out is not None and out.is_contiguous()) else full
+        dist.all_gather_into_tensor(target, shard, group=self.group)       # the ONLY collective of the MVM
+        if target is out:
+            return out
         b = full[: self.n]
         if out is not None:
             out.copy_(b)
             return out
-        return b
+        return b.clone()
 
     __matmul__ = matmul

@@ -43,6 +43,15 @@ class _Ctx:
         _ffi.check(_ffi.lib().covgram_ctx_set_option(self.handle, key.encode(), int(value)))
 
 
+def kernel_time(device=None, reset=True):
+    """(total_ms, launches) of the HIP-event-bracketed dominant kernels since the last reset
+    (enable with set_option("time_kernels", 1))."""
+    ctx = get_ctx(device)
+    ms, cnt = C.c_double(0), C.c_int64(0)
+    _ffi.check(_ffi.lib().covgram_ctx_kernel_time(ctx.handle, C.byref(ms), C.byref(cnt), 1 if reset else 0))
+    return ms.value, cnt.value
+
+
 def get_ctx(device=None) -> _Ctx:
     """The library context for `device` (default: torch's current CUDA/HIP device).  Raises if the
     shared library is missing or no gfx950 device is visible — there is no CPU fallback."""

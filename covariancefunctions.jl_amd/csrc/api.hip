@@ -180,6 +180,17 @@ int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out) {
 }
 
 // dense instantiation: generic over family via a uniform switch (HBM-write-bound, n*m*sizeof(T) out)
+std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx) {
+    if (!ctx->time_kernels) return nullptr;
+    if (ctx->timers_used == ctx->timers.size()) {
+        if (ctx->timers.size() >= 8192) return nullptr;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        ctx->timers.emplace_back(a, b);
+    }
+    return &ctx->timers[ctx->timers_used++];
+}
+
 template <typename T>
 __device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
     T v;
@@ -280,6 +291,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
+    for (auto& t : ctx->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return COVGRAM_OK;
@@ -305,7 +317,23 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
+    else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
+    return COVGRAM_OK;
+}
+
+int covgram_ctx_kernel_time(covgram_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset) {
+    CG_REQUIRE(ctx && total_ms && launches, COVGRAM_EINVAL, "NULL argument");
+    CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (size_t i = 0; i < ctx->timers_used; ++i) {
+        float ms = 0;
+        CG_CHECK_HIP(hipEventElapsedTime(&ms, ctx->timers[i].first, ctx->timers[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)ctx->timers_used;
+    if (reset) ctx->timers_used = 0;
     return COVGRAM_OK;
 }
 
@@ -466,7 +494,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         da.variant = (int)ctx->dense_variant; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
         if (jsplit == 1) da.out = y_c;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
+        auto* tm = timer_next(ctx);
+        if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(da, dtype); if (rc) return rc;
+        if (tm) (void)hipEventRecord(tm->second, ctx->stream);
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
@@ -574,7 +605,10 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         if (jsplit == 1) ga.out = y_dev;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * D * npad * ts, &ga.out); if (rc) return rc; }
+        auto* tm = timer_next(ctx);
+        if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(ga, dtype); if (rc) return rc;
+        if (tm) (void)hipEventRecord(tm->second, ctx->stream);
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const float*)ga.out,

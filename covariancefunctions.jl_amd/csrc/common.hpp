@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/covgram.h"
 
@@ -98,6 +100,10 @@ struct covgram_ctx {
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int num_cus = 256;
     int live_handles = 0;
+    // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
+    int64_t time_kernels = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;
+    size_t timers_used = 0;
 };
 
 struct covgram_points {
@@ -112,6 +118,8 @@ struct covgram_points {
 namespace covgram {
 
 int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out);
+// returns an event pair to record around the dominant kernel, or nullptr when timing is off / the pool is full
+std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx);
 inline size_t dtype_size(int dtype) { return dtype == COVGRAM_F64 ? 8 : 4; }
 
 // dispatch tables implemented in the per-family translation units -------------------------------

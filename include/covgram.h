@@ -103,6 +103,9 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 /* tuning / A-B knobs, e.g. "dense_variant" (0 = scalar-cache broadcast, 1 = LDS-staged), "rows_per_lane", "jsplit". */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 int covgram_sync(covgram_ctx* ctx);
+/* With option "time_kernels" = 1 every dense / gradient MVM brackets its dominant kernel with HIP events on the
+ * ctx stream; this returns the summed device time and the number of launches since the last reset. */
+int covgram_ctx_kernel_time(covgram_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* x: n points of dimension d, point-major.  loc == HOST: copied to the device; loc == DEVICE: borrowed
  * (the caller keeps it alive and unchanged while the handle lives). */

@@ -1,0 +1,66 @@
+"""Multi-process CPU test of the row-sharded MVM: world_size 2 over gloo.  The local operator is
+injected (the oracle, on CPU) so that the sharding + single all-gather logic of covgram.dist runs without a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, m, d, nrhs, q):
+    sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import covgram as cg
+    import covgram_oracle as o
+    rng = np.random.default_rng(123)             # same seed on every rank: replicated inputs
+    X = torch.from_numpy(rng.standard_normal((n, d))); Y = torch.from_numpy(rng.standard_normal((m, d)))
+    a = torch.from_numpy(rng.standard_normal((m, nrhs) if nrhs > 1 else m))
+    ko = o.Kernel(o.MATERNP, p=2)
+
+    def factory(k, x_rows, y_full):              # CPU stand-in for the device Gramian
+        return lambda vec: torch.from_numpy(o.mul(None, ko, x_rows.numpy(), y_full.numpy(), vec.numpy()))
+
+    G = cg.ShardedGramian(cg.MaternP(2), X, Y, local_factory=factory)
+    b = G @ a
+    ref = o.mul(None, ko, X.numpy(), Y.numpy(), a.numpy())
+    err = float(np.linalg.norm(b.numpy() - ref) / np.linalg.norm(ref))
+    q.put((rank, G.lo, G.hi, tuple(b.shape), err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n, m, d, nrhs, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, d, nrhs, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_row_sharded_mvm_world2_vector():
+    res = _run(n=101, m=67, d=3, nrhs=1)
+    assert [r[1:3] for r in res] == [(0, 51), (51, 101)]
+    for r in res:
+        assert r[3] == (101,) and r[4] < 1e-14
+
+
+def test_row_sharded_mvm_world2_matrix_and_ragged():
+    res = _run(n=3, m=40, d=2, nrhs=3)           # n < 2*ceil: second shard is short
+    assert [r[1:3] for r in res] == [(0, 2), (2, 3)]
+    for r in res:
+        assert r[3] == (3, 3) and r[4] < 1e-14

@@ -1,0 +1,143 @@
+"""CPU tier: the C-ABI library loads and exports every declared symbol (no compute without a GPU), the
+parameter tables the device kernels receive, the host-side trait/lowering logic, and the loud failure
+of the product path when no GPU is present."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import covgram_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol(cg):
+    header = open(os.path.join(ROOT, "include", "covgram.h")).read()
+    declared = set(re.findall(r"\b(covgram_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = cg._ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/covgram.h but not exported"
+    assert declared == set(cg._ffi.PROTOTYPES), declared ^ set(cg._ffi.PROTOTYPES)
+    assert lib.covgram_version() == 100
+    # and the library links only what the image provides
+    assert os.path.exists(cg._ffi.LIB_PATH)
+
+
+def test_struct_layout_matches_header(cg):
+    assert C.sizeof(cg._ffi.covgram_kernel) == 4 * 4 + 3 * 8
+
+
+def test_kernel_parameter_tables_match_exact_rationals(cg):
+    lib = cg._ffi.lib()
+    out = (C.c_double * 45)()
+    for p in range(0, 9):
+        spec = cg.device_spec(cg.MaternP(p))
+        for dtype, eps in ((cg._ffi.F32, np.finfo(np.float32).eps), (cg._ffi.F64, np.finfo(np.float64).eps)):
+            assert lib.covgram_debug_kernel_params(C.byref(spec), dtype, 0, out) == 0
+            v = list(out)
+            assert v[5] == 2 * p + 1
+            h0 = [float(x) for x in o.maternp_poly(p)]
+            assert np.allclose(v[9:9 + p + 1], h0, rtol=1e-15)
+            if p >= 1:
+                d = [float(x) for x in o.maternp_derivatives_at_zero(p)]
+                assert np.isclose(v[7], d[0], rtol=1e-15)
+                ty = [1.0] + [d[i - 1] / math.factorial(i) for i in range(1, p + 1)]
+                assert np.allclose(v[36:36 + p + 1], ty, rtol=1e-14)
+                assert np.isclose(v[6], float(eps) ** (1.0 / p), rtol=1e-15)
+                assert np.allclose(v[18:18 + p], [float(x) for x in o.maternp_poly(p - 1)], rtol=1e-15)
+            if p >= 2:
+                assert np.isclose(v[8], d[1], rtol=1e-15)
+                assert np.allclose(v[27:27 + p - 1], [float(x) for x in o.maternp_poly(p - 2)], rtol=1e-15)
+    # EQ: dense path folds sqrt(log2(e)/2)/l into gamma, gradient path keeps gamma = 1/l
+    spec = cg.device_spec(cg.Lengthscale(cg.EQ(), 0.5))
+    lib.covgram_debug_kernel_params(C.byref(spec), cg._ffi.F32, 0, out)
+    assert np.isclose(out[0], 2.0 * math.sqrt(0.5 * math.log2(math.e)))
+    lib.covgram_debug_kernel_params(C.byref(spec), cg._ffi.F32, 1, out)
+    assert np.isclose(out[0], 2.0) and np.isclose(out[4], -0.5 * math.log2(math.e))
+    # invalid kernels are rejected with the reference's error classes
+    bad = cg._ffi.covgram_kernel(cg._ffi.EQ, cg._ffi.DOTPRODUCT, 0, 1, 0.0, 1.0, 1.0)
+    assert lib.covgram_debug_kernel_params(C.byref(bad), 0, 0, out) == cg._ffi.EINVAL
+    bad = cg._ffi.covgram_kernel(cg._ffi.MATERNP, cg._ffi.ISOTROPIC, 9, 1, 0.0, 1.0, 1.0)
+    assert lib.covgram_debug_kernel_params(C.byref(bad), 0, 0, out) == cg._ffi.EUNSUPPORTED
+    assert b"MaternP" in lib.covgram_last_error()
+
+
+def test_input_traits_like_test_properties_jl(cg):
+    """test/properties.jl:10-32, test/gradient_algebra.jl:13-31."""
+    iso, dot, gen = cg.IsotropicInput(), cg.DotProductInput(), cg.GenericInput()
+    for k in (cg.EQ(), cg.RQ(1.0), cg.Exp(), cg.MaternP(2), cg.Lengthscale(cg.EQ(), 2.0), cg.Cauchy()):
+        assert cg.input_trait(k) == iso
+    for k in (cg.Dot(), cg.ExponentialDot(), cg.Dot() ** 3):
+        assert cg.input_trait(k) == dot
+    assert cg.input_trait(2.0 * cg.EQ()) == iso                       # constants are ignored
+    assert cg.input_trait(cg.EQ() * cg.RQ(1.0) + 1.0) == iso
+    assert cg.input_trait(cg.EQ() + cg.Dot()) == gen                  # mixed -> GenericInput
+    assert cg.input_trait(lambda x, y: 1.0) == gen
+    assert cg.input_trait(cg.GradientKernel(cg.EQ())) == iso
+    assert cg.input_trait(cg.GradientKernel(cg.Dot() ** 3)) == dot
+    assert cg.isisotropic(cg.EQ()) and cg.isstationary(cg.EQ()) and cg.ismercer(cg.EQ()) and not cg.isdot(cg.EQ())
+    assert cg.isdot(cg.Dot() ** 2) and not cg.isisotropic(cg.Dot())
+    # user extension point (README.md:90-99, test/gramian.jl:158-167)
+    f = lambda x, y: cg.EQ()(x, y)
+    cg.register_input_trait(f, cg.IsotropicInput())
+    assert cg.input_trait(f) == iso
+
+
+def test_kernel_lowering_and_folding(cg):
+    s = cg.device_spec(cg.Lengthscale(cg.MaternP(2), 0.7) ** 2 * 3.0)
+    assert (s.family, s.trait, s.p, s.power, s.lengthscale, s.scale) == (cg._ffi.MATERNP, cg._ffi.ISOTROPIC, 2, 2, 0.7, 3.0)
+    s = cg.device_spec((2.0 * cg.EQ()) ** 3)
+    assert s.power == 3 and s.scale == 8.0
+    s = cg.device_spec(cg.Lengthscale(cg.Lengthscale(cg.EQ(), 2.0), 3.0))
+    assert s.lengthscale == 6.0
+    assert cg.device_spec(cg.EQ() + cg.RQ(1.0)) is None and cg.device_spec(cg.Matern(2.7)) is None
+    assert cg.device_spec(cg.RQ(0.3)).param == 0.3 and cg.device_spec(cg.InverseMultiQuadratic(1.5)).param == 1.5
+    with pytest.raises(cg.DomainError):
+        cg.RQ(-1.0)
+    with pytest.raises(cg.DomainError):
+        cg.MaternP(-1)
+    with pytest.raises(cg.DomainError):
+        cg.Lengthscale(cg.EQ(), 0.0)
+    with pytest.raises(cg.DomainError):
+        cg.GammaExp(2.5)
+
+
+def test_host_kernel_call_matches_oracle_profiles(cg):
+    """k(x, y) on the host (API parity with the Julia call operators) agrees with the oracle's phi."""
+    import kernel_cases
+    rng = np.random.default_rng(8)
+    for name, k, ko in kernel_cases.cases(cg):
+        for d in (1, 3):
+            x, y = rng.standard_normal(d), rng.standard_normal(d)
+            assert np.isclose(k(x, y), float(o.matrix(ko, x[None], y[None])[0, 0]), rtol=1e-13), name
+    assert cg.Constant(2.0)(1.0, 3.0) == 2.0
+    assert np.isclose((cg.Dot() ** 3)(np.array([1.0, 2.0]), np.array([0.5, -1.0])), (-1.5) ** 3)
+    with pytest.raises(cg.DimensionMismatch):
+        cg.EQ()(np.zeros(2), np.zeros(3))                              # util.jl:41
+
+
+def test_product_path_fails_loudly_without_gpu(cg):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    n = C.c_int(-1)
+    assert cg._ffi.lib().covgram_device_count(C.byref(n)) == 0 and n.value == 0
+    h = cg._ffi._P()
+    assert cg._ffi.lib().covgram_ctx_create(C.byref(h), 0, None) == cg._ffi.ENODEVICE
+    with pytest.raises(cg.NoDevice):
+        cg.get_ctx()
+    with pytest.raises(cg.NoDevice):
+        cg.gramian(cg.EQ(), torch.randn(8, 3))                         # no CPU fallback anywhere
+
+
+def test_shard_bounds(cg):
+    for n in (1, 7, 8, 131072, 524288 + 3):
+        for world in (1, 2, 4, 8):
+            spans = [cg.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) == (n + world - 1) // world
