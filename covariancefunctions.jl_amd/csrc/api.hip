@@ -317,6 +317,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
+    else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -409,9 +410,11 @@ static int check_pair(const covgram_ctx* ctx, const covgram_points* X, const cov
 
 // choose the J split: enough workgroups to fill the chip, chunks aligned to the inner accumulation block
 static void choose_split(const covgram_ctx* ctx, int64_t rowblocks, int64_t m, int64_t align, int64_t* jchunk, int* jsplit) {
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 8;
+    // ~32 workgroups per CU: several rounds of resident workgroups even out the tail (measured on C2: 2.77 ms at 8 per
+    // CU, 2.56 ms at 32 per CU, profiles/r01_quickbench_packed.txt)
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 32;
     int64_t js = ctx->jsplit > 0 ? ctx->jsplit : (target + rowblocks - 1) / std::max<int64_t>(rowblocks, 1);
-    const int64_t maxsplit = std::max<int64_t>(1, m / (2 * align));
+    const int64_t maxsplit = std::max<int64_t>(1, m / align);
     js = std::max<int64_t>(1, std::min(js, maxsplit));
     int64_t jc = (m + js - 1) / js;
     jc = ((jc + align - 1) / align) * align;
@@ -457,7 +460,8 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     }
 
     const double alpha_eff = alpha * hk.kp.scale;
-    const int R = rows_per_lane_for(D, dtype);
+    const int R = rows_per_lane_for(D);
+    const int PKN = (dtype == COVGRAM_F32) ? 2 : 1;      // fp32 packs two columns per stream element
     const int64_t rows_per_wg = (int64_t)DENSE_THREADS * R;
     const int64_t rowblocks = (n + rows_per_wg - 1) / rows_per_wg;
     const int64_t npad = rowblocks * rows_per_wg;
@@ -479,13 +483,14 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             continue;
         }
         void* P;
-        rc = ws_reserve(ctx, 0, (size_t)m * (D + NRpad) * ts, &P); if (rc) return rc;
+        const int64_t mp = ((m + PKN - 1) / PKN) * PKN;     // stream padded to whole column groups
+        rc = ws_reserve(ctx, 0, (size_t)mp * (D + NRpad) * ts, &P); if (rc) return rc;
         if (dtype == COVGRAM_F32)
-            hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, (float)hk.kp.gamma);
+            hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma);
         else
-            hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, hk.kp.gamma);
+            hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma);
         int64_t jchunk; int jsplit;
         choose_split(ctx, rowblocks, m, DENSE_INNER, &jchunk, &jsplit);
         DenseArgs da;
@@ -601,7 +606,7 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         int64_t jchunk; int jsplit;
         choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
         GradArgs ga;
-        ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit;
+        ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         if (jsplit == 1) ga.out = y_dev;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * D * npad * ts, &ga.out); if (rc) return rc; }

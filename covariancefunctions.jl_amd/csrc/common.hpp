@@ -98,6 +98,7 @@ struct covgram_ctx {
     int64_t rows_per_lane = 0;   // 0 = auto
     int64_t jsplit = 0;          // 0 = auto
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
+    int64_t grad_keep_r = -1;    // -1 auto
     int num_cus = 256;
     int live_handles = 0;
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
@@ -142,6 +143,7 @@ struct GradArgs {
     const void* P; int64_t m;              // packed [m][2*D] stream: y_j (scaled) then a_j
     void* out; int64_t npad;               // partials [jsplit][npad][D] or final
     int32_t Dpad; int64_t jchunk; int32_t jsplit;
+    int32_t keep_r;                        // -1 auto, 0 recompute r in sweep 2, 1 keep r in VGPRs
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;

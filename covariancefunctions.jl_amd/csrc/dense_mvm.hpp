@@ -3,86 +3,114 @@
 // squared distance by DIRECT differences src/util.jl:40-47, dot product src/mercer.jl:3).
 //
 // MI355X mapping:
-//   * one LANE owns R output rows (x_i lives in 3R..D*R VGPRs, NRHS*R accumulators): no cross-lane
-//     reduction exists anywhere in the pair loop;
-//   * the column stream P[j] = (gamma*y_j[0..D), a_j[0..NRHS)) is wave-uniform.  Variant 0 reads it
-//     through the scalar data cache (s_load_dwordxN -> SGPR operands of the VALU ops: zero VGPR/LDS
-//     cost, the CDNA-native broadcast); variant 1 stages 16 KiB tiles in LDS and reads them back as
-//     same-address (broadcast) ds_read_b128;
-//   * the grid is (row blocks) × (J splits): every workgroup owns a 256*R-row × jchunk-column
-//     rectangle, partial sums go to a [jsplit][NRHS][npad] slab and a tiny second kernel applies
-//     alpha/beta (deterministic; no float atomics);
-//   * fp32 accumulation is two-level (512-column inner chunks) so the error against the fp64
-//     oracle stays ~1e-6 at m = 2^17 (SURVEY §7 "fp32 accumulation").
+//   * one LANE owns R output rows (x_i lives in VGPRs, NRHS*R accumulators): there is no cross-lane
+//     reduction anywhere in the pair loop;
+//   * the column stream is wave-uniform and is read through the scalar data cache (s_load_dwordx8/x16),
+//     so y_j and a_j are SGPR operands of the VALU instructions: no LDS, no VGPR copies, no barriers.
+//     (An LDS-staged variant — 16 KiB double-buffered tiles read back as broadcast ds_read_b128 — was
+//     built and measured 14 % slower on MI355X, profiles/r01_quickbench_variant_ab.txt, and removed.)
+//   * fp32 processes TWO columns per instruction with packed math (v_pk_add/mul/fma_f32): the stream is
+//     stored pair-interleaved, P[g] = (y_{2g,l}, y_{2g+1,l})_l, (a_{2g,c}, a_{2g+1,c})_c, so each 64-bit
+//     SGPR pair is one packed operand and x_il is splat.  Measured issue cost per 64 pairs and SIMD
+//     (tools/microbench.hip, profiles/r01_microbench_valu_rates.txt): 23.2 cycles packed vs 30.1 scalar;
+//     v_exp_f32 (8.2 cycles, quarter rate) is the single most expensive instruction of the pair body;
+//   * the grid is (row blocks) × (J splits): every workgroup owns a 256*R-row × jchunk-column rectangle,
+//     partial sums go to a [jsplit][NRHS][npad] slab and a tiny second kernel applies alpha/beta
+//     (deterministic; no float atomics);
+//   * accumulation is two-level (512-column inner chunks, then per-split partials) so the fp32 error
+//     against the fp64 oracle stays ~3e-7 at m = 2^17 (a sequential fp32 sum drifts to ~6e-6).
 #pragma once
 #include "profiles.hpp"
 
 namespace covgram {
 
 constexpr int DENSE_THREADS = 256;
-constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns)
+constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, so column pairs never straddle chunks
 
-template <int D, int NR>
-constexpr int stride_of() { return D + NR; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Dimensions are consumed in chunks of one 64-byte scalar load (16 floats / 8 doubles); for D larger
-// than a chunk a scheduling barrier after each chunk keeps hipcc from hoisting every s_load of a column
-// to the top, which would overflow the ~100 usable SGPRs and spill them through v_writelane.
-template <typename T> constexpr int dim_chunk() { return 64 / (int)sizeof(T); }
+// columns per stream element: 2 for float (packed math), 1 for double
+template <typename T> struct Pk;
+template <> struct Pk<float> {
+    using V = v2f;
+    static constexpr int N = 2;
+    static __device__ __forceinline__ V splat(float x) { return (V){x, x}; }
+    static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ float hsum(V a) { return a.x + a.y; }
+    template <class F> static __device__ __forceinline__ V map(V s, F f) { return (V){f(s.x), f(s.y)}; }
+};
+template <> struct Pk<double> {
+    using V = double;
+    static constexpr int N = 1;
+    static __device__ __forceinline__ V splat(double x) { return x; }
+    static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double hsum(V a) { return a; }
+    template <class F> static __device__ __forceinline__ V map(V s, F f) { return f(s); }
+};
 
-template <typename T, int FAM, int D, int NR, int R, bool POW, bool ISO, int JU>
+// Dimensions are consumed in chunks of one 64-byte scalar load; for rows wider than a chunk a scheduling
+// barrier after each chunk keeps hipcc from hoisting every s_load of a column group to the top, which would
+// overflow the ~100 usable SGPRs and spill them through v_writelane.
+template <typename T, int FAM, int D, int NR, int R, bool POW, bool ISO>
 struct DenseBody {
-    // One column j against R rows.  p points at the (uniform) packed record of column j.
-    template <typename PT>
-    static __device__ __forceinline__ void step(const PT* __restrict__ p, const T (&x)[R][D], T (&acc)[R][NR],
+    using PK = Pk<T>;
+    using V = typename PK::V;
+    static constexpr int DC = 64 / (int)sizeof(V);
+
+    // One column group (PK::N columns) against R rows.  p points at the (uniform) packed record of the group.
+    static __device__ __forceinline__ void step(const V* __restrict__ p, const T (&x)[R][D], V (&acc)[R][NR],
                                                 const KParams<T>& kp) {
-        constexpr int DC = dim_chunk<T>();
-        T s[R];
+        V s[R];
 #pragma unroll
         for (int c0 = 0; c0 < D; c0 += DC) {
 #pragma unroll
             for (int l = c0; l < ((c0 + DC < D) ? c0 + DC : D); ++l) {
-                const T yl = p[l];
+                const V yl = p[l];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    const V xl = PK::splat(x[r][l]);
                     if constexpr (ISO) {
-                        const T dl = x[r][l] - yl;
-                        s[r] = (l == 0) ? dl * dl : cg_fma(dl, dl, s[r]);
+                        const V dl = xl - yl;
+                        s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
                     } else {
-                        s[r] = (l == 0) ? x[r][l] * yl : cg_fma(x[r][l], yl, s[r]);
+                        s[r] = (l == 0) ? xl * yl : PK::fma(xl, yl, s[r]);
                     }
                 }
             }
             if constexpr (D > DC) __builtin_amdgcn_sched_barrier(0);
         }
-        T aj[NR];
+        V aj[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) aj[c] = p[D + c];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ), POW>(s[r], kp);
+            const V kv = PK::map(s[r], [&](T sv) { return phi_value<FAM, T, (FAM == COVGRAM_EQ), POW>(sv, kp); });
 #pragma unroll
-            for (int c = 0; c < NR; ++c) acc[r][c] = cg_fma(aj[c], kv, acc[r][c]);
+            for (int c = 0; c < NR; ++c) acc[r][c] = PK::fma(aj[c], kv, acc[r][c]);
         }
     }
 };
 
-// VARIANT 0: scalar-cache stream.  VARIANT 1: LDS-staged tiles.
-template <typename T, int FAM, int D, int NR, int R, bool POW, int VARIANT>
+template <typename T, int FAM, int D, int NR, int R, bool POW>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
-    const T* __restrict__ X, int64_t n, int32_t d, const T* __restrict__ P, int64_t m, T* __restrict__ out,
-    int64_t npad, int64_t ldy, int32_t nrhs, int64_t jchunk, T alpha, T beta, int32_t final_store,
-    const KParams<T> kp) {
+    const T* __restrict__ X, int64_t n, int32_t d, const typename Pk<T>::V* __restrict__ P, int64_t m,
+    T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs, int64_t jchunk, T alpha, T beta,
+    int32_t final_store, const KParams<T> kp) {
     constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
-    constexpr int S = D + NR;
-    constexpr int W = D * (int)sizeof(T) / 4;   // row width in dwords
-    constexpr int JU = (W <= 4) ? 8 : ((W <= 16) ? 4 : ((W <= 32) ? 2 : 1));
-    using Body = DenseBody<T, FAM, D, NR, R, POW, ISO, JU>;
+    using Body = DenseBody<T, FAM, D, NR, R, POW, ISO>;
+    using PK = Pk<T>;
+    using V = typename PK::V;
+    constexpr int S = D + NR;                               // stream elements per column group
+    constexpr int W = D * (int)sizeof(V) / 4;               // SGPRs per column group (coordinates)
+    constexpr int GU = (W <= 8) ? 4 : ((W <= 32) ? 2 : 1);  // groups per unrolled step
+    constexpr int GINNER = DENSE_INNER / PK::N;
 
     const int tid = threadIdx.x;
     const int64_t row_base = (int64_t)blockIdx.x * (DENSE_THREADS * R);
     const int64_t j0 = (int64_t)blockIdx.y * jchunk;
     const int64_t j1 = (j0 + jchunk < m) ? (j0 + jchunk) : m;
+    const int64_t g0 = j0 / PK::N;                          // jchunk is a multiple of DENSE_INNER (even)
+    const int64_t g1 = (j1 + PK::N - 1) / PK::N;            // the stream is padded to whole groups (a = 0)
 
     // rows of this lane: row_base + r*256 + tid  (coalesced across the wave for every r)
     T x[R][D];
@@ -91,8 +119,13 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
         int64_t row = row_base + (int64_t)r * DENSE_THREADS + tid;
         if (row >= n) row = n - 1;  // clamp: computed but never stored
         const T* xr = X + row * (int64_t)d;
+        if (d == D) {   // common case: no padding, straight loads
 #pragma unroll
-        for (int l = 0; l < D; ++l) x[r][l] = (l < d) ? xr[l] * kp.gamma : (T)0;
+            for (int l = 0; l < D; ++l) x[r][l] = xr[l] * kp.gamma;
+        } else {
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[r][l] = (l < d) ? xr[l] * kp.gamma : (T)0;
+        }
     }
 
     T tot[R][NR];
@@ -101,64 +134,24 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
 #pragma unroll
         for (int c = 0; c < NR; ++c) tot[r][c] = (T)0;
 
-    if constexpr (VARIANT == 0) {
-        for (int64_t jb = j0; jb < j1; jb += DENSE_INNER) {
-            const int64_t je = (jb + DENSE_INNER < j1) ? (jb + DENSE_INNER) : j1;
-            T acc[R][NR];
+    for (int64_t gb = g0; gb < g1; gb += GINNER) {
+        const int cnt = (int)(((gb + GINNER < g1) ? (gb + GINNER) : g1) - gb);
+        V acc[R][NR];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) acc[r][c] = (T)0;
-            const int cnt = (int)(je - jb);
-            const T* __restrict__ p = P + jb * S;       // uniform address -> s_load_dwordxN
-            int j = 0;
-            for (; j + JU <= cnt; j += JU, p += JU * S) {
+            for (int c = 0; c < NR; ++c) acc[r][c] = PK::splat((T)0);
+        const V* __restrict__ p = P + gb * S;               // uniform address -> s_load_dwordxN
+        int g = 0;
+        for (; g + GU <= cnt; g += GU, p += GU * S) {
 #pragma unroll
-                for (int u = 0; u < JU; ++u) Body::step(p + u * S, x, acc, kp);
-            }
-            for (; j < cnt; ++j, p += S) Body::step(p, x, acc, kp);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int c = 0; c < NR; ++c) tot[r][c] += acc[r][c];
+            for (int u = 0; u < GU; ++u) Body::step(p + u * S, x, acc, kp);
         }
-    } else {
-        // LDS-staged: tiles of DENSE_INNER columns, double-buffered, one barrier per tile.
-        // TJ columns per tile: 16 KiB per buffer (two buffers), a multiple of JU.
-        constexpr int TJ = ((16384 / (S * (int)sizeof(T))) / JU) * JU;
-        __shared__ __attribute__((aligned(16))) T tile[2][TJ * S];
-        const int64_t ntile = (j1 - j0 + TJ - 1) / TJ;
-        auto stage = [&](int buf, int64_t t) {
-            const int64_t jb = j0 + t * TJ;
-            const int64_t cnt = ((jb + TJ < j1) ? TJ : (j1 - jb)) * S;
-            const T* __restrict__ src = P + jb * S;
-            for (int64_t e = tid; e < cnt; e += DENSE_THREADS) tile[buf][e] = src[e];
-        };
-        if (ntile > 0) stage(0, 0);
-        __syncthreads();
-        for (int64_t t = 0; t < ntile; ++t) {
-            const int buf = (int)(t & 1);
-            if (t + 1 < ntile) stage(buf ^ 1, t + 1);
-            const int64_t jb = j0 + t * TJ;
-            const int cnt = (int)((jb + TJ < j1) ? TJ : (j1 - jb));
-            T acc[R][NR];
+        for (; g < cnt; ++g, p += S) Body::step(p, x, acc, kp);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) acc[r][c] = (T)0;
-            const T* tp = tile[buf];
-            int j = 0;
-            for (; j + JU <= cnt; j += JU) {
-#pragma unroll
-                for (int u = 0; u < JU; ++u) Body::step(tp + (j + u) * S, x, acc, kp);
-            }
-            for (; j < cnt; ++j) Body::step(tp + j * S, x, acc, kp);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int c = 0; c < NR; ++c) tot[r][c] += acc[r][c];
-            __syncthreads();
-        }
+            for (int c = 0; c < NR; ++c) tot[r][c] += PK::hsum(acc[r][c]);
     }
 
     // epilogue ------------------------------------------------------------------------------
@@ -200,16 +193,23 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const T* __restrict__
     *yp = v;
 }
 
-// P[j][0..D) = gamma * Y[j][0..d) (zero padded), P[j][D..D+NR) = A[j + c*lda] (zero padded)
+// Column stream, PK columns per group g:  P[(g*(D+NR) + l)*PK + h] = gamma * Y[g*PK+h][l]   (l < D, zero padded in l)
+//                                         P[(g*(D+NR) + D + c)*PK + h] = A[g*PK+h + (c0+c)*lda]
+// A column beyond m (odd m, fp32) duplicates the last point with weight 0, so it adds exactly 0 * phi(finite).
 template <typename T>
 __global__ __launch_bounds__(256) void dense_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
                                                          int64_t lda, int32_t nrhs, int32_t c0, T* __restrict__ P, int32_t D,
-                                                         int32_t NR, T gamma) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    T* p = P + j * (int64_t)(D + NR);
-    for (int l = 0; l < D; ++l) p[l] = (l < d) ? Y[j * (int64_t)d + l] * gamma : (T)0;
-    for (int c = 0; c < NR; ++c) p[D + c] = (c0 + c < nrhs) ? A[j + (int64_t)(c0 + c) * lda] : (T)0;
+                                                         int32_t NR, int32_t PKN, T gamma) {
+    const int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // padded column index
+    const int64_t mp = ((m + PKN - 1) / PKN) * PKN;
+    if (jj >= mp) return;
+    const bool pad = jj >= m;
+    const int64_t j = pad ? (m - 1) : jj;
+    const int64_t g = jj / PKN;
+    const int h = (int)(jj - g * PKN);
+    T* p = P + g * (int64_t)(D + NR) * PKN + h;
+    for (int l = 0; l < D; ++l) p[(int64_t)l * PKN] = (l < d) ? Y[j * (int64_t)d + l] * gamma : (T)0;
+    for (int c = 0; c < NR; ++c) p[(int64_t)(D + c) * PKN] = (!pad && c0 + c < nrhs) ? A[j + (int64_t)(c0 + c) * lda] : (T)0;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -221,35 +221,21 @@ static int launch_dense_one(const DenseArgs& a) {
     const int64_t rows_per_wg = (int64_t)DENSE_THREADS * R;
     dim3 grid((unsigned)((a.n + rows_per_wg - 1) / rows_per_wg), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
-    // the LDS-staged variant is compiled only where it is an A/B candidate (vector RHS, D <= 8)
-    constexpr bool HAS_LDS = (NR == 1 && !POW && D <= 8);
-    bool launched = false;
-    if constexpr (HAS_LDS) {
-        if (a.variant == 1) {
-            hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW, 1>), grid, dim3(DENSE_THREADS), 0, a.stream,
-                               (const T*)a.X, a.n, a.d, (const T*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs,
-                               a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp);
-            launched = true;
-        }
-    }
-    if (!launched)
-        hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW, 0>), grid, dim3(DENSE_THREADS), 0, a.stream,
-                           (const T*)a.X, a.n, a.d, (const T*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk,
-                           (T)a.alpha, (T)a.beta, final_store, kp);
+    hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW>), grid, dim3(DENSE_THREADS), 0, a.stream, (const T*)a.X, a.n,
+                       a.d, (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha,
+                       (T)a.beta, final_store, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
 }
 
-// rows per lane compiled for each D (register budget: R*(D+NR) VGPRs of state)
-template <typename T, int D> struct RowsFor {
-    static constexpr int W = D * (int)sizeof(T) / 4;
-    static constexpr int value = (W <= 4) ? 4 : ((W <= 16) ? 2 : 1);
-};
+// rows per lane compiled for each D (register budget: x is splat for fp32, so both dtypes cost 2 dwords per coordinate)
+template <int D> struct RowsFor { static constexpr int value = (D <= 4) ? 4 : ((D <= 16) ? 2 : 1); };
+inline int rows_per_lane_for(int Dpad) { return (Dpad <= 4) ? 4 : ((Dpad <= 16) ? 2 : 1); }
 
 template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {
-    constexpr int R = RowsFor<T, D>::value;
+    constexpr int R = RowsFor<D>::value;
     const bool pow = a.hk->k.power != 1;
     if (pow) return launch_dense_one<T, FAM, D, NR, R, true>(a);
     return launch_dense_one<T, FAM, D, NR, R, false>(a);
@@ -285,11 +271,6 @@ int launch_dense_family(const DenseArgs& a, int dtype) {
     }
     set_error("dense_mvm: nrhs pad %d not compiled", a.NRpad);
     return COVGRAM_EUNSUPPORTED;
-}
-
-inline int rows_per_lane_for(int Dpad, int dtype) {
-    const int W = Dpad * (dtype == COVGRAM_F64 ? 2 : 1);
-    return (W <= 4) ? 4 : ((W <= 16) ? 2 : 1);
 }
 
 }  // namespace covgram

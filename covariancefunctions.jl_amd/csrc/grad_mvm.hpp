@@ -36,11 +36,15 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_mvm_kernel(const T* __restr
     T x[D], b[D];
     {
         const T* xr = X + row * (int64_t)d;
+        if (d == D) {   // common case: no padding, straight vector loads
 #pragma unroll
-        for (int l = 0; l < D; ++l) {
-            x[l] = (l < d) ? xr[l] * kp.gamma : (T)0;
-            b[l] = (T)0;
+            for (int l = 0; l < D; ++l) x[l] = xr[l] * kp.gamma;
+        } else {
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[l] = (l < d) ? xr[l] * kp.gamma : (T)0;
         }
+#pragma unroll
+        for (int l = 0; l < D; ++l) b[l] = (T)0;
     }
 
     // Dimensions in chunks of one 64-byte scalar load per operand; scheduling barriers bound the SGPR
@@ -68,7 +72,12 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_mvm_kernel(const T* __restr
                     t = cg_fma(x[l], p[D + l], t);
                 }
             }
-            if constexpr (D > DC) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (D > DC) {
+                // pin both reductions at the chunk boundary: without this hipcc splits the s- and t-chains into separate
+                // sweeps and keeps every r_l of the column alive in between (+2D VGPRs, occupancy 1)
+                asm("" : "+v"(s), "+v"(t));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         T k1, k2;
         phi_derivs<FAM, T>(s, kp, k1, k2);
@@ -142,9 +151,23 @@ static int launch_grad_one(const GradArgs& a) {
     const KParams<T> kp = cast_params<T>(a.hk->kp);
     dim3 grid((unsigned)((a.n + GRAD_THREADS - 1) / GRAD_THREADS), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
-    // keep r = x - y in registers while 3 d-vectors of state fit the 256-VGPR budget, else recompute it
-    constexpr bool KEEP = (3 * D * (int)(sizeof(T) / 4) <= 144);
-    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEP>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n,
+    // keep r = x - y in registers (4 flops per dim and block) while 3 d-vectors of state leave >= 2 waves per SIMD,
+    // else recompute it in the second sweep (5 flops per dim, 2 d-vectors of state)
+    constexpr int W3 = 3 * D * (int)(sizeof(T) / 4);
+    constexpr bool CAN_KEEP = (W3 <= 200);
+    bool keep = (W3 <= 144);
+    if (a.keep_r == 0) keep = false;
+    if (a.keep_r == 1) keep = CAN_KEEP;
+    if constexpr (CAN_KEEP) {
+        if (keep) {
+            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, true>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,
+                               (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+            return COVGRAM_OK;
+        }
+    }
+    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n,
                        a.d, (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }

@@ -98,19 +98,22 @@ def test_config1_maternp2_d3_n4096_f64(cg, oracle):
     assert relerr(b, ref) <= 1e-12
 
 
-def test_lds_variant_matches_scalar_variant(cg, oracle):
-    rng = np.random.default_rng(11)
-    X = rng.standard_normal((5000, 3)).astype(np.float32); a = rng.standard_normal(5000).astype(np.float32)
-    G = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda())
+@pytest.mark.parametrize("m", [4999, 5000, 5001, 511, 513])
+def test_dense_odd_column_counts_and_split_options(cg, oracle, m):
+    """fp32 streams two columns per packed instruction: odd m exercises the zero-weight pad column, and the J-split
+    options exercise the partial-slab reduction."""
+    rng = np.random.default_rng(11 + m)
+    X = rng.standard_normal((3000, 3)).astype(np.float32); Y = rng.standard_normal((m, 3)).astype(np.float32)
+    a = rng.standard_normal(m).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
     ad = torch.from_numpy(a).cuda()
-    ref = oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a, dtype=np.float32)
-    try:
-        cg.set_option("dense_variant", 1)
-        b1 = (G @ ad).cpu().numpy()
-    finally:
-        cg.set_option("dense_variant", 0)
-    b0 = (G @ ad).cpu().numpy()
-    assert relerr(b1, ref) <= 1e-5 and relerr(b0, ref) <= 1e-5
+    ref = oracle.mul(None, oracle.Kernel(oracle.EQ), X, Y, a, dtype=np.float32)
+    for js in (0, 1, 3):
+        try:
+            cg.set_option("jsplit", js)
+            assert relerr((G @ ad).cpu().numpy(), ref) <= 1e-5, (m, js)
+        finally:
+            cg.set_option("jsplit", 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

@@ -60,6 +60,60 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                     asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(s) : "v"(d2));
                     asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(s), "v"(x));
                 }
+            } else if (OP == 8) {   // packed pair body: two pairs per lane with v_pk_* (7 packed VALU + 2 v_exp per 2 pairs)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    v2f d0, d1, d2, s, e;
+                    v2f xx = (v2f){x, x};
+                    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "v"(xx), "v"(p[i]));
+                    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "v"(p[(i + 1) & 7]), "v"(xx));
+                    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d2) : "v"(p[(i + 2) & 7]), "v"(xx));
+                    asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(s) : "v"(d0));
+                    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(s) : "v"(d1));
+                    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(s) : "v"(d2));
+                    asm volatile("v_exp_f32 %0, -%1" : "=v"(e.x) : "v"(s.x));
+                    asm volatile("v_exp_f32 %0, -%1" : "=v"(e.y) : "v"(s.y));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(e), "v"(xx));
+                }
+            } else if (OP == 9) {   // scalar pair body, software-pipelined: all distances, then all exps, then all accumulates
+                float sv[8], ev[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float d0, d1, d2;
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x), "v"(a[i]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(a[(i + 1) & 7]), "v"(x));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d2) : "v"(a[(i + 2) & 7]), "v"(x));
+                    asm volatile("v_mul_f32 %0, %1, %1" : "=v"(sv[i]) : "v"(d0));
+                    asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(sv[i]) : "v"(d1));
+                    asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(sv[i]) : "v"(d2));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, -%1" : "=v"(ev[i]) : "v"(sv[i]));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(ev[i]), "v"(x));
+            } else if (OP == 10) {  // alternate 1 exp : 1 fma (independent registers)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i + 4]) : "v"(x));
+                }
+            } else if (OP == 11) {  // 1 exp : 3 fma
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i + 2]) : "v"(x));
+                    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i + 4]) : "v"(x));
+                    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i + 6]) : "v"(x));
+                }
+            } else if (OP == 12) {  // 1 exp : 7 fma (all independent)
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[0]));
+#pragma unroll
+                for (int i = 1; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(x));
+            } else if (OP == 13) {  // 1 exp : 7 pk_fma-halves (4 exps + 14 pk_fma per 8-slot group ~ same ratio)
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[0]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[1]));
+#pragma unroll
+                for (int i = 0; i < 7; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(p[7]));
             } else if (OP == 6) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(da[i]) : "v"(da[(i + 1) & 3]));
@@ -118,5 +172,11 @@ int main() {
     run<6>("v_add_f64", 4, dout, cus);
     run<5>("pair body w/o exp (7 VALU)", 8 * 7, dout, cus);
     run<4>("EQ pair body (7 VALU+exp)", 8 * 8, dout, cus);
+    run<9>("EQ pair body, grouped", 8 * 8, dout, cus);
+    run<8>("EQ pair body, packed", 8 * 8, dout, cus);
+    run<10>("1 exp : 1 fma", 8, dout, cus);
+    run<11>("1 exp : 3 fma", 8, dout, cus);
+    run<12>("1 exp : 7 fma", 8, dout, cus);
+    run<13>("2 exp : 7 pk_fma (16 lane-ops)", 16, dout, cus);
     return 0;
 }

@@ -29,13 +29,11 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
     n = 131072
-    for variant in (0, 1):
-        cg.set_option("dense_variant", variant)
-        for tw in (0, 1024, 4096, 8192):
-            cg.set_option("target_wgs", tw)
-            print(f"variant={variant} target_wgs={tw}: ", end="")
-            G, X, a, y = dense(n, 3, torch.float32)
-    cg.set_option("dense_variant", 0); cg.set_option("target_wgs", 0)
+    for tw in (0, 512, 1024, 4096, 8192):
+        cg.set_option("target_wgs", tw)
+        print(f"target_wgs={tw}: ", end="")
+        G, X, a, y = dense(n, 3, torch.float32)
+    cg.set_option("target_wgs", 0)
     # accuracy on a row subset against the fp64 oracle
     G, X, a, y = dense(n, 3, torch.float32)
     rows = np.random.default_rng(1).choice(n, 2048, replace=False)
