@@ -175,7 +175,7 @@ def main():
             "pairs_per_s": mvms * float(n) * m,
             "rel_err_vs_fp64_oracle": rel_err,
             "roofline": {
-                "bound": "valu", "kernel": "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=4>",
+                "bound": "valu", "kernel": "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>",
                 "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,

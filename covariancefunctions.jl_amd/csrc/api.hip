@@ -409,10 +409,11 @@ static int check_pair(const covgram_ctx* ctx, const covgram_points* X, const cov
 }
 
 // choose the J split: enough workgroups to fill the chip, chunks aligned to the inner accumulation block
-static void choose_split(const covgram_ctx* ctx, int64_t rowblocks, int64_t m, int64_t align, int64_t* jchunk, int* jsplit) {
-    // ~32 workgroups per CU: several rounds of resident workgroups even out the tail (measured on C2: 2.77 ms at 8 per
-    // CU, 2.56 ms at 32 per CU, profiles/r01_quickbench_packed.txt)
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 32;
+static void choose_split(const covgram_ctx* ctx, int64_t rowblocks, int64_t m, int64_t align, int64_t* jchunk, int* jsplit,
+                         int64_t default_target = 0) {
+    // ~128 single-wave workgroups per CU = 4 rounds of resident waves: measured on C2 (profiles/r01_quickbench_wg64.txt)
+    // 3.63 ms at 8 waves per CU, 2.76 ms at 32, 2.63 ms at 64, 2.56 ms at 128 — dynamic rounds even out per-CU speed
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (default_target > 0 ? default_target : (int64_t)ctx->num_cus * 128);
     int64_t js = ctx->jsplit > 0 ? ctx->jsplit : (target + rowblocks - 1) / std::max<int64_t>(rowblocks, 1);
     const int64_t maxsplit = std::max<int64_t>(1, m / align);
     js = std::max<int64_t>(1, std::min(js, maxsplit));
@@ -585,18 +586,19 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
     const double alpha_eff = alpha * hk.kp.scale * (iso ? -2.0 * hk.kp.gamma2 : 1.0);
     const int64_t rowblocks = (n + GRAD_THREADS - 1) / GRAD_THREADS;
     const int64_t npad = rowblocks * GRAD_THREADS;
+    const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)d);
 
     if (m == 0) {
         if (dtype == COVGRAM_F32)
-            hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const float*)nullptr,
+            hipLaunchKernelGGL(grad_reduce_kernel<float>, rgrid, dim3(256), 0, ctx->stream, (const float*)nullptr,
                                npad, D, 0, (float*)y_dev, n, d, 0.0f, (float)beta);
         else
-            hipLaunchKernelGGL(grad_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)nullptr,
+            hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)nullptr,
                                npad, D, 0, (double*)y_dev, n, d, 0.0, beta);
     } else {
         void* P;
-        rc = ws_reserve(ctx, 0, (size_t)m * 2 * D * ts, &P); if (rc) return rc;
-        const int64_t pe = m * (int64_t)D;
+        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * 2 * D * ts, &P); if (rc) return rc;   // + 1 prefetch-only record
+        const int64_t pe = (m + 1) * (int64_t)D;
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma);
@@ -604,7 +606,9 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma);
         int64_t jchunk; int jsplit;
-        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
+        // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
+        // (C4: 2.47 ms at CUs*8, 2.09 ms at CUs*32, profiles/r01_gradbench_sweep_v2.txt)
+        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 32);
         GradArgs ga;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
@@ -616,10 +620,10 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         if (tm) (void)hipEventRecord(tm->second, ctx->stream);
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
-                hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const float*)ga.out,
+                hipLaunchKernelGGL(grad_reduce_kernel<float>, rgrid, dim3(256), 0, ctx->stream, (const float*)ga.out,
                                    npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta);
             else
-                hipLaunchKernelGGL(grad_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)ga.out,
+                hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)ga.out,
                                    npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta);
         }
     }

@@ -24,7 +24,12 @@
 
 namespace covgram {
 
-constexpr int DENSE_THREADS = 256;
+#ifndef CG_DENSE_THREADS
+#define CG_DENSE_THREADS 64
+#endif
+// one wave per workgroup: the kernel uses no LDS and no barriers, so small workgroups only improve tail balance and
+// shrink the partial slab (jsplit ~ waves * 64 R / n)
+constexpr int DENSE_THREADS = CG_DENSE_THREADS;
 constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, so column pairs never straddle chunks
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -229,9 +234,11 @@ static int launch_dense_one(const DenseArgs& a) {
     return COVGRAM_OK;
 }
 
-// rows per lane compiled for each D (register budget: x is splat for fp32, so both dtypes cost 2 dwords per coordinate)
-template <int D> struct RowsFor { static constexpr int value = (D <= 4) ? 4 : ((D <= 16) ? 2 : 1); };
-inline int rows_per_lane_for(int Dpad) { return (Dpad <= 4) ? 4 : ((Dpad <= 16) ? 2 : 1); }
+// Rows per lane.  R = 1, 2 and 4 were measured on C2 at equal wave counts (profiles/r01_quickbench_rows_per_lane.txt):
+// 2.53-2.62 ms for all three — SGPR operands make the column stream free to re-read, so more rows per lane buy nothing,
+// while R = 1 gives 4x more row blocks, i.e. a 4x smaller split-J partial slab (8.4 MB instead of 33.5 MB on C2).
+template <int D> struct RowsFor { static constexpr int value = 1; };
+inline int rows_per_lane_for(int) { return 1; }
 
 template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {

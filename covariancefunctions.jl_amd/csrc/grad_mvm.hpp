@@ -7,25 +7,55 @@
 //
 // MI355X mapping: one lane owns one block row (x_i and the d-vector accumulator b_i live in VGPRs);
 // the column stream P[j] = (gamma*y_j[0..D), a_j[0..D)) is wave-uniform and arrives through the
-// scalar data cache as SGPR operands, so the 5d flops per block contain no cross-lane traffic, no
+// scalar data cache as SGPR operands, so the 4-5 d flops per block contain no cross-lane traffic, no
 // LDS and no VGPR copies.  With gamma = 1/l the chain rule gives
 //   b = -2 gamma^2 (psi' a + 2 psi'' r' (r'.a)),  r' = gamma r,  psi(s') = phi(s'/gamma^2),
 // so the host folds -2 gamma^2 * scale into alpha.  Grid = (row blocks) × (J splits) with a
 // deterministic second-pass reduction, as in dense_mvm.hpp.
+//
+// Software pipeline of the scalar stream.  The state (x_i, b_i [, r]) costs 2-3 d-vectors of VGPRs, so wide fp64 rows
+// run at 2 waves per SIMD and cannot hide scalar-load latency by occupancy: rocprofv3 showed 61 % of the wave cycles of
+// the first version parked in s_waitcnt (profiles/r01_pmc_counters_v1.txt).  SMEM returns out of order, so only
+// lgkmcnt(0) exists: a load can overlap compute only if it is ISSUED AFTER the wait that validates the current chunk.
+// Each 64-byte chunk step is therefore pinned (scheduling barriers) as
+//     touch the current chunk (the compiler's s_waitcnt lands here)  ->  issue the s_load of the NEXT chunk  ->
+//     the rest of the current chunk's VALU work
+// across both sweeps of a column and across columns (the last chunk of column j prefetches the first of j+1; the
+// stream is padded by one record so the final prefetch stays in bounds).
 #pragma once
 #include "profiles.hpp"
 
 namespace covgram {
 
-constexpr int GRAD_THREADS = 256;
+constexpr int GRAD_THREADS = 64;   // one wave per workgroup: no LDS, no barriers — finer tail balance, smaller partial slabs
 
-template <typename T, int FAM, int D, bool KEEP_R>
-__global__ __launch_bounds__(GRAD_THREADS) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
+template <typename T, int DC>
+struct GradChunk {
+    T y[DC];
+    T a[DC];
+};
+
+// Register budget: the state is 2 (or 3 with KEEP_R) d-vectors; ask the allocator for the occupancy that state allows
+// with ~40 VGPRs of temporaries (e.g. fp64 d = 32 without r: 128 + 40 = 168 -> 3 waves per SIMD instead of 2).
+template <typename T, int D, bool KEEP_R>
+constexpr int grad_min_waves() {
+    const int state = (KEEP_R ? 3 : 2) * D * (int)(sizeof(T) / 4);
+    const int w = 512 / (state + 40);
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
+template <typename T, int FAM, int D, bool KEEP_R, bool POW>
+__global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
                                                                 const T* __restrict__ P, const T* __restrict__ P2,
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
-                                                                int64_t jchunk, T alpha, T beta,
-                                                                int32_t final_store, const KParams<T> kp) {
+                                                                int64_t jchunk, T alpha, T beta, int32_t final_store,
+                                                                const KParams<T> kp) {
     constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
+    constexpr int DC = (64 / (int)sizeof(T) < D) ? 64 / (int)sizeof(T) : D;   // dims per chunk (one 64-byte s_load per operand)
+    constexpr int NC = (D + DC - 1) / DC;
+    constexpr bool NEED_Y2 = !ISO || !KEEP_R;                                    // sweep 2 needs y_j again
+    using Chunk = GradChunk<T, DC>;
+
     const int tid = threadIdx.x;
     int64_t row = (int64_t)blockIdx.x * GRAD_THREADS + tid;
     const bool live = row < n;
@@ -47,55 +77,94 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_mvm_kernel(const T* __restr
         for (int l = 0; l < D; ++l) b[l] = (T)0;
     }
 
-    // Dimensions in chunks of one 64-byte scalar load per operand; scheduling barriers bound the SGPR
-    // live ranges (see dense_mvm.hpp), and the second pass re-reads its operands through P2 — the SAME
-    // address passed as a second kernel argument — so the compiler cannot merge the two reads and keep
-    // all 2*D scalars of pass 1 alive (SGPR spills) instead of re-fetching them from the scalar cache.
-    constexpr int DC = 64 / (int)sizeof(T);
+    // chunk loaders: uniform addresses -> s_load_dwordx16.  The tail chunk of a D that is not a multiple of DC is
+    // clamped into the record (it overlaps the previous chunk; the overlapped lanes are skipped by the consumer).
+    auto load_ya = [&](const T* __restrict__ rec, int c) {
+        Chunk ch;
+        const int base = (c * DC + DC <= D) ? c * DC : D - DC;
+#pragma unroll
+        for (int e = 0; e < DC; ++e) { ch.y[e] = rec[base + e]; ch.a[e] = rec[D + base + e]; }
+        return ch;
+    };
+    auto load_a = [&](const T* __restrict__ rec, int c) {
+        Chunk ch;
+        const int base = (c * DC + DC <= D) ? c * DC : D - DC;
+#pragma unroll
+        for (int e = 0; e < DC; ++e) {
+            ch.a[e] = rec[D + base + e];
+            if constexpr (NEED_Y2) ch.y[e] = rec[base + e];
+            else ch.y[e] = (T)0;
+        }
+        return ch;
+    };
+
+    // Sweep 2 reads the stream through P2 — the SAME address passed as a second kernel argument — so the compiler cannot
+    // merge its loads with sweep 1's (it would re-materialise them right before use instead of prefetching them).
     const int cnt = (int)(j1 - j0);
     const T* __restrict__ p = P + j0 * (2 * D);
     const T* __restrict__ q = P2 + j0 * (2 * D);
+    Chunk cur = load_ya(p, 0);
     for (int jj = 0; jj < cnt; ++jj, p += 2 * D, q += 2 * D) {
         T s = (T)0, t = (T)0;
         T r[(ISO && KEEP_R) ? D : 1];
+        // ---- sweep 1: s = |r|^2 (or x.y), t = r.a (or x.a) ------------------------------------------------------
 #pragma unroll
-        for (int c0 = 0; c0 < D; c0 += DC) {
+        for (int c = 0; c < NC; ++c) {
+            const int base = (c * DC + DC <= D) ? c * DC : D - DC;
+            const int skip = c * DC - base;     // lanes of a clamped tail chunk that chunk c-1 already consumed
+            Chunk nxt;
 #pragma unroll
-            for (int l = c0; l < ((c0 + DC < D) ? c0 + DC : D); ++l) {
+            for (int e = 0; e < DC; ++e) {
+                if (e < skip) continue;
+                const int l = base + e;
                 if constexpr (ISO) {
-                    const T rl = x[l] - p[l];
+                    const T rl = x[l] - cur.y[e];
                     if constexpr (KEEP_R) r[l] = rl;
                     s = cg_fma(rl, rl, s);
-                    t = cg_fma(rl, p[D + l], t);
+                    t = cg_fma(rl, cur.a[e], t);
                 } else {
-                    s = cg_fma(x[l], p[l], s);
-                    t = cg_fma(x[l], p[D + l], t);
+                    s = cg_fma(x[l], cur.y[e], s);
+                    t = cg_fma(x[l], cur.a[e], t);
+                }
+                if (e == skip) {   // the first use above carried the wait; now put the next chunk in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = (c + 1 < NC) ? load_ya(p, c + 1) : load_a(q, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (D > DC) {
-                // pin both reductions at the chunk boundary: without this hipcc splits the s- and t-chains into separate
-                // sweeps and keeps every r_l of the column alive in between (+2D VGPRs, occupancy 1)
-                asm("" : "+v"(s), "+v"(t));
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            asm("" : "+v"(s), "+v"(t));   // pin both reductions at the chunk boundary (bounds VGPR live ranges)
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
         T k1, k2;
-        phi_derivs<FAM, T>(s, kp, k1, k2);
+        phi_derivs<FAM, T, POW>(s, kp, k1, k2);
         const T c2 = ISO ? (T)2 * k2 * t : k2 * t;
+        // ---- sweep 2: b += k1 a + c2 r   (or k1 a + c2 y) --------------------------------------------------------
 #pragma unroll
-        for (int c0 = 0; c0 < D; c0 += DC) {
+        for (int c = 0; c < NC; ++c) {
+            const int base = (c * DC + DC <= D) ? c * DC : D - DC;
+            const int skip = c * DC - base;
+            Chunk nxt;
 #pragma unroll
-            for (int l = c0; l < ((c0 + DC < D) ? c0 + DC : D); ++l) {
+            for (int e = 0; e < DC; ++e) {
+                if (e < skip) continue;
+                const int l = base + e;
                 T v;
                 if constexpr (ISO) {
                     if constexpr (KEEP_R) v = r[l];
-                    else v = x[l] - q[l];
+                    else v = x[l] - cur.y[e];
                 } else {
-                    v = q[l];
+                    v = cur.y[e];
                 }
-                b[l] = cg_fma(c2, v, cg_fma(k1, q[D + l], b[l]));
+                b[l] = cg_fma(c2, v, cg_fma(k1, cur.a[e], b[l]));
+                if (e == skip) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = (c + 1 < NC) ? load_a(q, c + 1) : load_ya(p + 2 * D, 0);   // last chunk: next column (stream is padded)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if constexpr (D > DC) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
     }
 
@@ -118,32 +187,34 @@ __global__ __launch_bounds__(GRAD_THREADS) void grad_mvm_kernel(const T* __restr
     }
 }
 
+// y[i*d + l] = alpha * sum_s partial[s][l][i] + beta * y ; one thread per (i, l) with i fastest: coalesced slab reads
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partial, int64_t npad, int32_t D, int32_t jsplit,
                                                           T* __restrict__ y, int64_t n, int32_t d, T alpha, T beta) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int l = 0; l < d; ++l) {
-        T s = (T)0;
-        for (int sp = 0; sp < jsplit; ++sp) s += partial[((int64_t)sp * D + l) * npad + i];
-        T* yp = y + i * (int64_t)d + l;
-        T v = alpha * s;
-        if (beta != (T)0) v = cg_fma(beta, *yp, v);
-        *yp = v;
-    }
+    const int l = blockIdx.y;
+    if (i >= n || l >= d) return;
+    T s = (T)0;
+    for (int sp = 0; sp < jsplit; ++sp) s += partial[((int64_t)sp * D + l) * npad + i];
+    T* yp = y + i * (int64_t)d + l;
+    T v = alpha * s;
+    if (beta != (T)0) v = cg_fma(beta, *yp, v);
+    *yp = v;
 }
 
-// P[j][0..D) = gamma * Y[j][0..d), P[j][D..2D) = a[j*d + 0..d)   (zero padded)
+// P[j][0..D) = gamma * Y[j][0..d), P[j][D..2D) = a[j*d + 0..d)   (zero padded); record m (one past the end) is zeroed:
+// the kernel's software pipeline prefetches it and never consumes it.
 template <typename T>
 __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
                                                         T* __restrict__ P, int32_t D, T gamma) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m * (int64_t)D) return;
+    if (e >= (m + 1) * (int64_t)D) return;
     const int64_t j = e / D;
     const int l = (int)(e - j * D);
     T* p = P + j * (int64_t)(2 * D);
-    p[l] = (l < d) ? Y[j * (int64_t)d + l] * gamma : (T)0;
-    p[D + l] = (l < d) ? A[j * (int64_t)d + l] : (T)0;
+    const bool real = (j < m) && (l < d);
+    p[l] = real ? Y[j * (int64_t)d + l] * gamma : (T)0;
+    p[D + l] = real ? A[j * (int64_t)d + l] : (T)0;
 }
 
 template <typename T, int FAM, int D>
@@ -155,20 +226,24 @@ static int launch_grad_one(const GradArgs& a) {
     // else recompute it in the second sweep (5 flops per dim, 2 d-vectors of state)
     constexpr int W3 = 3 * D * (int)(sizeof(T) / 4);
     constexpr bool CAN_KEEP = (W3 <= 200);
-    bool keep = (W3 <= 144);
+    // measured (profiles/r01_gradbench_sweep_v3.txt): keeping r wins only while it costs no occupancy that matters —
+    // fp32 d <= 32 and fp64 d <= 16; beyond that the recomputing variant's extra wave per SIMD is worth more than a flop per dim
+    bool keep = CAN_KEEP && (W3 <= 100);
     if (a.keep_r == 0) keep = false;
     if (a.keep_r == 1) keep = CAN_KEEP;
+    const bool pow = a.hk->k.power != 1;
+#define CG_GRAD_LAUNCH(KEEPV, POWV)                                                                                              \
+    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, \
+                       (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp)
+    bool done = false;
     if constexpr (CAN_KEEP) {
         if (keep) {
-            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, true>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,
-                               (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
-            return COVGRAM_OK;
+            if (pow) CG_GRAD_LAUNCH(true, true); else CG_GRAD_LAUNCH(true, false);
+            done = true;
         }
     }
-    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n,
-                       a.d, (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp);
+    if (!done) { if (pow) CG_GRAD_LAUNCH(false, true); else CG_GRAD_LAUNCH(false, false); }
+#undef CG_GRAD_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -201,12 +201,14 @@ struct DPhi<COVGRAM_EXPDOT, T> {
     }
 };
 
-template <int FAM, typename T>
+// POW = false compiles the Power chain rule away: the gradient kernel's software pipeline needs the derivative
+// evaluation to stay ONE basic block (a branch lets hipcc sink the prefetch loads past it, to their first use).
+template <int FAM, typename T, bool POW>
 __device__ __forceinline__ void phi_derivs(T s, const KParams<T>& kp, T& d1, T& d2) {
     T v;
     DPhi<FAM, T>::eval(s, kp, v, d1, d2);
-    const int q = kp.power;
-    if (q != 1) {  // (phi^q)' , (phi^q)'' — uniform branch, once per n² block (O(d) work follows)
+    if constexpr (POW) {  // (phi^q)' , (phi^q)''
+        const int q = kp.power;
         T vq2 = (q >= 2) ? ((q == 2) ? (T)1 : ipow(v, q - 2)) : (T)0;
         T vq1 = vq2 * v;
         if (q < 2) vq1 = (T)1;

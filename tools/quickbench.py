@@ -29,7 +29,7 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
     n = 131072
-    for tw in (0, 512, 1024, 4096, 8192):
+    for tw in (0, 16384, 65536):
         cg.set_option("target_wgs", tw)
         print(f"target_wgs={tw}: ", end="")
         G, X, a, y = dense(n, 3, torch.float32)
