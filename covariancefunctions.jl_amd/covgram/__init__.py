@@ -22,5 +22,6 @@ from .gramian import (Gramian, BlockGramian, SymmetricToeplitz, Toeplitz, Circul
                       SeparableGramian, LazyMatrixProduct, LazyMatrixSum, Fill, LazyOperator, LazyGrid, StepRangeLen,
                       srange, gramian, mul_, get_ctx, set_option, kernel_time)
 from .dist import ShardedGramian, shard_bounds
+from .solve import cg, solve
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -16,40 +16,81 @@
 
 namespace covgram {
 
-// C[b][i][j] = sum_k F[i + k*ldf] * B[b][k][j];  B, C row-major per batch: B[b] is (K × N) with row
-// stride N, C[b] is (M × N).  32×32 output tile per workgroup, K staged through LDS in slabs of 32.
-template <typename T>
+// Mode product as a batched GEMM with generic strides:
+//     C[b][i][j] = sum_k F[i + k*ldf] * B[b*sBb + k*sBk + j*sBj],      C address = b*sCb + i*sCi + j*sCj
+// 64×64 output tile per workgroup, 4×4 outputs per thread, K in slabs of 16 staged through LDS.  JCONTIG selects the
+// thread->element map of the B-tile loads and C-tile stores so that the unit-stride index runs along the lanes:
+//   JCONTIG = true : sBj == sCj == 1 (all modes but the last: "post" is contiguous)
+//   JCONTIG = false: sBk == sCi == 1 (the last mode, post == 1: the mode's own index is contiguous; columns j are the batches)
+// HBM-bound for the small factors of a Kronecker Gramian (each mode reads and writes the whole tensor once).
+template <typename T, bool JCONTIG>
 __global__ __launch_bounds__(256) void mode_product_kernel(const T* __restrict__ F, int64_t ldf, int64_t M, int64_t K,
-                                                           const T* __restrict__ B, T* __restrict__ C, int64_t N) {
-    __shared__ T sF[32][33];
-    __shared__ T sB[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 × 8
+                                                           const T* __restrict__ B, T* __restrict__ C, int64_t N, int64_t sBb,
+                                                           int64_t sBk, int64_t sBj, int64_t sCb, int64_t sCi, int64_t sCj) {
+    constexpr int BM = 64, BN = 64, BK = 16;
+    __shared__ T sF[BK][BM + 1];
+    __shared__ T sB[BK][BN + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;                  // 16 × 16 threads, each a 4×4 micro-tile (strided by 16)
     const int64_t b = blockIdx.z;
-    const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
-    const T* Bb = B + b * K * N;
-    T* Cb = C + b * M * N;
-    T acc[4] = {0, 0, 0, 0};
-    for (int64_t k0 = 0; k0 < K; k0 += 32) {
-        for (int r = ty; r < 32; r += 8) {
-            // sF[i][k] = F[i0+i, k0+k]  (column-major F: consecutive tx walk k -> stride ldf; small factors, L2-resident)
-            const int64_t i = i0 + r, k = k0 + tx;
-            sF[r][tx] = (i < M && k < K) ? F[i + k * ldf] : (T)0;
-            const int64_t kk = k0 + r, j = j0 + tx;
-            sB[r][tx] = (kk < K && j < N) ? Bb[kk * N + j] : (T)0;
+    const int64_t i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
+    const T* Bb = B + b * sBb;
+    T* Cb = C + b * sCb;
+    T acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = (T)0;
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+        // F tile: i fastest (column-major F)
+#pragma unroll
+        for (int e = tid; e < BM * BK; e += 256) {
+            const int i = e & (BM - 1), k = e >> 6;
+            sF[k][i] = (i0 + i < M && k0 + k < K) ? F[(i0 + i) + (k0 + k) * ldf] : (T)0;
+        }
+        // B tile
+#pragma unroll
+        for (int e = tid; e < BN * BK; e += 256) {
+            int j, k;
+            if constexpr (JCONTIG) { j = e & (BN - 1); k = e >> 6; }
+            else { k = e & (BK - 1); j = e >> 4; }
+            sB[k][j] = (j0 + j < N && k0 + k < K) ? Bb[(k0 + k) * sBk + (j0 + j) * sBj] : (T)0;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const T bv = sB[k][tx];
+        for (int k = 0; k < BK; ++k) {
+            T fv[4], bv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(sF[ty + 8 * q][k], bv, acc[q]);
+            for (int ii = 0; ii < 4; ++ii) fv[ii] = sF[k][ty + 16 * ii];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bv[jj] = sB[k][tx + 16 * jj];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_fma(fv[ii], bv[jj], acc[ii][jj]);
         }
         __syncthreads();
     }
+    if constexpr (JCONTIG) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t i = i0 + ty + 8 * q, j = j0 + tx;
-        if (i < M && j < N) Cb[i * N + j] = acc[q];
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int64_t i = i0 + ty + 16 * ii, j = j0 + tx + 16 * jj;      // tx (lanes) along j: unit stride
+                if (i < M && j < N) Cb[i * sCi + j * sCj] = acc[ii][jj];
+            }
+    } else {
+        // unit stride is along i: transpose the micro-tiles through LDS so that lanes run along i
+        __shared__ T sC[BN][BM + 1];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sC[tx + 16 * jj][ty + 16 * ii] = acc[ii][jj];
+        __syncthreads();
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int i = e & (BM - 1), j = e >> 6;
+            if (i0 + i < M && j0 + j < N) Cb[(i0 + i) * sCi + (j0 + j) * sCj] = sC[j][i];
+        }
     }
 }
 
@@ -113,8 +154,22 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
         for (int i = 0; i < k; ++i) pre *= rows[i];
         for (int i = k + 1; i < q; ++i) post *= cols[i];
         const int64_t M = rows[k], K = cols[k];
-        dim3 grid((unsigned)((post + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)pre);
-        hipLaunchKernelGGL(mode_product_kernel<T>, grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst, post);
+        if (post >= 16 || pre == 1) {
+            // tensor viewed as [pre][K][post]: columns j = the contiguous trailing index, batches = pre
+            dim3 grid((unsigned)((post + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)pre);
+            hipLaunchKernelGGL((mode_product_kernel<T, true>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
+                               post, K * post, post, (int64_t)1, M * post, post, (int64_t)1);
+        } else if (post == 1) {
+            // last mode: [pre][K] -> [pre][M]; columns j = the batches, unit stride along the mode's own index
+            dim3 grid((unsigned)((pre + 63) / 64), (unsigned)((M + 63) / 64), 1u);
+            hipLaunchKernelGGL((mode_product_kernel<T, false>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
+                               pre, (int64_t)0, (int64_t)1, K, (int64_t)0, (int64_t)1, M);
+        } else {
+            // small trailing extent (tiny tensors): same kernel, short rows
+            dim3 grid((unsigned)((post + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)pre);
+            hipLaunchKernelGGL((mode_product_kernel<T, true>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
+                               post, K * post, post, (int64_t)1, M * post, post, (int64_t)1);
+        }
         src = dst;
         dst = (dst == bufA) ? bufB : bufA;
     }

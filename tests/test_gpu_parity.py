@@ -274,3 +274,24 @@ def test_lazy_sum_with_diagonal(cg, oracle):
     S = G + 1e-2 * torch.ones(300, device="cuda", dtype=torch.float64)
     b = (S @ torch.from_numpy(a).cuda()).cpu().numpy()
     assert relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a) + 1e-2 * a) <= 1e-12
+
+
+def test_cg_solve_through_the_hot_path(cg, oracle):
+    """SURVEY §8f-1 / test/gradient.jl:56-63: ‖K (K \\ Ka) - Ka‖ / ‖Ka‖ < 1e-6, for a noisy scalar Gramian and a
+    gradient-kernel Gramian; every iteration's MVM runs on the device."""
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((400, 2))
+    G = cg.gramian(cg.MaternP(2), torch.from_numpy(X).cuda())
+    S = G + 1e-2 * torch.ones(400, device="cuda", dtype=torch.float64)            # G + sigma^2 I stays lazy
+    bvec = torch.from_numpy(rng.standard_normal(400)).cuda()
+    x, info = cg.cg(S, bvec, reltol=1e-10)
+    assert info["converged"]
+    M = oracle.matrix(oracle.Kernel(oracle.MATERNP, p=2), X) + 1e-2 * np.eye(400)
+    assert relerr(x.cpu().numpy(), np.linalg.solve(M, bvec.cpu().numpy())) < 1e-7
+    n, d = 16, 3
+    Xg = rng.standard_normal((n, d)) / np.sqrt(d)
+    K = cg.gramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(Xg).cuda())
+    a = torch.from_numpy(rng.standard_normal(n * d)).cuda()
+    Ka = K @ a
+    xs = cg.solve(K + 1e-8 * torch.ones(n * d, device="cuda", dtype=torch.float64), Ka, reltol=1e-10, maxiter=2000)
+    assert float(torch.linalg.norm(K @ xs - Ka) / torch.linalg.norm(Ka)) < 1e-6
