@@ -493,7 +493,9 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma);
         int64_t jchunk; int jsplit;
-        choose_split(ctx, rowblocks, m, DENSE_INNER, &jchunk, &jsplit);
+        // chunks are multiples of 64 columns (whole packed pairs); small problems split finer than the 512-column
+        // inner accumulation block so that they still expose thousands of waves
+        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
         DenseArgs da;
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
         da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;

@@ -13,6 +13,9 @@
 // HBM-bound: per MVM one pad pass, R2C, one pointwise pass, C2R, one epilogue pass.
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 
 namespace covgram {
@@ -73,6 +76,203 @@ __global__ __launch_bounds__(256) void toep_epilogue_kernel(const T* __restrict_
     y[i] = v;
 }
 
+
+// ================================================================================================
+// Fast path for power-of-two embeddings (N >= 16384): a four-step FFT that never transposes.
+//
+// rocFFT runs the 2^23-point real transform of config C5 as SIX HBM passes per direction (three transposes, two
+// length-2048 kernels, one real<->complex pass; profiles/r01_toeplitz_c5_kernel_stats.csv) because a strided
+// (column) batch costs it 125-135 us against 29 us for the same batch laid out contiguously
+// (profiles/r01_fft_probe.txt).  Here the packed complex signal z_j = x_2j + i x_2j+1 (M = N/2 points) is viewed as
+// a 1024 x M' matrix:
+//     colfft_kernel   length-1024 FFTs down the columns (stride M'): tiles of TW adjacent columns, i.e. coalesced
+//                     128-byte row segments, whole tile in LDS (radix-4 DIT, five in-place stages), the inter-step
+//                     twiddle W_M^(n' k1) applied on the way out; it reads the real input directly (no pad pass) and
+//                     skips the zero half;
+//     rocFFT          1024 contiguous length-M' transforms (ONE kernel);
+// which leaves the spectrum in the permuted order  Z[k1 + 1024 k'] at [k1][k'].  The convolution does not care:
+//     spectral_kernel real-FFT untangling, multiplication by the cached (equally permuted, 1/M-scaled) spectrum and
+//                     re-tangling for the inverse, fused, one thread per conjugate pair (k, M-k);
+// and the inverse is the transposed algorithm (the DFT matrix is symmetric): contiguous inverse rocFFT, then the
+// inverse colfft_kernel, which ends in natural order and writes  y <- alpha t + beta y  directly.
+// Five passes over HBM instead of fifteen.
+// ================================================================================================
+template <typename T> struct V2T;
+template <> struct V2T<float> { using type = float2; };
+template <> struct V2T<double> { using type = double2; };
+
+template <typename V> __device__ __forceinline__ V cmul(V a, V b) { return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename V> __device__ __forceinline__ V cconj(V a) { return V{a.x, -a.y}; }
+template <typename V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
+template <typename V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
+// a * (+i) and a * (-i)
+template <typename V> __device__ __forceinline__ V cmuli(V a) { return V{-a.y, a.x}; }
+template <typename V> __device__ __forceinline__ V cmulmi(V a) { return V{a.y, -a.x}; }
+
+__device__ __forceinline__ int rev4_10(int x) {   // reverse the five base-4 digits of a 10-bit index
+    return ((x & 0x3) << 8) | ((x & 0xC) << 4) | (x & 0x30) | ((x >> 4) & 0xC) | ((x >> 8) & 0x3);
+}
+
+constexpr int COLFFT_N1 = 1024;
+constexpr int TWID_LB = 11;   // two-level twiddle: W_M^idx = thi[idx >> 11] * tlo[idx & 2047]
+
+// Forward (INV = false): src (real, length src_len, implicitly zero beyond) -> zbuf[k1][n'] = twiddled column FFT.
+// Inverse (INV = true):  zbuf[k1][n'] -> y[0..n) (real) with alpha/beta.
+constexpr int COLFFT_THREADS = 1024;   // 4 waves per SIMD: one wave per SIMD reaches only a fraction of the LDS rates
+
+template <typename T, int TW, bool INV>
+__global__ __launch_bounds__(COLFFT_THREADS) void colfft_kernel(const T* __restrict__ src, int64_t src_len,
+                                                     typename V2T<T>::type* __restrict__ zbuf, int64_t Mp,
+                                                     const typename V2T<T>::type* __restrict__ tw1024,
+                                                     const typename V2T<T>::type* __restrict__ tlo,
+                                                     const typename V2T<T>::type* __restrict__ thi, T* __restrict__ y, int64_t n,
+                                                     T alpha, T beta) {
+    using V = typename V2T<T>::type;
+    __shared__ V buf[COLFFT_N1 * TW];
+    __shared__ V stw[COLFFT_N1];
+    const int tid = threadIdx.x;
+    // XCD-aware tile map (speed only): within each group of 16 workgroups, b and b+8 take the two halves of one line
+    const unsigned bid = blockIdx.x;
+    const unsigned tile = (gridDim.x % 16 == 0) ? (2 * (8 * (bid / 16) + (bid % 8)) + ((bid / 8) % 2)) : bid;
+    const int64_t col0 = (int64_t)tile * TW;
+    constexpr int NT = COLFFT_THREADS;
+    for (int t = tid; t < COLFFT_N1; t += NT) stw[t] = INV ? cconj(tw1024[t]) : tw1024[t];
+    // ---- load (digit-reversed rows) ---------------------------------------------------------------------------------
+    for (int e = tid; e < COLFFT_N1 * TW; e += NT) {
+        const int c = e % TW, row = e / TW;
+        const int64_t np = col0 + c;
+        V v;
+        if constexpr (!INV) {
+            const int64_t j = (int64_t)row * Mp + np;                 // packed complex index: z_j = x[2j] + i x[2j+1]
+            v.x = (2 * j < src_len) ? src[2 * j] : (T)0;
+            v.y = (2 * j + 1 < src_len) ? src[2 * j + 1] : (T)0;
+        } else {
+            const int64_t idx = np * (int64_t)row;                    // n' * k1 < M
+            const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
+            v = cmul(zbuf[(int64_t)row * Mp + np], cconj(w));
+        }
+        buf[rev4_10(row) * TW + c] = v;
+    }
+    __syncthreads();
+    // ---- five in-place radix-4 DIT stages -----------------------------------------------------------------------------
+    const int c = tid % TW, bb = tid / TW;
+#pragma unroll 1
+    for (int s = 0; s < 5; ++s) {
+        const int L = 1 << (2 * s);
+#pragma unroll
+        for (int r = 0; r < 256 * TW / NT; ++r) {
+            const int bf = bb + (NT / TW) * r;                         // butterfly 0..255 of this column
+            const int j = bf & (L - 1), g = bf >> (2 * s);
+            const int i0 = (g * 4 * L + j) * TW + c;
+            const int tq = j << (8 - 2 * s);                           // j * (256 / L)
+            const V a = buf[i0];
+            const V b = cmul(stw[tq], buf[i0 + L * TW]);
+            const V cc = cmul(stw[2 * tq], buf[i0 + 2 * L * TW]);
+            const V d = cmul(stw[3 * tq], buf[i0 + 3 * L * TW]);
+            const V apc = cadd(a, cc), amc = csub(a, cc), bpd = cadd(b, d), bmd = csub(b, d);
+            // forward: y1 = (a - c) - i (b - d), y3 = (a - c) + i (b - d); inverse: signs of i swapped
+            const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+            buf[i0] = cadd(apc, bpd);
+            buf[i0 + L * TW] = cadd(amc, ib);
+            buf[i0 + 2 * L * TW] = csub(apc, bpd);
+            buf[i0 + 3 * L * TW] = csub(amc, ib);
+        }
+        __syncthreads();
+    }
+    // ---- store ------------------------------------------------------------------------------------------------------
+    for (int e = tid; e < COLFFT_N1 * TW; e += NT) {
+        const int cq = e % TW, row = e / TW;
+        const int64_t np = col0 + cq;
+        const V v = buf[row * TW + cq];
+        if constexpr (!INV) {
+            const int64_t idx = np * (int64_t)row;
+            const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
+            zbuf[(int64_t)row * Mp + np] = cmul(v, w);
+        } else {
+            const int64_t j = (int64_t)row * Mp + np;                 // natural order: y[2j], y[2j+1]
+            if (2 * j < n) {
+                T o = alpha * v.x;
+                if (beta != (T)0) o = __builtin_fma(beta, y[2 * j], o);
+                y[2 * j] = o;
+            }
+            if (2 * j + 1 < n) {
+                T o = alpha * v.y;
+                if (beta != (T)0) o = __builtin_fma(beta, y[2 * j + 1], o);
+                y[2 * j + 1] = o;
+            }
+        }
+    }
+}
+
+// position of the conjugate partner M-k of k = k1 + 1024 k' in the [k1][k'] layout
+__device__ __forceinline__ int64_t partner_pos(int k1, int64_t kp, int64_t Mp) {
+    const int k1p = (COLFFT_N1 - k1) & (COLFFT_N1 - 1);
+    const int64_t kpp = (k1 != 0) ? (Mp - 1 - kp) : ((Mp - kp) & (Mp - 1));
+    return (int64_t)k1p * Mp + kpp;
+}
+
+// S[pos] = X[k] * scale with X the half spectrum of the real signal whose packed transform is D; S[M] = X[M] * scale (Nyquist)
+template <typename T>
+__global__ __launch_bounds__(256) void half_spectrum_kernel(const typename V2T<T>::type* __restrict__ D, int64_t Mp,
+                                                            const typename V2T<T>::type* __restrict__ tA,
+                                                            const typename V2T<T>::type* __restrict__ tB,
+                                                            typename V2T<T>::type* __restrict__ S, T scale) {
+    using V = typename V2T<T>::type;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= COLFFT_N1 * Mp) return;
+    const int k1 = (int)(pos / Mp);
+    const int64_t kp = pos - (int64_t)k1 * Mp;
+    const V Z = D[pos], Zp = D[partner_pos(k1, kp, Mp)];
+    const V w = cmul(tA[k1], tB[kp]);                                   // exp(-i pi k / M)
+    const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
+    const V wo = cmul(w, o);
+    V X{(T)0.5 * (e.x + wo.y), (T)0.5 * (e.y - wo.x)};                  // 0.5 e - 0.5 i (w o)
+    if (pos == 0) { X = V{Z.x + Z.y, (T)0}; S[(int64_t)COLFFT_N1 * Mp] = V{(Z.x - Z.y) * scale, (T)0}; }
+    S[pos] = V{X.x * scale, X.y * scale};
+}
+
+// D <- the packed spectrum of the product signal, in place, one thread per conjugate pair
+template <typename T>
+__global__ __launch_bounds__(256) void spectral_kernel(typename V2T<T>::type* __restrict__ D, int64_t Mp,
+                                                       const typename V2T<T>::type* __restrict__ S,
+                                                       const typename V2T<T>::type* __restrict__ tA,
+                                                       const typename V2T<T>::type* __restrict__ tB) {
+    using V = typename V2T<T>::type;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;        // rows k1 = 0 .. 512
+    if (pos >= (int64_t)(COLFFT_N1 / 2 + 1) * Mp) return;
+    const int k1 = (int)(pos / Mp);
+    const int64_t kp = pos - (int64_t)k1 * Mp;
+    const int64_t ppos = partner_pos(k1, kp, Mp);
+    if ((k1 == 0 || k1 == COLFFT_N1 / 2) && ppos < pos) return;        // self-paired rows: the lower position owns the pair
+    const V Z = D[pos];
+    if (pos == 0) {                                                     // k = 0 and the Nyquist bin share Z[0]
+        const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
+        const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+        D[0] = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
+        return;
+    }
+    const V Zp = D[ppos];
+    const V w = cmul(tA[k1], tB[kp]);                                   // w_k = exp(-i pi k / M);  w_{M-k} = -conj(w_k)
+    const V wc = cconj(w);
+    // untangle: X[k] = 0.5 (Z + conj Zp) - 0.5 i w (Z - conj Zp);  X[M-k] = 0.5 (Zp + conj Z) + 0.5 i conj(w) (Zp - conj Z)
+    const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
+    const V wo = cmul(w, o);
+    const V X{(T)0.5 * (e.x + wo.y), (T)0.5 * (e.y - wo.x)};
+    const V ep = cconj(e), op = V{-o.x, o.y};                           // Zp + conj Z = conj(e);  Zp - conj Z = -conj(o)
+    const V wop = cmul(wc, op);
+    const V Xp{(T)0.5 * (ep.x - wop.y), (T)0.5 * (ep.y + wop.x)};       // 0.5 ep + 0.5 i (conj(w) op)
+    const V Y = cmul(X, S[pos]), Yp = cmul(Xp, S[ppos]);
+    // tangle: Z'[k] = 0.5 (Y + conj Yp) + 0.5 i conj(w) (Y - conj Yp);  Z'[M-k] = 0.5 (Yp + conj Y) - 0.5 i w (Yp - conj Y)
+    const V f = cadd(Y, cconj(Yp)), h = csub(Y, cconj(Yp));
+    const V wh = cmul(wc, h);
+    D[pos] = V{(T)0.5 * (f.x - wh.y), (T)0.5 * (f.y + wh.x)};
+    if (ppos != pos) {
+        const V fp = cconj(f), hp = V{-h.x, h.y};
+        const V whp = cmul(w, hp);
+        D[ppos] = V{(T)0.5 * (fp.x + whp.y), (T)0.5 * (fp.y - whp.x)};
+    }
+}
+
 }  // namespace covgram
 
 using namespace covgram;
@@ -89,7 +289,87 @@ struct covgram_toeplitz {
     void* rbuf = nullptr;   // N reals
     void* cbuf = nullptr;   // (N/2+1) complex
     void* stage_a = nullptr; void* stage_y = nullptr;  // device staging for loc == HOST
+    // fast path (four-step FFT without transposes): M = N/2 = 1024 * Mp
+    bool fast = false;
+    int64_t Mp = 0;
+    rocfft_plan bfwd = nullptr, binv = nullptr;   // 1024 contiguous length-Mp complex transforms, in place
+    void* zbuf = nullptr;    // M complex
+    void* sperm = nullptr;   // M + 1 complex: permuted half spectrum of the embedding / M, Nyquist bin last
+    void* tables = nullptr;  // tw1024 | tlo(2048) | thi(M/2048) | tA(1024) | tB(Mp)   (complex)
 };
+
+
+namespace covgram {
+
+// Columns per tile.  64-byte row segments (half a cache line) so that a tile + the stage twiddles take 80 KiB of LDS and TWO
+// workgroups share a CU: one tile's HBM phases overlap the other's LDS butterfly stages.  The two tiles that split each
+// 128-byte line are mapped to workgroups b and b+8, which the dispatcher places on the same XCD (same L2) back to back.
+template <typename T> constexpr int colfft_tw() { return sizeof(T) == 8 ? 4 : 8; }
+
+// complex tables for the fast path, computed in long double on the host
+template <typename T>
+static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    const int64_t nhi = M >> TWID_LB;
+    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp));
+    size_t o = 0;
+    auto put = [&](long double ang) { h[o++] = (T)cosl(ang); h[o++] = (T)sinl(ang); };
+    for (int t = 0; t < COLFFT_N1; ++t) put(-2 * PI * t / COLFFT_N1);                 // tw1024[t] = W_1024^t
+    for (int l = 0; l < (1 << TWID_LB); ++l) put(-2 * PI * l / (long double)M);        // tlo[l]    = W_M^l
+    for (int64_t q = 0; q < nhi; ++q) put(-2 * PI * q / (long double)nhi);             // thi[q]    = W_M^(2048 q)
+    for (int k1 = 0; k1 < COLFFT_N1; ++k1) put(-PI * k1 / (long double)M);             // tA[k1]    = exp(-i pi k1 / M)
+    for (int64_t kp = 0; kp < Mp; ++kp) put(-PI * kp / (long double)Mp);               // tB[k']    = exp(-i pi 1024 k' / M)
+}
+
+struct FastTables { const void *tw, *tlo, *thi, *tA, *tB; };
+static FastTables table_ptrs(const covgram_toeplitz* Tz) {
+    const size_t cs = 2 * dtype_size(Tz->dtype);
+    const char* b = (const char*)Tz->tables;
+    const int64_t M = Tz->N / 2, nhi = M >> TWID_LB;
+    FastTables t;
+    t.tw = b; b += cs * COLFFT_N1;
+    t.tlo = b; b += cs * (1 << TWID_LB);
+    t.thi = b; b += cs * nhi;
+    t.tA = b; b += cs * COLFFT_N1;
+    t.tB = b;
+    return t;
+}
+
+// zbuf <- permuted packed spectrum of the real signal src[0..len) (zero beyond), length N
+template <typename T>
+static int fast_forward(covgram_toeplitz* Tz, const T* src, int64_t len) {
+    using V = typename V2T<T>::type;
+    constexpr int TW = colfft_tw<T>();
+    const FastTables t = table_ptrs(Tz);
+    hipStream_t st = Tz->ctx->stream;
+    hipLaunchKernelGGL((colfft_kernel<T, TW, false>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
+                       (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, (T*)nullptr, (int64_t)0, (T)0, (T)0);
+    void* io[1] = {Tz->zbuf};
+    CG_CHECK_FFT(rocfft_execute(Tz->bfwd, io, nullptr, Tz->info));
+    return COVGRAM_OK;
+}
+
+template <typename T>
+static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double beta) {
+    using V = typename V2T<T>::type;
+    constexpr int TW = colfft_tw<T>();
+    const FastTables t = table_ptrs(Tz);
+    hipStream_t st = Tz->ctx->stream;
+    int rc = fast_forward<T>(Tz, a, Tz->m);
+    if (rc) return rc;
+    const int64_t pairs = (int64_t)(COLFFT_N1 / 2 + 1) * Tz->Mp;
+    hipLaunchKernelGGL(spectral_kernel<T>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (V*)Tz->zbuf, Tz->Mp, (const V*)Tz->sperm,
+                       (const V*)t.tA, (const V*)t.tB);
+    void* io[1] = {Tz->zbuf};
+    CG_CHECK_FFT(rocfft_execute(Tz->binv, io, nullptr, Tz->info));
+    hipLaunchKernelGGL((colfft_kernel<T, TW, true>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, (const T*)nullptr, (int64_t)0, (V*)Tz->zbuf,
+                       Tz->Mp, (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, Tz->n, (T)alpha, (T)beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("toeplitz fast path launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+}  // namespace covgram
 
 static int64_t next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -101,8 +381,10 @@ int covgram_toeplitz_destroy(covgram_toeplitz* T) {
     (void)hipStreamSynchronize(T->ctx->stream);
     if (T->fwd) rocfft_plan_destroy(T->fwd);
     if (T->inv) rocfft_plan_destroy(T->inv);
+    if (T->bfwd) rocfft_plan_destroy(T->bfwd);
+    if (T->binv) rocfft_plan_destroy(T->binv);
     if (T->info) rocfft_execution_info_destroy(T->info);
-    void* bufs[] = {T->work, T->spec, T->rbuf, T->cbuf, T->stage_a, T->stage_y};
+    void* bufs[] = {T->work, T->spec, T->rbuf, T->cbuf, T->stage_a, T->stage_y, T->zbuf, T->sperm, T->tables};
     for (void* b : bufs) if (b) (void)hipFree(b);
     T->ctx->live_handles--;
     if (--g_rocfft_users == 0) rocfft_cleanup();
@@ -130,16 +412,38 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
     auto fail = [&](int code) { covgram_toeplitz_destroy(T); return code; };
 #define TRY_HIP(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); return fail(COVGRAM_EHIP); } } while (0)
 #define TRY_FFT(e) do { rocfft_status _s = (e); if (_s != rocfft_status_success) { set_error("%s failed: rocfft_status %d", #e, (int)_s); return fail(COVGRAM_EHIP); } } while (0)
-    TRY_HIP(hipMalloc(&T->spec, (size_t)NC * 2 * ts));
-    TRY_HIP(hipMalloc(&T->rbuf, (size_t)N * ts));
-    TRY_HIP(hipMalloc(&T->cbuf, (size_t)NC * 2 * ts));
+    const int64_t Mh = N / 2;
+    T->fast = !T->circulant && (Mh % COLFFT_N1 == 0) && (Mh / COLFFT_N1 >= (dtype == COVGRAM_F64 ? colfft_tw<double>() : colfft_tw<float>()));
+    T->Mp = T->fast ? Mh / COLFFT_N1 : 0;
     const rocfft_precision prec = (dtype == COVGRAM_F64) ? rocfft_precision_double : rocfft_precision_single;
-    size_t len[1] = {(size_t)N};
-    TRY_FFT(rocfft_plan_create(&T->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 1, len, 1, nullptr));
-    TRY_FFT(rocfft_plan_create(&T->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 1, len, 1, nullptr));
+    TRY_HIP(hipMalloc(&T->rbuf, (size_t)N * ts));
     size_t w1 = 0, w2 = 0;
-    TRY_FFT(rocfft_plan_get_work_buffer_size(T->fwd, &w1));
-    TRY_FFT(rocfft_plan_get_work_buffer_size(T->inv, &w2));
+    if (T->fast) {
+        TRY_HIP(hipMalloc(&T->zbuf, (size_t)Mh * 2 * ts));
+        TRY_HIP(hipMalloc(&T->sperm, (size_t)(Mh + 1) * 2 * ts));
+        size_t blen[1] = {(size_t)T->Mp};
+        TRY_FFT(rocfft_plan_create(&T->bfwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, blen, COLFFT_N1, nullptr));
+        TRY_FFT(rocfft_plan_create(&T->binv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, blen, COLFFT_N1, nullptr));
+        TRY_FFT(rocfft_plan_get_work_buffer_size(T->bfwd, &w1));
+        TRY_FFT(rocfft_plan_get_work_buffer_size(T->binv, &w2));
+        if (dtype == COVGRAM_F64) {
+            std::vector<double> h; fill_tables<double>(h, Mh, T->Mp);
+            TRY_HIP(hipMalloc(&T->tables, h.size() * sizeof(double)));
+            TRY_HIP(hipMemcpy(T->tables, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> h; fill_tables<float>(h, Mh, T->Mp);
+            TRY_HIP(hipMalloc(&T->tables, h.size() * sizeof(float)));
+            TRY_HIP(hipMemcpy(T->tables, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    } else {
+        TRY_HIP(hipMalloc(&T->spec, (size_t)NC * 2 * ts));
+        TRY_HIP(hipMalloc(&T->cbuf, (size_t)NC * 2 * ts));
+        size_t len[1] = {(size_t)N};
+        TRY_FFT(rocfft_plan_create(&T->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 1, len, 1, nullptr));
+        TRY_FFT(rocfft_plan_create(&T->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 1, len, 1, nullptr));
+        TRY_FFT(rocfft_plan_get_work_buffer_size(T->fwd, &w1));
+        TRY_FFT(rocfft_plan_get_work_buffer_size(T->inv, &w2));
+    }
     T->work_bytes = std::max(w1, w2);
     TRY_FFT(rocfft_execution_info_create(&T->info));
     if (T->work_bytes) {
@@ -166,10 +470,27 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
     const int64_t me = T->circulant ? 1 : m;   // circulant: plain copy of vc (no wrapped row part)
     if (dtype == COVGRAM_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(gN), dim3(256), 0, ctx->stream, (const float*)dvc, (const float*)dvr, n, me, N, (float*)T->rbuf);
     else hipLaunchKernelGGL(embed_kernel<double>, dim3(gN), dim3(256), 0, ctx->stream, (const double*)dvc, (const double*)dvr, n, me, N, (double*)T->rbuf);
-    void* in[1] = {T->rbuf}; void* outb[1] = {T->spec};
-    TRY_FFT(rocfft_execute(T->fwd, in, outb, T->info));
-    if (dtype == COVGRAM_F32) hipLaunchKernelGGL(cmul_kernel<float>, dim3(gC), dim3(256), 0, ctx->stream, (float*)T->spec, (const float*)nullptr, NC, 1.0f / (float)N);
-    else hipLaunchKernelGGL(cmul_kernel<double>, dim3(gC), dim3(256), 0, ctx->stream, (double*)T->spec, (const double*)nullptr, NC, 1.0 / (double)N);
+    if (T->fast) {
+        // permuted half spectrum of the embedding, pre-divided by M (the unnormalised inverse transforms return M * signal)
+        const int64_t tot = (int64_t)COLFFT_N1 * T->Mp;
+        const FastTables ft = table_ptrs(T);
+        if (dtype == COVGRAM_F32) {
+            if (fast_forward<float>(T, (const float*)T->rbuf, N)) return fail(COVGRAM_EHIP);
+            hipLaunchKernelGGL(half_spectrum_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const float2*)T->zbuf, T->Mp,
+                               (const float2*)ft.tA, (const float2*)ft.tB, (float2*)T->sperm, 1.0f / (float)Mh);
+        } else {
+            if (fast_forward<double>(T, (const double*)T->rbuf, N)) return fail(COVGRAM_EHIP);
+            hipLaunchKernelGGL(half_spectrum_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)T->zbuf, T->Mp,
+                               (const double2*)ft.tA, (const double2*)ft.tB, (double2*)T->sperm, 1.0 / (double)Mh);
+        }
+        TRY_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(T->rbuf); T->rbuf = nullptr;      // the fast path needs no real scratch buffer per MVM
+    } else {
+        void* in[1] = {T->rbuf}; void* outb[1] = {T->spec};
+        TRY_FFT(rocfft_execute(T->fwd, in, outb, T->info));
+        if (dtype == COVGRAM_F32) hipLaunchKernelGGL(cmul_kernel<float>, dim3(gC), dim3(256), 0, ctx->stream, (float*)T->spec, (const float*)nullptr, NC, 1.0f / (float)N);
+        else hipLaunchKernelGGL(cmul_kernel<double>, dim3(gC), dim3(256), 0, ctx->stream, (double*)T->spec, (const double*)nullptr, NC, 1.0 / (double)N);
+    }
     TRY_HIP(hipStreamSynchronize(ctx->stream));
     if (tmp_c) (void)hipFree(tmp_c);
     if (tmp_r) (void)hipFree(tmp_r);
@@ -195,6 +516,16 @@ int covgram_toeplitz_mvm(covgram_toeplitz* T, const void* a, void* y, double alp
         a_dev = T->stage_a; y_dev = T->stage_y;
     }
     CG_CHECK_FFT(rocfft_execution_info_set_stream(T->info, ctx->stream));
+    if (T->fast) {
+        int rc = (T->dtype == COVGRAM_F32) ? fast_mvm<float>(T, (const float*)a_dev, (float*)y_dev, alpha, beta)
+                                           : fast_mvm<double>(T, (const double*)a_dev, (double*)y_dev, alpha, beta);
+        if (rc) return rc;
+        if (loc == COVGRAM_HOST) {
+            CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)n * ts, hipMemcpyDeviceToHost, ctx->stream));
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return COVGRAM_OK;
+    }
     const unsigned gN = (unsigned)((N + 255) / 256), gC = (unsigned)((NC + 255) / 256), gn = (unsigned)((n + 255) / 256);
     if (T->dtype == COVGRAM_F32) hipLaunchKernelGGL(pad_kernel<float>, dim3(gN), dim3(256), 0, ctx->stream, (const float*)a_dev, m, N, (float*)T->rbuf);
     else hipLaunchKernelGGL(pad_kernel<double>, dim3(gN), dim3(256), 0, ctx->stream, (const double*)a_dev, m, N, (double*)T->rbuf);

@@ -295,3 +295,38 @@ def test_cg_solve_through_the_hot_path(cg, oracle):
     Ka = K @ a
     xs = cg.solve(K + 1e-8 * torch.ones(n * d, device="cuda", dtype=torch.float64), Ka, reltol=1e-10, maxiter=2000)
     assert float(torch.linalg.norm(K @ xs - Ka) / torch.linalg.norm(Ka)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [8192, 16384, 20000, 65536, 100003])
+def test_toeplitz_four_step_fft_path(cg, oracle, dtype, n):
+    """Embeddings N >= 16384 take the transposition-free four-step FFT (csrc/toeplitz.hip): symmetric, shifted
+    (non-symmetric) and alpha/beta forms against the numpy circulant-embedding oracle and explicit dense rows."""
+    tol = 3e-5 if dtype == torch.float32 else 1e-10
+    rng = np.random.default_rng(n)
+    x = cg.srange(-1, 1, n, dtype)
+    xs = oracle.srange_points(oracle.srange(-1, 1, n))
+    a = rng.standard_normal(n).astype(npdt(dtype)); y0 = rng.standard_normal(n).astype(npdt(dtype))
+    ad = torch.from_numpy(a).cuda()
+    for k, ko in ((cg.Exp(), oracle.Kernel(oracle.EXP)), (cg.Lengthscale(cg.EQ(), 0.05), oracle.Kernel(oracle.EQ, lengthscale=0.05))):
+        G = cg.gramian(k, x)
+        assert isinstance(G, cg.SymmetricToeplitz)
+        vc, _ = oracle.toeplitz_vectors(ko, oracle.srange(-1, 1, n))
+        ref = oracle.toeplitz_mul(None, vc, None, a.astype(np.float64))
+        b = (G @ ad).cpu().numpy()
+        assert relerr(b, ref) <= tol, (n, relerr(b, ref))
+        rows = rng.choice(n, 16, replace=False)
+        dense_rows = np.array([np.dot(vc[np.abs(i - np.arange(n))], a.astype(np.float64)) for i in rows])
+        assert relerr(b[rows], dense_rows) <= tol
+        yd = torch.from_numpy(y0.copy()).cuda()
+        cg.mul_(yd, G, ad, 0.3, -1.1)
+        assert relerr(yd.cpu().numpy(), 0.3 * ref - 1.1 * y0) <= tol
+        yn = torch.full((n,), float("nan"), dtype=dtype, device="cuda")       # beta == 0 ignores NaN
+        cg.mul_(yn, G, ad, 1.0, 0.0)
+        assert relerr(yn.cpu().numpy(), ref) <= tol
+    # non-symmetric: shifted y, same step
+    Tn = cg.gramian(cg.Exp(), x, x + 0.123)
+    assert isinstance(Tn, cg.Toeplitz)
+    rg = oracle.srange(-1, 1, n)
+    vc2, vr2 = oracle.toeplitz_vectors(oracle.Kernel(oracle.EXP), rg, (rg[0] + 0.123, rg[1], rg[2]))
+    assert relerr((Tn @ ad).cpu().numpy(), oracle.toeplitz_mul(None, vc2, vr2, a.astype(np.float64))) <= tol
