@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "dense_mvm.hpp"
+#include "dense_wide.hpp"
 #include "grad_mvm.hpp"
 
 namespace covgram {
@@ -37,8 +38,9 @@ int pad_dim(int d) {
 }
 
 // per-family launchers (dense_fam.hip / grad_fam.hip, one translation unit per family)
-#define CG_DECL(n)                                            \
-    int launch_dense_family_##n(const DenseArgs&, int dtype); \
+#define CG_DECL(n)                                                 \
+    int launch_dense_family_##n(const DenseArgs&, int dtype);      \
+    int launch_dense_wide_family_##n(const DenseArgs&, int dtype); \
     int launch_grad_family_##n(const GradArgs&, int dtype);
 CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
 #undef CG_DECL
@@ -47,6 +49,13 @@ dense_launch_fn dense_launcher(int family) {
     static const dense_launch_fn t[COVGRAM_NFAMILY] = {
         launch_dense_family_0, launch_dense_family_1, launch_dense_family_2, launch_dense_family_3, launch_dense_family_4,
         launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8};
+    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+}
+dense_launch_fn dense_wide_launcher(int family) {
+    static const dense_launch_fn t[COVGRAM_NFAMILY] = {
+        launch_dense_wide_family_0, launch_dense_wide_family_1, launch_dense_wide_family_2, launch_dense_wide_family_3,
+        launch_dense_wide_family_4, launch_dense_wide_family_5, launch_dense_wide_family_6, launch_dense_wide_family_7,
+        launch_dense_wide_family_8};
     return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
 }
 grad_launch_fn grad_launcher(int family) {
@@ -439,9 +448,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     HostKernel hk;
     rc = make_host_kernel(k, dtype, false, &hk);
     if (rc) return rc;
-    const int D = pad_dim(X->d);
-    CG_REQUIRE(D > 0, COVGRAM_EUNSUPPORTED, "dense_mvm: d = %d exceeds the largest compiled dimension %d", X->d, kDims[kNumDims - 1]);
-    dense_launch_fn launch = dense_launcher(k->family);
+    // d <= 64: x_i lives in registers (dense_mvm.hpp); beyond that the chunked kernel of dense_wide.hpp (any d)
+    const bool wide = X->d > kDims[kNumDims - 1];
+    const int D = wide ? ((X->d + 31) / 32) * 32 : pad_dim(X->d);
+    dense_launch_fn launch = wide ? dense_wide_launcher(k->family) : dense_launcher(k->family);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return COVGRAM_OK;
 
@@ -484,9 +494,21 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             continue;
         }
         void* P;
-        const int64_t mp = ((m + PKN - 1) / PKN) * PKN;     // stream padded to whole column groups
+        int64_t mp = ((m + PKN - 1) / PKN) * PKN;           // stream padded to whole column groups
+        if (wide) {                                         // ... or to whole column blocks of the wide kernel
+            const int64_t bc = 32 * PKN;
+            mp = ((m + bc - 1) / bc) * bc;
+        }
         rc = ws_reserve(ctx, 0, (size_t)mp * (D + NRpad) * ts, &P); if (rc) return rc;
-        if (dtype == COVGRAM_F32)
+        if (wide) {
+            const int64_t tot = mp * (int64_t)(D + NRpad);
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(dense_wide_pack_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const float*)Y->dptr, m, Y->d, D, (const float*)a_c, lda_d, nr, 0, (float*)P, NRpad, PKN, 32, (float)hk.kp.gamma);
+            else
+                hipLaunchKernelGGL(dense_wide_pack_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const double*)Y->dptr, m, Y->d, D, (const double*)a_c, lda_d, nr, 0, (double*)P, NRpad, PKN, 32, hk.kp.gamma);
+        } else if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma);
         else

@@ -137,6 +137,7 @@ struct DenseArgs {
 };
 typedef int (*dense_launch_fn)(const DenseArgs&, int dtype);
 dense_launch_fn dense_launcher(int family);
+dense_launch_fn dense_wide_launcher(int family);
 
 struct GradArgs {
     const void* X; int64_t n; int32_t d;

@@ -330,3 +330,26 @@ def test_toeplitz_four_step_fft_path(cg, oracle, dtype, n):
     rg = oracle.srange(-1, 1, n)
     vc2, vr2 = oracle.toeplitz_vectors(oracle.Kernel(oracle.EXP), rg, (rg[0] + 0.123, rg[1], rg[2]))
     assert relerr((Tn @ ad).cpu().numpy(), oracle.toeplitz_mul(None, vc2, vr2, a.astype(np.float64))) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [65, 100, 256])
+def test_dense_wide_dimensions(cg, oracle, dtype, d):
+    """d > 64 takes the chunked kernel (csrc/dense_wide.hpp): same direct-difference arithmetic, any d, odd m, matrix RHS."""
+    rng = np.random.default_rng(1000 + d)
+    n, m = 300, 257
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype)); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+    a = rng.standard_normal(m).astype(npdt(dtype)); A3 = rng.standard_normal((m, 3)).astype(npdt(dtype))
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    for name, k, ko in kernel_cases.cases(cg):
+        if name not in ("EQ", "MaternP(2)", "RQ(1.0)", "Dot()^3", "ExponentialDot", "2.5*Lengthscale(MaternP(2),1.3)"):
+            continue
+        G = cg.gramian(k, Xd, Yd)
+        assert relerr((G @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.mul(None, ko, X, Y, a, dtype=npdt(dtype))) <= TOL[dtype], (name, d)
+        assert relerr((G @ torch.from_numpy(A3).cuda()).cpu().numpy(), oracle.mul(None, ko, X, Y, A3, dtype=npdt(dtype))) <= TOL[dtype], (name, d)
+    # README-sized case: EQ, d = 1024 (README.md:369-395 uses d = 32; the gradient README case has d = 1024)
+    if d == 256:
+        Xb = rng.standard_normal((2048, 1024)).astype(npdt(dtype)) / 32; ab = rng.standard_normal(2048).astype(npdt(dtype))
+        Gb = cg.gramian(cg.EQ(), torch.from_numpy(Xb).cuda())
+        rows = rng.choice(2048, 64, replace=False)
+        assert relerr((Gb @ torch.from_numpy(ab).cuda()).cpu().numpy()[rows], oracle.mul(None, oracle.Kernel(oracle.EQ), Xb[rows], Xb, ab, dtype=npdt(dtype))) <= TOL[dtype]

@@ -58,3 +58,10 @@ if __name__ == "__main__":
     T = cg.gramian(cg.Exp(), cg.srange(-1, 1, nt)); at = torch.randn(nt, dtype=torch.float64, device="cuda"); yt = torch.empty_like(at)
     med, mn = timeit(lambda: T.mul_(yt, at))
     print(f"Toeplitz Exp n=2^22 f64: median {med:.3f} ms min {mn:.3f} ms -> {1e3/mn:.1f} MVM/s; ideal 470MB -> {470e6/(mn*1e-3)*1e-12:.2f} TB/s algorithmic")
+    # wide-d dense (d > 64): README-like EQ d=1024, n=16384 would be 2.7e8 pairs x 2048 lane-ops
+    for (nw, dw, dt) in ((16384, 128, torch.float32), (8192, 1024, torch.float32), (8192, 1024, torch.float64)):
+        rngw = np.random.default_rng(5)
+        Xw = torch.from_numpy(rngw.standard_normal((nw, dw)) / np.sqrt(dw)).to(dt).cuda(); aw = torch.randn(nw, dtype=dt, device="cuda")
+        Gw = cg.gramian(cg.EQ(), Xw); yw = torch.empty(nw, dtype=dt, device="cuda")
+        med, mn = timeit(lambda: Gw.mul_(yw, aw), warm=2, reps=5)
+        print(f"wide EQ n={nw} d={dw} {dt}: median {med:.3f} ms min {mn:.3f} ms -> {nw*nw*2.0*dw/(mn*1e-3)*1e-12:.2f} T lane-ops/s")
