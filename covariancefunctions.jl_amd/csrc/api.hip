@@ -10,6 +10,7 @@
 #include "dense_mvm.hpp"
 #include "dense_wide.hpp"
 #include "grad_mvm.hpp"
+#include "grad_wide.hpp"
 
 namespace covgram {
 
@@ -41,7 +42,8 @@ int pad_dim(int d) {
 #define CG_DECL(n)                                                 \
     int launch_dense_family_##n(const DenseArgs&, int dtype);      \
     int launch_dense_wide_family_##n(const DenseArgs&, int dtype); \
-    int launch_grad_family_##n(const GradArgs&, int dtype);
+    int launch_grad_family_##n(const GradArgs&, int dtype);        \
+    int launch_grad_wide_family_##n(const GradWideArgs&, int dtype);
 CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
 #undef CG_DECL
 
@@ -189,6 +191,14 @@ int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out) {
 }
 
 // dense instantiation: generic over family via a uniform switch (HBM-write-bound, n*m*sizeof(T) out)
+grad_wide_launch_fn grad_wide_launcher(int family) {
+    static const grad_wide_launch_fn t[COVGRAM_NFAMILY] = {
+        launch_grad_wide_family_0, launch_grad_wide_family_1, launch_grad_wide_family_2, launch_grad_wide_family_3,
+        launch_grad_wide_family_4, launch_grad_wide_family_5, launch_grad_wide_family_6, launch_grad_wide_family_7,
+        launch_grad_wide_family_8};
+    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+}
+
 std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx) {
     if (!ctx->time_kernels) return nullptr;
     if (ctx->timers_used == ctx->timers.size()) {
@@ -589,8 +599,9 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
     HostKernel hk;
     rc = make_host_kernel(k, dtype, true, &hk);
     if (rc) return rc;
-    const int D = pad_dim(d);
-    CG_REQUIRE(D > 0, COVGRAM_EUNSUPPORTED, "grad_mvm: d = %d exceeds the largest compiled dimension %d", d, kDims[kNumDims - 1]);
+    // lane-owned rows up to d = 64 (fp32) / 48 (fp64) (grad_mvm.hpp); wider rows take the two-kernel panel path (grad_wide.hpp)
+    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
+    const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(k->family);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return COVGRAM_OK;
@@ -619,6 +630,35 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         else
             hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)nullptr,
                                npad, D, 0, (double*)y_dev, n, d, 0.0, beta);
+    } else if (wide) {
+        const int PKN = (dtype == COVGRAM_F32) ? 2 : 1;
+        const int64_t BC = (int64_t)GJG * PKN;
+        const int64_t mpad = ((m + BC - 1) / BC) * BC;
+        const int64_t npad64 = ((n + 63) / 64) * 64;
+        int64_t panel = (((int64_t)256 << 20) / (npad64 * 2 * (int64_t)ts)) / BC * BC;   // coefficient slab <= 256 MB
+        panel = std::max<int64_t>(BC, std::min<int64_t>(panel, mpad));
+        grad_wide_launch_fn wlaunch = grad_wide_launcher(k->family);
+        for (int64_t col0 = 0; col0 < mpad; col0 += panel) {
+            const int64_t pc = std::min<int64_t>(panel, mpad - col0);
+            void *P, *C;
+            rc = ws_reserve(ctx, 0, (size_t)pc * D * 2 * ts, &P); if (rc) return rc;
+            rc = ws_reserve(ctx, 1, (size_t)pc * npad64 * 2 * ts, &C); if (rc) return rc;
+            const int64_t pe = pc * (int64_t)D;
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(grad_wide_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const float*)Y->dptr, m, d, D, (const float*)a_dev, col0, pc, (float*)P, PKN, (float)hk.kp.gamma);
+            else
+                hipLaunchKernelGGL(grad_wide_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma);
+            GradWideArgs wa;
+            wa.X = X->dptr; wa.n = n; wa.d = d; wa.dpad = D; wa.P = P; wa.C1 = C; wa.C2 = (char*)C + (size_t)pc * npad64 * ts;
+            wa.npad = npad64; wa.nblocks = pc / BC; wa.y = y_dev; wa.alpha = alpha_eff; wa.beta = beta; wa.accumulate = col0 > 0 ? 1 : 0;
+            wa.hk = &hk; wa.stream = ctx->stream;
+            auto* tm = timer_next(ctx);
+            if (tm) (void)hipEventRecord(tm->first, ctx->stream);
+            rc = wlaunch(wa, dtype); if (rc) return rc;
+            if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+        }
     } else {
         void* P;
         rc = ws_reserve(ctx, 0, (size_t)(m + 1) * 2 * D * ts, &P); if (rc) return rc;   // + 1 prefetch-only record

@@ -353,3 +353,32 @@ def test_dense_wide_dimensions(cg, oracle, dtype, d):
         Gb = cg.gramian(cg.EQ(), torch.from_numpy(Xb).cuda())
         rows = rng.choice(2048, 64, replace=False)
         assert relerr((Gb @ torch.from_numpy(ab).cuda()).cpu().numpy()[rows], oracle.mul(None, oracle.Kernel(oracle.EQ), Xb[rows], Xb, ab, dtype=npdt(dtype))) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [65, 100, 256])
+def test_gradient_wide_dimensions(cg, oracle, dtype, d):
+    """d beyond the lane-owned limit takes the two-kernel panel path (csrc/grad_wide.hpp): rectangular, odd m, alpha/beta."""
+    tol = 3e-5 if dtype == torch.float32 else 1e-12
+    rng = np.random.default_rng(2000 + d)
+    n, m = 70, 45
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype)); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+    a = rng.standard_normal(m * d).astype(npdt(dtype)); b0 = rng.standard_normal(n * d).astype(npdt(dtype))
+    Xd, Yd, ad = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(a).cuda()
+    for name, k, ko in kernel_cases.grad_cases(cg):
+        if name not in ("EQ", "MaternP(2)", "RQ(1.0)", "Dot()^3", "ExponentialDot", "2.5*Lengthscale(MaternP(2),1.3)", "EQ^2"):
+            continue
+        K = cg.gramian(cg.GradientKernel(k), Xd, Yd)
+        assert tuple(K.shape) == (n * d, m * d)
+        assert relerr((K @ ad).cpu().numpy(), oracle.grad_mul(None, ko, X, Y, a, dtype=npdt(dtype))) <= tol, (name, d)
+        bd = torch.from_numpy(b0.copy()).cuda()
+        cg.mul_(bd, K, ad, -0.6, 1.4)
+        assert relerr(bd.cpu().numpy(), oracle.grad_mul(b0, ko, X, Y, a, -0.6, 1.4, npdt(dtype))) <= tol, (name, d)
+    if d == 256:   # the README gradient case shape (README.md:231-245): MaternP(2), d = 1024, n = 1024 (here checked on a row subset)
+        nb, db = 1024, 1024
+        Xb = (rng.standard_normal((nb, db)) / np.sqrt(db)).astype(npdt(dtype)); ab = rng.standard_normal(nb * db).astype(npdt(dtype))
+        Kb = cg.gramian(cg.GradientKernel(cg.MaternP(2)), torch.from_numpy(Xb).cuda())
+        got = (Kb @ torch.from_numpy(ab).cuda()).cpu().numpy().reshape(nb, db)
+        rows = np.sort(rng.choice(nb, 8, replace=False))
+        ref = oracle.grad_mul(None, oracle.Kernel(oracle.MATERNP, p=2), Xb[rows], Xb, ab, dtype=npdt(dtype)).reshape(8, db)
+        assert relerr(got[rows], ref) <= tol
