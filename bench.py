@@ -87,13 +87,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # RCCL prints its version banner and warnings on fd 1; keep the contract's ONE JSON line clean by routing every other
+    # write to stdout (C libraries included) to stderr and printing the result on the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("COVGRAM_FORCE_COLLECTIVE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -195,9 +202,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(Xh, ah)
             except Exception as e:   # the baseline is reporting only; never fail the GPU measurement for it
                 line["cpu_baseline"] = {"value": None, "unit": "MVM/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -46,13 +46,15 @@ class ShardedGramian:
         else:
             self.local = None
         self.shape = (self.n, self.m)
+        # exercise the collective even on one rank (used to validate the RCCL path on single-GPU boxes)
+        self.force_collective = bool(int(__import__("os").environ.get("COVGRAM_FORCE_COLLECTIVE", "0"))) and dist.is_initialized()
 
     def _buffers(self, a: torch.Tensor):
         key = (tuple(a.shape[1:]), a.dtype, a.device)
         if getattr(self, "_buf_key", None) != key:
             tail = tuple(a.shape[1:])
             self._shard = torch.zeros((self.per,) + tail, dtype=a.dtype, device=a.device)
-            self._full = torch.empty((self.per * self.world,) + tail, dtype=a.dtype, device=a.device) if self.world > 1 else None
+            self._full = torch.empty((self.per * self.world,) + tail, dtype=a.dtype, device=a.device)
             self._buf_key = key
         return self._shard, self._full
 
@@ -67,7 +69,7 @@ class ShardedGramian:
         """b = G a, complete on every rank.  a: (m,) or (m, p), replicated.  Buffers are allocated once and reused
         (Krylov callers multiply with the same shapes every iteration)."""
         rows = self.hi - self.lo
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             if out is None:
                 out = torch.empty((self.n,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
             if self.local is not None:
