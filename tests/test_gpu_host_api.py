@@ -1,0 +1,160 @@
+"""GPU tier: the C ABI exactly as a `ccall` shim would use it — HOST pointers (numpy arrays), library-side staging — for
+every entry point of include/covgram.h, plus the edge cases the reference's loops accept (empty inputs, many RHS)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(b, ref):
+    b = np.asarray(b, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    den = np.linalg.norm(ref)
+    return np.linalg.norm(b - ref) / (den if den > 0 else 1.0)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def ctx(cg):
+    lib = cg._ffi.lib()
+    h = cg._ffi._P()
+    cg._ffi.check(lib.covgram_ctx_create(C.byref(h), 0, None))     # NULL stream = the default stream
+    yield h
+    assert lib.covgram_ctx_destroy(h) == 0
+
+
+def make_points(cg, ctx, X):
+    lib = cg._ffi.lib()
+    h = cg._ffi._P()
+    X = np.ascontiguousarray(X)
+    cg._ffi.check(lib.covgram_points_create(ctx, C.byref(h), P(X), X.shape[0], X.shape[1],
+                                            cg._ffi.F64 if X.dtype == np.float64 else cg._ffi.F32, cg._ffi.HOST))
+    return h
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_host_pointer_mvm_matrix_gradient(cg, oracle, ctx, dt):
+    lib, f = cg._ffi.lib(), cg._ffi
+    tol = 1e-5 if dt == np.float32 else 1e-12
+    rng = np.random.default_rng(3)
+    n, m, d = 301, 123, 3
+    X = rng.standard_normal((n, d)).astype(dt); Y = rng.standard_normal((m, d)).astype(dt)
+    hx, hy = make_points(cg, ctx, X), make_points(cg, ctx, Y)
+    nn, dd, tt = C.c_int64(), C.c_int32(), C.c_int32()
+    assert lib.covgram_points_info(hx, C.byref(nn), C.byref(dd), C.byref(tt)) == 0 and (nn.value, dd.value) == (n, d)
+    spec = cg.device_spec(cg.Lengthscale(cg.MaternP(2), 0.8) * 1.7)
+    ko = oracle.Kernel(oracle.MATERNP, p=2, lengthscale=0.8, scale=1.7)
+    # vector and 7-column matrix right-hand sides with leading dimensions larger than the extents
+    for nrhs in (1, 7):
+        lda, ldy = m + 5, n + 3
+        A = np.zeros((nrhs, lda), dtype=dt); A[:, :m] = rng.standard_normal((nrhs, m))          # column-major m x nrhs, lda
+        Yo = np.zeros((nrhs, ldy), dtype=dt); Yo[:, :n] = rng.standard_normal((nrhs, n))
+        Y0 = Yo.copy()
+        f.check(lib.covgram_mvm(ctx, C.byref(spec), hx, hy, P(A), lda, P(Yo), ldy, nrhs, -0.7, 1.3, f.HOST))
+        ref = oracle.mul(Y0[:, :n].T, ko, X, Y, A[:, :m].T, -0.7, 1.3, dt)
+        assert relerr(Yo[:, :n].T, ref) <= tol
+        assert np.array_equal(Yo[:, n:], Y0[:, n:])                                              # padding rows untouched
+    # Matrix(G)
+    M = np.zeros((m, n + 2), dtype=dt)
+    f.check(lib.covgram_matrix(ctx, C.byref(spec), hx, hy, P(M), n + 2, f.HOST))
+    assert relerr(M[:, :n].T, oracle.matrix(ko, X, Y, dt)) <= tol
+    # row-shard slice == the corresponding rows
+    hs = f._P()
+    f.check(lib.covgram_points_slice(hx, 100, 50, C.byref(hs)))
+    a = rng.standard_normal(m).astype(dt); ys = np.zeros(50, dtype=dt)
+    f.check(lib.covgram_mvm(ctx, C.byref(spec), hs, hy, P(a), m, P(ys), 50, 1, 1.0, 0.0, f.HOST))
+    assert relerr(ys, oracle.mul(None, ko, X[100:150], Y, a, dtype=dt)) <= tol
+    assert lib.covgram_points_slice(hx, 290, 50, C.byref(f._P())) == f.EINVAL
+    # gradient MVM through host pointers
+    ag = rng.standard_normal(m * d).astype(dt); yg = rng.standard_normal(n * d).astype(dt); yg0 = yg.copy()
+    f.check(lib.covgram_grad_mvm(ctx, C.byref(spec), hx, hy, P(ag), P(yg), 0.4, -0.9, f.HOST))
+    assert relerr(yg, oracle.grad_mul(yg0, ko, X, Y, ag, 0.4, -0.9, dt)) <= (3e-5 if dt == np.float32 else 1e-12)
+    # dimension mismatch -> status, not a crash
+    hz = make_points(cg, ctx, rng.standard_normal((5, 2)).astype(dt))
+    assert lib.covgram_mvm(ctx, C.byref(spec), hx, hz, P(a), m, P(ys), n, 1, 1.0, 0.0, f.HOST) == f.EINVAL
+    assert b"same length" in lib.covgram_last_error()
+    for h in (hs, hx, hy, hz):
+        assert lib.covgram_points_destroy(h) == 0
+
+
+def test_host_pointer_toeplitz_kron_lowrank(cg, oracle, ctx):
+    lib, f = cg._ffi.lib(), cg._ffi
+    rng = np.random.default_rng(4)
+    # Toeplitz, non-symmetric, both the rocFFT path (small) and the four-step path (N >= 16384)
+    for n, m in ((300, 200), (9000, 9000)):
+        vc = rng.standard_normal(n); vr = rng.standard_normal(m); vr[0] = vc[0]
+        a = rng.standard_normal(m); y = rng.standard_normal(n); y0 = y.copy()
+        h = f._P()
+        f.check(lib.covgram_toeplitz_create(ctx, C.byref(h), P(vc), P(vr), n, m, f.F64, f.HOST, 0))
+        f.check(lib.covgram_toeplitz_mvm(h, P(a), P(y), 0.5, 2.0, f.HOST))
+        assert relerr(y, oracle.toeplitz_mul(y0, vc, vr, a, 0.5, 2.0)) <= 1e-10
+        assert lib.covgram_toeplitz_destroy(h) == 0
+    # circulant of odd length
+    vc = rng.standard_normal(33); a = rng.standard_normal(33); y = np.zeros(33)
+    h = f._P()
+    f.check(lib.covgram_toeplitz_create(ctx, C.byref(h), P(vc), None, 33, 33, f.F64, f.HOST, 1))
+    f.check(lib.covgram_toeplitz_mvm(h, P(a), P(y), 1.0, 0.0, f.HOST))
+    assert relerr(y, oracle.toeplitz_dense(vc, circulant=True) @ a) <= 1e-12
+    assert lib.covgram_toeplitz_destroy(h) == 0
+    # Kronecker with host factors (column-major with padding in the leading dimension)
+    shapes = [(3, 5), (4, 2), (2, 6)]
+    Fs = [rng.standard_normal(s) for s in shapes]
+    lds = [s[0] + 1 for s in shapes]
+    bufs = []
+    for Fm, ld in zip(Fs, lds):
+        b = np.zeros((Fm.shape[1], ld)); b[:, :Fm.shape[0]] = Fm.T
+        bufs.append(b)
+    ptrs = (f._P * 3)(*[P(b) for b in bufs])
+    rows = (C.c_int64 * 3)(*[s[0] for s in shapes]); cols = (C.c_int64 * 3)(*[s[1] for s in shapes]); ldarr = (C.c_int64 * 3)(*lds)
+    av = rng.standard_normal(5 * 2 * 6); yv = rng.standard_normal(3 * 4 * 2); yv0 = yv.copy()
+    f.check(lib.covgram_kron_mvm(ctx, ptrs, rows, cols, ldarr, 3, f.F64, P(av), P(yv), 1.5, -0.5, f.HOST))
+    assert relerr(yv, 1.5 * np.kron(np.kron(Fs[0], Fs[1]), Fs[2]) @ av - 0.5 * yv0) <= 1e-12
+    # low rank
+    n, m, r = 500, 300, 5
+    U = rng.standard_normal((n, r)); V = rng.standard_normal((m, r))
+    Uc = np.asfortranarray(U); Vc = np.asfortranarray(V)
+    a = rng.standard_normal(m); y = rng.standard_normal(n); y0 = y.copy()
+    f.check(lib.covgram_lowrank_mvm(ctx, P(Uc), n, P(Vc), m, n, m, r, f.F64, P(a), P(y), 2.0, 0.25, f.HOST))
+    assert relerr(y, oracle.lowrank_mul(y0, U, V, a, 2.0, 0.25)) <= 1e-12
+
+
+def test_empty_and_degenerate_inputs(cg, oracle):
+    """Edge cases the reference's loops accept: no columns (y <- beta y), no rows, one point, many RHS, d at the boundaries."""
+    dev = "cuda"
+    x = torch.randn(17, 3, device=dev, dtype=torch.float64)
+    empty = torch.zeros(0, 3, device=dev, dtype=torch.float64)
+    G = cg.gramian(cg.EQ(), x, empty)                       # 17 x 0
+    y = torch.randn(17, device=dev, dtype=torch.float64); y0 = y.clone()
+    cg.mul_(y, G, torch.zeros(0, device=dev, dtype=torch.float64), 1.0, 0.5)
+    assert torch.allclose(y, 0.5 * y0)
+    yn = torch.full((17,), float("nan"), device=dev, dtype=torch.float64)
+    cg.mul_(yn, G, torch.zeros(0, device=dev, dtype=torch.float64), 1.0, 0.0)
+    assert torch.all(yn == 0)                               # beta == 0: zero-filled, NaN ignored (gramian.jl:80)
+    G0 = cg.gramian(cg.EQ(), empty, x)                      # 0 x 17
+    assert (G0 @ torch.randn(17, device=dev, dtype=torch.float64)).shape == (0,)
+    Kg = cg.gramian(cg.GradientKernel(cg.EQ()), x, empty)
+    yg = torch.randn(51, device=dev, dtype=torch.float64); yg0 = yg.clone()
+    cg.mul_(yg, Kg, torch.zeros(0, device=dev, dtype=torch.float64), 1.0, -2.0)
+    assert torch.allclose(yg, -2.0 * yg0)
+    # d exactly at the lane-owned limits and one past them (dense 64/65; gradient fp64 48/49)
+    rng = np.random.default_rng(12)
+    for d in (64, 65):
+        X = rng.standard_normal((130, d)) / np.sqrt(d); a = rng.standard_normal(130)
+        Gd = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda())
+        assert relerr((Gd @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a)) <= 1e-12
+    for d in (48, 49):
+        X = rng.standard_normal((40, d)) / np.sqrt(d); a = rng.standard_normal(40 * d)
+        Kd = cg.gramian(cg.GradientKernel(cg.RQ(1.0)), torch.from_numpy(X).cuda())
+        assert relerr((Kd @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.grad_mul(None, oracle.Kernel(oracle.RQ, param=1.0), X, X, a)) <= 1e-12
+    # 9 right-hand sides (three kernel passes of <= 4 columns), non-contiguous inputs
+    X = rng.standard_normal((200, 2)); A = rng.standard_normal((200, 9))
+    Gm = cg.gramian(cg.Cauchy(), torch.from_numpy(X).cuda())
+    At = torch.from_numpy(np.asfortranarray(A)).cuda()      # non-C-contiguous tensor
+    assert relerr((Gm @ At).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.CAUCHY), X, X, A)) <= 1e-12
+    one = torch.randn(1, 3, device=dev, dtype=torch.float32)
+    assert abs(float((cg.gramian(cg.EQ(), one) @ torch.ones(1, device=dev))[0]) - 1.0) < 1e-6
