@@ -337,6 +337,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
+    else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -531,7 +532,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         DenseArgs da;
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
         da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;
-        da.variant = (int)ctx->dense_variant; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
+        da.variant = (int)ctx->dense_variant; da.lds_pad = (int)ctx->lds_pad; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
         if (jsplit == 1) da.out = y_c;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
         auto* tm = timer_next(ctx);

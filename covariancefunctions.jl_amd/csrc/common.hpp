@@ -99,6 +99,7 @@ struct covgram_ctx {
     int64_t jsplit = 0;          // 0 = auto
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int64_t grad_keep_r = -1;    // -1 auto
+    int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int num_cus = 256;
     int live_handles = 0;
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
@@ -131,6 +132,7 @@ struct DenseArgs {
     int64_t npad; int64_t ldy;
     int32_t nrhs; int32_t Dpad; int32_t NRpad;
     int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
+    int32_t lds_pad = 0;                   // dynamic LDS bytes requested only to cap waves per CU (occupancy experiments)
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;

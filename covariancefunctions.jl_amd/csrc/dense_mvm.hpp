@@ -226,7 +226,7 @@ static int launch_dense_one(const DenseArgs& a) {
     const int64_t rows_per_wg = (int64_t)DENSE_THREADS * R;
     dim3 grid((unsigned)((a.n + rows_per_wg - 1) / rows_per_wg), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
-    hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW>), grid, dim3(DENSE_THREADS), 0, a.stream, (const T*)a.X, a.n,
+    hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW>), grid, dim3(DENSE_THREADS), (size_t)a.lds_pad, a.stream, (const T*)a.X, a.n,
                        a.d, (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha,
                        (T)a.beta, final_store, kp);
     hipError_t e = hipGetLastError();

@@ -121,7 +121,7 @@ constexpr int TWID_LB = 11;   // two-level twiddle: W_M^idx = thi[idx >> 11] * t
 constexpr int COLFFT_THREADS = 1024;   // 4 waves per SIMD: one wave per SIMD reaches only a fraction of the LDS rates
 
 template <typename T, int TW, bool INV>
-__global__ __launch_bounds__(COLFFT_THREADS) void colfft_kernel(const T* __restrict__ src, int64_t src_len,
+__global__ __launch_bounds__(COLFFT_THREADS, 8) void colfft_kernel(const T* __restrict__ src, int64_t src_len,
                                                      typename V2T<T>::type* __restrict__ zbuf, int64_t Mp,
                                                      const typename V2T<T>::type* __restrict__ tw1024,
                                                      const typename V2T<T>::type* __restrict__ tlo,
@@ -137,27 +137,39 @@ __global__ __launch_bounds__(COLFFT_THREADS) void colfft_kernel(const T* __restr
     const int64_t col0 = (int64_t)tile * TW;
     constexpr int NT = COLFFT_THREADS;
     for (int t = tid; t < COLFFT_N1; t += NT) stw[t] = INV ? cconj(tw1024[t]) : tw1024[t];
-    // ---- load (digit-reversed rows) ---------------------------------------------------------------------------------
-    for (int e = tid; e < COLFFT_N1 * TW; e += NT) {
-        const int c = e % TW, row = e / TW;
+    // ---- load fused with the first radix-4 stage (its twiddles are all 1) --------------------------------------------------
+    // DIT stage 0 combines the LDS slots 4g .. 4g+3, i.e. (digit reversal) the rows rr, rr+256, rr+512, rr+768 with
+    // rr = rev4(g): each thread fetches those four rows of one column straight from HBM and writes the butterfly outputs.
+    for (int e = tid; e < 256 * TW; e += NT) {
+        const int c = e % TW, rr = e / TW;
         const int64_t np = col0 + c;
-        V v;
-        if constexpr (!INV) {
-            const int64_t j = (int64_t)row * Mp + np;                 // packed complex index: z_j = x[2j] + i x[2j+1]
-            v.x = (2 * j < src_len) ? src[2 * j] : (T)0;
-            v.y = (2 * j + 1 < src_len) ? src[2 * j + 1] : (T)0;
-        } else {
-            const int64_t idx = np * (int64_t)row;                    // n' * k1 < M
-            const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
-            v = cmul(zbuf[(int64_t)row * Mp + np], cconj(w));
+        V v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rr + 256 * q;
+            if constexpr (!INV) {
+                const int64_t j = (int64_t)row * Mp + np;             // packed complex index: z_j = x[2j] + i x[2j+1]
+                v[q].x = (2 * j < src_len) ? src[2 * j] : (T)0;
+                v[q].y = (2 * j + 1 < src_len) ? src[2 * j + 1] : (T)0;
+            } else {
+                const int64_t idx = np * (int64_t)row;                // n' * k1 < M
+                const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
+                v[q] = cmul(zbuf[(int64_t)row * Mp + np], cconj(w));
+            }
         }
-        buf[rev4_10(row) * TW + c] = v;
+        const V apc = cadd(v[0], v[2]), amc = csub(v[0], v[2]), bpd = cadd(v[1], v[3]), bmd = csub(v[1], v[3]);
+        const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+        const int g = ((rr & 0x3) << 6) | ((rr & 0xC) << 2) | ((rr >> 2) & 0xC) | ((rr >> 6) & 0x3);   // rev4 of the 8-bit index
+        buf[(4 * g + 0) * TW + c] = cadd(apc, bpd);
+        buf[(4 * g + 1) * TW + c] = cadd(amc, ib);
+        buf[(4 * g + 2) * TW + c] = csub(apc, bpd);
+        buf[(4 * g + 3) * TW + c] = csub(amc, ib);
     }
     __syncthreads();
-    // ---- five in-place radix-4 DIT stages -----------------------------------------------------------------------------
+    // ---- three in-place radix-4 DIT stages in LDS (L = 4, 16, 64) ------------------------------------------------------------
     const int c = tid % TW, bb = tid / TW;
 #pragma unroll 1
-    for (int s = 0; s < 5; ++s) {
+    for (int s = 1; s < 4; ++s) {
         const int L = 1 << (2 * s);
 #pragma unroll
         for (int r = 0; r < 256 * TW / NT; ++r) {
@@ -179,26 +191,36 @@ __global__ __launch_bounds__(COLFFT_THREADS) void colfft_kernel(const T* __restr
         }
         __syncthreads();
     }
-    // ---- store ------------------------------------------------------------------------------------------------------
-    for (int e = tid; e < COLFFT_N1 * TW; e += NT) {
-        const int cq = e % TW, row = e / TW;
+    // ---- last stage (L = 256) fused with the store: outputs are the rows j, j+256, j+512, j+768 in natural order ---------------
+    for (int e = tid; e < 256 * TW; e += NT) {
+        const int cq = e % TW, j = e / TW;
         const int64_t np = col0 + cq;
-        const V v = buf[row * TW + cq];
-        if constexpr (!INV) {
-            const int64_t idx = np * (int64_t)row;
-            const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
-            zbuf[(int64_t)row * Mp + np] = cmul(v, w);
-        } else {
-            const int64_t j = (int64_t)row * Mp + np;                 // natural order: y[2j], y[2j+1]
-            if (2 * j < n) {
-                T o = alpha * v.x;
-                if (beta != (T)0) o = __builtin_fma(beta, y[2 * j], o);
-                y[2 * j] = o;
-            }
-            if (2 * j + 1 < n) {
-                T o = alpha * v.y;
-                if (beta != (T)0) o = __builtin_fma(beta, y[2 * j + 1], o);
-                y[2 * j + 1] = o;
+        const V a = buf[j * TW + cq];
+        const V b = cmul(stw[j], buf[(j + 256) * TW + cq]);
+        const V cc = cmul(stw[2 * j], buf[(j + 512) * TW + cq]);
+        const V d = cmul(stw[3 * j], buf[(j + 768) * TW + cq]);
+        const V apc = cadd(a, cc), amc = csub(a, cc), bpd = cadd(b, d), bmd = csub(b, d);
+        const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+        V o[4] = {cadd(apc, bpd), cadd(amc, ib), csub(apc, bpd), csub(amc, ib)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = j + 256 * q;
+            if constexpr (!INV) {
+                const int64_t idx = np * (int64_t)row;
+                const V w = cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]);
+                zbuf[(int64_t)row * Mp + np] = cmul(o[q], w);
+            } else {
+                const int64_t jj = (int64_t)row * Mp + np;            // natural order: y[2jj], y[2jj+1]
+                if (2 * jj < n) {
+                    T ov = alpha * o[q].x;
+                    if (beta != (T)0) ov = __builtin_fma(beta, y[2 * jj], ov);
+                    y[2 * jj] = ov;
+                }
+                if (2 * jj + 1 < n) {
+                    T ov = alpha * o[q].y;
+                    if (beta != (T)0) ov = __builtin_fma(beta, y[2 * jj + 1], ov);
+                    y[2 * jj + 1] = ov;
+                }
             }
         }
     }
