@@ -14,7 +14,7 @@ from ._ffi import CovgramError, DimensionMismatch, UnsupportedKernel, NoDevice
 from .kernels import (AbstractKernel, MercerKernel, StationaryKernel, IsotropicKernel, MultiKernel, Constant,
                       ExponentiatedQuadratic, EQ, RationalQuadratic, RQ, Exponential, Exp, GammaExponential, GammaExp,
                       Cauchy, InverseMultiQuadratic, MaternP, Matern, Dot, ExponentialDot, FiniteBasis, Product, Sum, Power,
-                      Lengthscale, SeparableProduct, separable, SeparableKernel, Separable, GradientKernel, InputTrait,
+                      Lengthscale, SeparableProduct, separable, SeparableKernel, Separable, GradientKernel, ValueGradientKernel, InputTrait,
                       GenericInput, IsotropicInput, DotProductInput, StationaryInput, StationaryLinearFunctionalInput,
                       PeriodicInput, input_trait, register_input_trait, ismercer, isstationary, isisotropic, isdot,
                       device_spec, DomainError)

@@ -14,6 +14,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
 
 # enums (include/covgram.h)
 EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT = range(9)
+CONSTANT, COMPOSITE = 100, 101
+COMPOSITE_MAX_TERMS, COMPOSITE_MAX_FACTORS = 4, 6
 ISOTROPIC, DOTPRODUCT = 1, 2
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
@@ -31,6 +33,21 @@ class covgram_kernel(C.Structure):
         ("lengthscale", C.c_double),
         ("scale", C.c_double),
     ]
+
+
+class covgram_kernel_composite(C.Structure):
+    """Sum of products of same-trait profiles; pass `kref(c)` (== &c.head) wherever a covgram_kernel* is expected."""
+    _fields_ = [
+        ("head", covgram_kernel),
+        ("nterms", C.c_int32),
+        ("nfactors", C.c_int32 * COMPOSITE_MAX_TERMS),
+        ("factors", covgram_kernel * COMPOSITE_MAX_FACTORS),
+    ]
+
+
+def kref(spec):
+    """`const covgram_kernel*` for a simple spec or a composite (whose head is its first member)."""
+    return C.cast(C.pointer(spec), C.POINTER(covgram_kernel))
 
 
 class CovgramError(RuntimeError):
@@ -76,6 +93,7 @@ PROTOTYPES = {
     "covgram_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_matrix": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _I32]),
     "covgram_grad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
+    "covgram_valgrad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_create": (C.c_int, [_P, C.POINTER(_P), _P, _P, _I64, _I64, _I32, _I32, _I32]),
     "covgram_toeplitz_mvm": (C.c_int, [_P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_destroy": (C.c_int, [_P]),

@@ -275,7 +275,7 @@ class Gramian(LazyOperator):
         if a.dim() == 1:
             a_c = a.contiguous()
             y_c = y if y.is_contiguous() else y.contiguous()
-            _ffi.check(lib.covgram_mvm(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(a_c.data_ptr()), max(m, 1),
+            _ffi.check(lib.covgram_mvm(ctx, _ffi.kref(spec), self._px.handle, self._py.handle, _ffi._P(a_c.data_ptr()), max(m, 1),
                                        _ffi._P(y_c.data_ptr()), max(n, 1), 1, float(alpha), float(beta), _ffi.DEVICE))
             if y_c is not y:
                 y.copy_(y_c)
@@ -284,7 +284,7 @@ class Gramian(LazyOperator):
         a_cm = a.t().contiguous()                              # (p, m) row-major == m×p column-major
         direct = y.t().is_contiguous()
         y_cm = y.t() if direct else y.t().contiguous()
-        _ffi.check(lib.covgram_mvm(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(a_cm.data_ptr()), max(m, 1),
+        _ffi.check(lib.covgram_mvm(ctx, _ffi.kref(spec), self._px.handle, self._py.handle, _ffi._P(a_cm.data_ptr()), max(m, 1),
                                    _ffi._P(y_cm.data_ptr()), max(n, 1), p, float(alpha), float(beta), _ffi.DEVICE))
         if not direct:
             y.copy_(y_cm.t())
@@ -297,7 +297,7 @@ class Gramian(LazyOperator):
         if n * m:
             spec = self._spec()
             ctx = self._px.ctx.bind_stream()
-            _ffi.check(_ffi.lib().covgram_matrix(ctx, C.byref(spec), self._px.handle, self._py.handle, _ffi._P(buf.data_ptr()), n, _ffi.DEVICE))
+            _ffi.check(_ffi.lib().covgram_matrix(ctx, _ffi.kref(spec), self._px.handle, self._py.handle, _ffi._P(buf.data_ptr()), n, _ffi.DEVICE))
         return buf.t()
 
     def __getitem__(self, ij):
@@ -319,13 +319,15 @@ class BlockGramian(LazyOperator):
     """Gramian of a GradientKernel: the lazy (n d)×(m d) BlockFactorization of src/gramian.jl:120-123 whose
     `mul!` is blockmul! (src/gramian.jl:241-257) with the O(d) block product of src/gradient.jl:86-115."""
 
-    def __init__(self, g: K.GradientKernel, x, y=None):
+    def __init__(self, g, x, y=None):
         self.g = g
+        self.value = isinstance(g, K.ValueGradientKernel)      # blocks of d+1: src/gradient.jl:400-474
         self.inner = Gramian(g.k, x, y)
         n, m = self.inner.shape
         d = self.inner.x.shape[1]
         self.d = d
-        self.shape = (n * d, m * d)
+        self.block = d + 1 if self.value else d
+        self.shape = (n * self.block, m * self.block)
         self.dtype, self.device = self.inner.dtype, self.inner.device
 
     def issymmetric(self):
@@ -345,7 +347,8 @@ class BlockGramian(LazyOperator):
         a_c = a.contiguous()
         y_c = y if y.is_contiguous() else y.contiguous()
         ctx = self.inner._px.ctx.bind_stream()
-        _ffi.check(_ffi.lib().covgram_grad_mvm(ctx, C.byref(spec), self.inner._px.handle, self.inner._py.handle, _ffi._P(a_c.data_ptr()),
+        fn = _ffi.lib().covgram_valgrad_mvm if self.value else _ffi.lib().covgram_grad_mvm
+        _ffi.check(fn(ctx, _ffi.kref(spec), self.inner._px.handle, self.inner._py.handle, _ffi._P(a_c.data_ptr()),
                                                _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
         if y_c is not y:
             y.copy_(y_c)
@@ -629,7 +632,7 @@ def gramian(k, x=None, y=None, trait: Optional[K.InputTrait] = None):
             return LazyMatrixProduct(U, V)
         raise _ffi.UnsupportedKernel(_ffi.EUNSUPPORTED, "FiniteBasis with fewer points than basis functions is a GenericInput Gramian (src/mercer.jl:68)")
 
-    if isinstance(k, K.GradientKernel):                         # src/gramian.jl:120-123
+    if isinstance(k, (K.GradientKernel, K.ValueGradientKernel)):   # src/gramian.jl:120-123
         return BlockGramian(k, x, None if same else y)
     if isinstance(k, K.SeparableKernel):
         return SeparableGramian(k, x, None if same else y)

@@ -390,6 +390,14 @@ class GradientKernel(MultiKernel):
         self.input_trait = input_trait(k) if it is None else it
 
 
+class ValueGradientKernel(MultiKernel):
+    """src/gradient.jl:400-411: the (d+1)×(d+1) block kernel of [f, ∂f]; carries input_trait(k)."""
+
+    def __init__(self, k, it: Optional[InputTrait] = None):
+        self.k = k
+        self.input_trait = input_trait(k) if it is None else it
+
+
 # ----------------------------------------------------------------------------------------------
 # input_trait (src/properties.jl:39-45, gradient.jl:16) — user-extensible like the reference
 # ----------------------------------------------------------------------------------------------
@@ -407,7 +415,7 @@ def input_trait(k) -> InputTrait:
     for t, tr in _USER_TRAITS.items():
         if isinstance(t, type) and isinstance(k, t):
             return tr
-    if isinstance(k, (Product, Sum, Power, GradientKernel)):
+    if isinstance(k, (Product, Sum, Power, GradientKernel, ValueGradientKernel)):
         return k.input_trait
     if isinstance(k, (Dot, ExponentialDot)):
         return DotProductInput()
@@ -433,8 +441,8 @@ _BASE = {
 }
 
 
-def device_spec(k) -> Optional[_ffi.covgram_kernel]:
-    """covgram_kernel for `k`, or None if k has no device profile (GenericInput in the reference's terms).
+def _simple_spec(k) -> Optional[_ffi.covgram_kernel]:
+    """covgram_kernel for a single profile, or None.
 
     Handles base profiles, Lengthscale nesting, Power (exponents multiply; (c·k)^p = c^p k^p) and
     products with Constants (scale) — the compositions that keep the IsotropicInput / DotProductInput
@@ -475,7 +483,96 @@ def device_spec(k) -> Optional[_ffi.covgram_kernel]:
     return spec
 
 
-def require_device_spec(k) -> _ffi.covgram_kernel:
+def _expand(k, budget=64):
+    """Sum-of-products normal form of a kernel expression: list of (coefficient, [simple specs]), or None.
+
+    Sum concatenates, Product distributes over sums, Power of a composite multiplies out; a Constant is a bare
+    coefficient.  Anything without a compiled profile (closures, Matern(ν), FiniteBasis, ...) gives None."""
+    if isinstance(k, Constant):
+        return [(k.c, [])]
+    s = _simple_spec(k)
+    if s is not None:
+        c, s.scale = s.scale, 1.0
+        return [(c, [s])]
+    if isinstance(k, Sum):
+        out = []
+        for a in k.args:
+            e = _expand(a, budget)
+            if e is None:
+                return None
+            out += e
+        return out if len(out) <= budget else None
+    if isinstance(k, Product) or (isinstance(k, Power) and k.p >= 1):
+        parts = k.args if isinstance(k, Product) else (k.k,) * k.p
+        out = [(1.0, [])]
+        for a in parts:
+            e = _expand(a, budget)
+            if e is None:
+                return None
+            out = [(c1 * c2, f1 + f2) for (c1, f1) in out for (c2, f2) in e]
+            if len(out) > budget:
+                return None
+        return out
+    return None
+
+
+def _copy_spec(dst, src):
+    for name, _ in _ffi.covgram_kernel._fields_:
+        setattr(dst, name, getattr(src, name))
+
+
+def device_spec(k):
+    """What the device runs for `k`: a covgram_kernel (single profile), a covgram_kernel_composite (Sum / Product /
+    Power of kernels sharing one input trait, src/algebra.jl:5-63 with the trait rule of src/properties.jl:47-63),
+    or None if k is GenericInput in the reference's terms or exceeds the composite limits (4 terms, 6 factors)."""
+    s = _simple_spec(k)
+    if s is not None:
+        return s
+    terms = _expand(k)
+    if not terms:
+        return None
+    # merge like terms (pure constants included), drop zero terms
+    merged = {}
+    for c, fs in terms:
+        fs = sorted(fs, key=lambda f: (f.family, f.p, f.power, f.param, f.lengthscale))
+        key = tuple((f.family, f.p, f.power, f.param, f.lengthscale) for f in fs)
+        if key in merged:
+            merged[key] = (merged[key][0] + c, fs)
+        else:
+            merged[key] = (c, fs)
+    terms = [(c, fs) for key, (c, fs) in merged.items() if key and c != 0.0]
+    if () in merged and merged[()][0] != 0.0:
+        terms.append((merged[()][0], []))
+    traits = {f.trait for _, fs in terms for f in fs}
+    if len(traits) != 1:
+        return None                                           # mixed traits: GenericInput (src/properties.jl:56-62)
+    nfac = sum(max(len(fs), 1) for _, fs in terms)
+    if not (1 <= len(terms) <= _ffi.COMPOSITE_MAX_TERMS) or nfac > _ffi.COMPOSITE_MAX_FACTORS:
+        return None
+    comp = _ffi.covgram_kernel_composite()
+    comp.head.family = _ffi.COMPOSITE
+    comp.head.trait = traits.pop()
+    comp.head.p, comp.head.power = 0, 1
+    comp.head.param, comp.head.lengthscale, comp.head.scale = 0.0, 1.0, 1.0
+    comp.nterms = len(terms)
+    fi = 0
+    for t, (c, fs) in enumerate(terms):
+        if not fs:
+            comp.nfactors[t] = 1
+            comp.factors[fi].family = _ffi.CONSTANT
+            comp.factors[fi].trait = comp.head.trait
+            comp.factors[fi].power, comp.factors[fi].lengthscale, comp.factors[fi].scale = 1, 1.0, c
+            fi += 1
+            continue
+        comp.nfactors[t] = len(fs)
+        for q, f in enumerate(fs):
+            _copy_spec(comp.factors[fi], f)
+            comp.factors[fi].scale = c if q == 0 else 1.0     # the term's coefficient rides on its first factor
+            fi += 1
+    return comp
+
+
+def require_device_spec(k):
     spec = device_spec(k)
     if spec is None:
         raise _ffi.UnsupportedKernel(

@@ -44,27 +44,29 @@ int pad_dim(int d) {
     int launch_dense_wide_family_##n(const DenseArgs&, int dtype); \
     int launch_grad_family_##n(const GradArgs&, int dtype);        \
     int launch_grad_wide_family_##n(const GradWideArgs&, int dtype);
-CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
+CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(9) CG_DECL(10)
 #undef CG_DECL
 
 dense_launch_fn dense_launcher(int family) {
-    static const dense_launch_fn t[COVGRAM_NFAMILY] = {
+    static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_family_0, launch_dense_family_1, launch_dense_family_2, launch_dense_family_3, launch_dense_family_4,
-        launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8};
-    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+        launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8, launch_dense_family_9,
+        launch_dense_family_10};
+    return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 dense_launch_fn dense_wide_launcher(int family) {
-    static const dense_launch_fn t[COVGRAM_NFAMILY] = {
+    static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_wide_family_0, launch_dense_wide_family_1, launch_dense_wide_family_2, launch_dense_wide_family_3,
         launch_dense_wide_family_4, launch_dense_wide_family_5, launch_dense_wide_family_6, launch_dense_wide_family_7,
-        launch_dense_wide_family_8};
-    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+        launch_dense_wide_family_8, launch_dense_wide_family_9, launch_dense_wide_family_10};
+    return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 grad_launch_fn grad_launcher(int family) {
-    static const grad_launch_fn t[COVGRAM_NFAMILY] = {
+    static const grad_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_family_0, launch_grad_family_1, launch_grad_family_2, launch_grad_family_3, launch_grad_family_4,
-        launch_grad_family_5, launch_grad_family_6, launch_grad_family_7, launch_grad_family_8};
-    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+        launch_grad_family_5, launch_grad_family_6, launch_grad_family_7, launch_grad_family_8, launch_grad_family_9,
+        launch_grad_family_10};
+    return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -101,8 +103,51 @@ static void maternp_derivs0(int p, long double* d /* d[1..p] */) {
     }
 }
 
+static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out);
+
+// Composite: every factor keeps its own parameter block with gamma = 1/l (unfolded EQ); rows and columns stay unscaled.
+static int make_composite_kernel(const covgram_kernel_composite* c, int dtype, HostKernel* out) {
+    const covgram_kernel& h = c->head;
+    CG_REQUIRE(h.trait == COVGRAM_ISOTROPIC || h.trait == COVGRAM_DOTPRODUCT, COVGRAM_EINVAL, "composite: bad trait %d", h.trait);
+    CG_REQUIRE(h.power == 1 && h.lengthscale == 1.0, COVGRAM_EINVAL, "composite head must have power == 1 and lengthscale == 1");
+    CG_REQUIRE(c->nterms >= 1 && c->nterms <= EXPR_MAXT, COVGRAM_EUNSUPPORTED, "composite: %d terms (1..%d supported)", c->nterms, EXPR_MAXT);
+    memset(out, 0, sizeof(*out));
+    out->k = h;
+    out->kp.gamma = 1.0; out->kp.gamma2 = 1.0; out->kp.scale = h.scale; out->kp.power = 1;
+    out->eq_folded = false;
+    out->tu_family = (h.trait == COVGRAM_ISOTROPIC) ? FAM_EXPR_ISO : FAM_EXPR_DOT;
+    out->nterms = c->nterms;
+    int nf = 0;
+    for (int t = 0; t < c->nterms; ++t) {
+        CG_REQUIRE(c->nfactors[t] >= 1, COVGRAM_EINVAL, "composite: term %d has no factors", t);
+        out->nfac[t] = c->nfactors[t];
+        for (int f = 0; f < c->nfactors[t]; ++f, ++nf) {
+            CG_REQUIRE(nf < EXPR_MAXF, COVGRAM_EUNSUPPORTED, "composite: more than %d factors", EXPR_MAXF);
+            const covgram_kernel& fk = c->factors[nf];
+            if (fk.family == COVGRAM_CONSTANT) {
+                out->ffam[nf] = COVGRAM_CONSTANT;
+                out->fkp[nf].gamma = out->fkp[nf].gamma2 = 1.0; out->fkp[nf].scale = fk.scale; out->fkp[nf].power = 1;
+                continue;
+            }
+            CG_REQUIRE(fk.trait == h.trait, COVGRAM_EINVAL, "composite: factor %d has trait %d, head has %d (GenericInput is not a device path)",
+                       nf, fk.trait, h.trait);
+            HostKernel one;
+            int rc = make_simple_kernel(&fk, dtype, true, &one);
+            if (rc) return rc;
+            out->ffam[nf] = fk.family;
+            out->fkp[nf] = one.kp;
+        }
+    }
+    return COVGRAM_OK;
+}
+
 int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out) {
     CG_REQUIRE(k != nullptr, COVGRAM_EINVAL, "kernel is NULL");
+    if (k->family == COVGRAM_COMPOSITE) return make_composite_kernel((const covgram_kernel_composite*)k, dtype, out);
+    return make_simple_kernel(k, dtype, for_gradient, out);
+}
+
+static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out) {
     CG_REQUIRE(k->family >= 0 && k->family < COVGRAM_NFAMILY, COVGRAM_EUNSUPPORTED, "unknown kernel family %d", k->family);
     const bool dotfam = (k->family == COVGRAM_DOT || k->family == COVGRAM_EXPDOT);
     const int trait = dotfam ? COVGRAM_DOTPRODUCT : COVGRAM_ISOTROPIC;
@@ -113,6 +158,7 @@ int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, Host
     CG_REQUIRE(!(dotfam && k->lengthscale != 1.0), COVGRAM_EINVAL, "Lengthscale applies to isotropic kernels only");
     memset(out, 0, sizeof(*out));
     out->k = *k;
+    out->tu_family = k->family;
     KParams<double>& kp = out->kp;
     const double inv_l = 1.0 / k->lengthscale;
     kp.scale = k->scale;
@@ -192,11 +238,11 @@ int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out) {
 
 // dense instantiation: generic over family via a uniform switch (HBM-write-bound, n*m*sizeof(T) out)
 grad_wide_launch_fn grad_wide_launcher(int family) {
-    static const grad_wide_launch_fn t[COVGRAM_NFAMILY] = {
+    static const grad_wide_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_wide_family_0, launch_grad_wide_family_1, launch_grad_wide_family_2, launch_grad_wide_family_3,
         launch_grad_wide_family_4, launch_grad_wide_family_5, launch_grad_wide_family_6, launch_grad_wide_family_7,
-        launch_grad_wide_family_8};
-    return (family >= 0 && family < COVGRAM_NFAMILY) ? t[family] : nullptr;
+        launch_grad_wide_family_8, launch_grad_wide_family_9, launch_grad_wide_family_10};
+    return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 
 std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx) {
@@ -208,24 +254,6 @@ std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx) {
         ctx->timers.emplace_back(a, b);
     }
     return &ctx->timers[ctx->timers_used++];
-}
-
-template <typename T>
-__device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
-    T v;
-    switch (family) {
-        case COVGRAM_EQ: v = Phi<COVGRAM_EQ, T, false>::eval(s, kp); break;
-        case COVGRAM_EXP: v = Phi<COVGRAM_EXP, T, false>::eval(s, kp); break;
-        case COVGRAM_RQ: v = Phi<COVGRAM_RQ, T, false>::eval(s, kp); break;
-        case COVGRAM_GAMMAEXP: v = Phi<COVGRAM_GAMMAEXP, T, false>::eval(s, kp); break;
-        case COVGRAM_CAUCHY: v = Phi<COVGRAM_CAUCHY, T, false>::eval(s, kp); break;
-        case COVGRAM_IMQ: v = Phi<COVGRAM_IMQ, T, false>::eval(s, kp); break;
-        case COVGRAM_MATERNP: v = Phi<COVGRAM_MATERNP, T, false>::eval(s, kp); break;
-        case COVGRAM_DOT: v = s; break;
-        default: v = Phi<COVGRAM_EXPDOT, T, false>::eval(s, kp); break;
-    }
-    if (kp.power != 1) v = ipow(v, kp.power);
-    return v;
 }
 
 template <typename T>
@@ -246,6 +274,25 @@ __global__ __launch_bounds__(256) void matrix_kernel(const T* __restrict__ X, in
             else s = cg_fma(xi[l], yj[l], s);
         }
         out[i + j * ldo] = scale * phi_any<T>(family, s, kp);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void matrix_expr_kernel(const T* __restrict__ X, int64_t n, const T* __restrict__ Y, int64_t m,
+                                                          int32_t d, T* __restrict__ out, int64_t ldo, int iso, T scale,
+                                                          const ExprParams<T> ep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t jb = (int64_t)blockIdx.y * 16;
+    if (i >= n) return;
+    const T* xi = X + i * (int64_t)d;
+    for (int64_t j = jb; j < jb + 16 && j < m; ++j) {
+        const T* yj = Y + j * (int64_t)d;
+        T s = (T)0;
+        for (int l = 0; l < d; ++l) {
+            if (iso) { T r = xi[l] - yj[l]; s = cg_fma(r, r, s); }
+            else s = cg_fma(xi[l], yj[l], s);
+        }
+        out[i + j * ldo] = scale * (iso ? expr_value<T, true>(s, ep) : expr_value<T, false>(s, ep));
     }
 }
 
@@ -462,7 +509,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // d <= 64: x_i lives in registers (dense_mvm.hpp); beyond that the chunked kernel of dense_wide.hpp (any d)
     const bool wide = X->d > kDims[kNumDims - 1];
     const int D = wide ? ((X->d + 31) / 32) * 32 : pad_dim(X->d);
-    dense_launch_fn launch = wide ? dense_wide_launcher(k->family) : dense_launcher(k->family);
+    dense_launch_fn launch = wide ? dense_wide_launcher(hk.tu_family) : dense_launcher(hk.tu_family);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return COVGRAM_OK;
 
@@ -574,7 +621,15 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
     int64_t ld = ldo;
     if (loc == COVGRAM_HOST) { rc = ws_reserve(ctx, 3, (size_t)n * m * ts, &o); if (rc) return rc; ld = n; }
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)((m + 15) / 16));
-    if (dtype == COVGRAM_F32)
+    if (hk.tu_family >= COVGRAM_NFAMILY) {
+        const int iso = hk.tu_family == FAM_EXPR_ISO;
+        if (dtype == COVGRAM_F32)
+            hipLaunchKernelGGL(matrix_expr_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, (const float*)Y->dptr,
+                               m, X->d, (float*)o, ld, iso, (float)hk.kp.scale, make_params<FAM_EXPR_ISO, float>(hk));
+        else
+            hipLaunchKernelGGL(matrix_expr_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)X->dptr, n, (const double*)Y->dptr,
+                               m, X->d, (double*)o, ld, iso, hk.kp.scale, make_params<FAM_EXPR_ISO, double>(hk));
+    } else if (dtype == COVGRAM_F32)
         hipLaunchKernelGGL(matrix_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, (const float*)Y->dptr, m,
                            X->d, (float*)o, ld, k->family, (float)hk.kp.scale, cast_params<float>(hk.kp));
     else
@@ -588,12 +643,14 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
     return COVGRAM_OK;
 }
 
-int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
-                     void* y, double alpha, double beta, int32_t loc) {
+// vg = 0: GradientKernel blocks (d × d); vg = 1: ValueGradientKernel blocks ((d+1) × (d+1))
+static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                         void* y, double alpha, double beta, int32_t loc, int vg) {
     int rc = check_pair(ctx, X, Y);
     if (rc) return rc;
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
+    const int bd = d + vg;                                  // entries per block of a and y
     CG_REQUIRE((a != nullptr || m == 0) && (y != nullptr || n == 0), COVGRAM_EINVAL, "a or y is NULL");
     const int dtype = X->dtype;
     const size_t ts = dtype_size(dtype);
@@ -603,7 +660,9 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
     // lane-owned rows up to d = 64 (fp32) / 48 (fp64) (grad_mvm.hpp); wider rows take the two-kernel panel path (grad_wide.hpp)
     const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
-    grad_launch_fn launch = grad_launcher(k->family);
+    grad_launch_fn launch = grad_launcher(hk.tu_family);
+    CG_REQUIRE(!(vg && wide), COVGRAM_EUNSUPPORTED, "valgrad_mvm: d = %d exceeds the lane-per-row limit %d of this dtype", d,
+               dtype == COVGRAM_F64 ? 48 : 64);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return COVGRAM_OK;
 
@@ -611,26 +670,27 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
     void* y_dev = y;
     if (loc == COVGRAM_HOST) {
         void *sa, *sy;
-        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * d * ts, &sa); if (rc) return rc;
-        rc = ws_reserve(ctx, 3, (size_t)n * d * ts, &sy); if (rc) return rc;
-        if (m > 0) CG_CHECK_HIP(hipMemcpyAsync(sa, a, (size_t)m * d * ts, hipMemcpyHostToDevice, ctx->stream));
-        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(sy, y, (size_t)n * d * ts, hipMemcpyHostToDevice, ctx->stream));
+        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * bd * ts, &sa); if (rc) return rc;
+        rc = ws_reserve(ctx, 3, (size_t)n * bd * ts, &sy); if (rc) return rc;
+        if (m > 0) CG_CHECK_HIP(hipMemcpyAsync(sa, a, (size_t)m * bd * ts, hipMemcpyHostToDevice, ctx->stream));
+        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(sy, y, (size_t)n * bd * ts, hipMemcpyHostToDevice, ctx->stream));
         a_dev = sa; y_dev = sy;
     }
     const bool iso = (k->trait == COVGRAM_ISOTROPIC);
+    const double alpha0 = alpha * hk.kp.scale;              // value row of the value-gradient blocks
     // isotropic: b = -2 gamma^2 (psi' a + 2 psi'' r'(r'.a));  dot product: b = k1 a + k2 y (x.a)
     const double alpha_eff = alpha * hk.kp.scale * (iso ? -2.0 * hk.kp.gamma2 : 1.0);
     const int64_t rowblocks = (n + GRAD_THREADS - 1) / GRAD_THREADS;
     const int64_t npad = rowblocks * GRAD_THREADS;
-    const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)d);
+    const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)bd);
 
     if (m == 0) {
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_reduce_kernel<float>, rgrid, dim3(256), 0, ctx->stream, (const float*)nullptr,
-                               npad, D, 0, (float*)y_dev, n, d, 0.0f, (float)beta);
+                               npad, D, 0, (float*)y_dev, n, d, 0.0f, (float)beta, vg, 0.0f);
         else
             hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)nullptr,
-                               npad, D, 0, (double*)y_dev, n, d, 0.0, beta);
+                               npad, D, 0, (double*)y_dev, n, d, 0.0, beta, vg, 0.0);
     } else if (wide) {
         const int PKN = (dtype == COVGRAM_F32) ? 2 : 1;
         const int64_t BC = (int64_t)GJG * PKN;
@@ -638,7 +698,7 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         const int64_t npad64 = ((n + 63) / 64) * 64;
         int64_t panel = (((int64_t)256 << 20) / (npad64 * 2 * (int64_t)ts)) / BC * BC;   // coefficient slab <= 256 MB
         panel = std::max<int64_t>(BC, std::min<int64_t>(panel, mpad));
-        grad_wide_launch_fn wlaunch = grad_wide_launcher(k->family);
+        grad_wide_launch_fn wlaunch = grad_wide_launcher(hk.tu_family);
         for (int64_t col0 = 0; col0 < mpad; col0 += panel) {
             const int64_t pc = std::min<int64_t>(panel, mpad - col0);
             void *P, *C;
@@ -662,14 +722,16 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         }
     } else {
         void* P;
-        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * 2 * D * ts, &P); if (rc) return rc;   // + 1 prefetch-only record
+        // + 1 prefetch-only record; the value weights A0[0..m] of the value-gradient variant follow the stream
+        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * (2 * D + vg) * ts, &P); if (rc) return rc;
+        void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * 2 * D * ts) : nullptr;
         const int64_t pe = (m + 1) * (int64_t)D;
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma);
+                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma, vg, (float*)A0);
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma);
+                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.09 ms at CUs*32, profiles/r01_gradbench_sweep_v2.txt)
@@ -677,8 +739,11 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         GradArgs ga;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
+        ga.vg = vg; ga.A0 = A0; ga.alpha0 = alpha0;
+        ga.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma;
+        ga.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
         if (jsplit == 1) ga.out = y_dev;
-        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * D * npad * ts, &ga.out); if (rc) return rc; }
+        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * (D + vg) * npad * ts, &ga.out); if (rc) return rc; }
         auto* tm = timer_next(ctx);
         if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(ga, dtype); if (rc) return rc;
@@ -686,18 +751,28 @@ int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_po
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(grad_reduce_kernel<float>, rgrid, dim3(256), 0, ctx->stream, (const float*)ga.out,
-                                   npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta);
+                                   npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta, vg, (float)alpha0);
             else
                 hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)ga.out,
-                                   npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta);
+                                   npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta, vg, alpha0);
         }
     }
     CG_CHECK_HIP(hipGetLastError());
     if (loc == COVGRAM_HOST) {
-        CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)n * d * ts, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)n * bd * ts, hipMemcpyDeviceToHost, ctx->stream));
         CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     }
     return COVGRAM_OK;
+}
+
+int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                     void* y, double alpha, double beta, int32_t loc) {
+    return grad_mvm_impl(ctx, k, X, Y, a, y, alpha, beta, loc, 0);
+}
+
+int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                        void* y, double alpha, double beta, int32_t loc) {
+    return grad_mvm_impl(ctx, k, X, Y, a, y, alpha, beta, loc, 1);
 }
 
 // debugging / test hook: the double-precision parameter block the device kernels receive.

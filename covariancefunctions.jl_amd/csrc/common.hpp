@@ -59,10 +59,41 @@ struct KParams {
     int32_t power;  // Power exponent
 };
 
+// Composite kernels (covgram_kernel_composite: a sum of products of simple profiles that share one input trait,
+// src/algebra.jl:5-63, src/properties.jl:47-63) run through the same kernels under two extra template "families"
+// whose parameter block carries one KParams per factor; the profile is interpreted per pair with wave-uniform
+// (scalar) control flow.
+constexpr int FAM_EXPR_ISO = COVGRAM_NFAMILY;        // composite of isotropic factors:   phi(s), s = |x-y|^2
+constexpr int FAM_EXPR_DOT = COVGRAM_NFAMILY + 1;    // composite of dot-product factors: phi(s), s = x.y
+constexpr int NUM_TU_FAMILIES = COVGRAM_NFAMILY + 2; // translation units per kernel kind (Makefile FAMS)
+constexpr int EXPR_MAXT = COVGRAM_COMPOSITE_MAX_TERMS;
+constexpr int EXPR_MAXF = COVGRAM_COMPOSITE_MAX_FACTORS;
+
+template <typename T>
+struct ExprParams {
+    T gamma;                     // coordinate pre-scale of the rows: always 1 (every factor scales s by its own gamma2)
+    int32_t power;               // always 1 (Power is applied per factor)
+    int32_t nterms;
+    int32_t nfac[EXPR_MAXT];     // factors per term, stored consecutively in f[]
+    int32_t fam[EXPR_MAXF];      // covgram_family of each factor (COVGRAM_CONSTANT allowed)
+    KParams<T> f[EXPR_MAXF];     // per factor: gamma2 = 1/l^2, scale, power and the profile constants
+};
+
+template <int FAM, typename T> struct ParamsOf { using type = KParams<T>; };
+template <typename T> struct ParamsOf<FAM_EXPR_ISO, T> { using type = ExprParams<T>; };
+template <typename T> struct ParamsOf<FAM_EXPR_DOT, T> { using type = ExprParams<T>; };
+template <int FAM> constexpr bool fam_is_expr = (FAM == FAM_EXPR_ISO || FAM == FAM_EXPR_DOT);
+template <int FAM> constexpr bool fam_is_iso = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT && FAM != FAM_EXPR_DOT);
+
 struct HostKernel {
-    covgram_kernel k;
-    KParams<double> kp;   // un-typed master copy
+    covgram_kernel k;     // simple kernel, or the head of a composite
+    KParams<double> kp;   // un-typed master copy (composite: gamma = 1, scale = head scale)
     bool eq_folded;       // dense path folds -log2(e)/2 into gamma for EQ
+    int tu_family;        // launcher index: k.family, or FAM_EXPR_ISO / FAM_EXPR_DOT
+    int nterms;           // composite only
+    int nfac[EXPR_MAXT];
+    int ffam[EXPR_MAXF];
+    KParams<double> fkp[EXPR_MAXF];
 };
 
 // Validates `k` and fills the parameter block.  `for_gradient` keeps gamma = 1/l (no log2e fold).
@@ -76,6 +107,20 @@ inline KParams<T> cast_params(const KParams<double>& s) {
     for (int i = 0; i <= MAXP; ++i) { d.h0[i] = (T)s.h0[i]; d.h1[i] = (T)s.h1[i]; d.h2[i] = (T)s.h2[i]; d.ty[i] = (T)s.ty[i]; }
     d.p = s.p; d.power = s.power;
     return d;
+}
+
+template <int FAM, typename T>
+inline typename ParamsOf<FAM, T>::type make_params(const HostKernel& hk) {
+    if constexpr (fam_is_expr<FAM>) {
+        ExprParams<T> e;
+        memset(&e, 0, sizeof(e));
+        e.gamma = (T)1; e.power = 1; e.nterms = hk.nterms;
+        for (int t = 0; t < EXPR_MAXT; ++t) e.nfac[t] = hk.nfac[t];
+        for (int f = 0; f < EXPR_MAXF; ++f) { e.fam[f] = hk.ffam[f]; e.f[f] = cast_params<T>(hk.fkp[f]); }
+        return e;
+    } else {
+        return cast_params<T>(hk.kp);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -147,6 +192,9 @@ struct GradArgs {
     void* out; int64_t npad;               // partials [jsplit][npad][D] or final
     int32_t Dpad; int64_t jchunk; int32_t jsplit;
     int32_t keep_r;                        // -1 auto, 0 recompute r in sweep 2, 1 keep r in VGPRs
+    int32_t vg = 0;                        // 1: ValueGradientKernel blocks of d+1 (out slab rows D+1)
+    const void* A0 = nullptr;              // vg: value weights of the columns, m+1 entries
+    double alpha0 = 0, vg_c = 0, vg_b = 0; // vg: scale of the value row, c2 and b0 coupling coefficients
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;

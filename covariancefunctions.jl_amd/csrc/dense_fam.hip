@@ -4,7 +4,7 @@
 #include "dense_wide.hpp"
 
 #ifndef COVGRAM_FAM
-#error "compile with -DCOVGRAM_FAM=<0..8>"
+#error "compile with -DCOVGRAM_FAM=<0..10>"
 #endif
 
 namespace covgram {

@@ -64,7 +64,7 @@ struct DenseBody {
 
     // One column group (PK::N columns) against R rows.  p points at the (uniform) packed record of the group.
     static __device__ __forceinline__ void step(const V* __restrict__ p, const T (&x)[R][D], V (&acc)[R][NR],
-                                                const KParams<T>& kp) {
+                                                const typename ParamsOf<FAM, T>::type& kp) {
         V s[R];
 #pragma unroll
         for (int c0 = 0; c0 < D; c0 += DC) {
@@ -100,8 +100,8 @@ template <typename T, int FAM, int D, int NR, int R, bool POW>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     const T* __restrict__ X, int64_t n, int32_t d, const typename Pk<T>::V* __restrict__ P, int64_t m,
     T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs, int64_t jchunk, T alpha, T beta,
-    int32_t final_store, const KParams<T> kp) {
-    constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
+    int32_t final_store, const typename ParamsOf<FAM, T>::type kp) {
+    constexpr bool ISO = fam_is_iso<FAM>;
     using Body = DenseBody<T, FAM, D, NR, R, POW, ISO>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const T* __restrict__ Y
 // -------------------------------------------------------------------------------------------------
 template <typename T, int FAM, int D, int NR, int R, bool POW>
 static int launch_dense_one(const DenseArgs& a) {
-    const KParams<T> kp = cast_params<T>(a.hk->kp);
+    const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     const int64_t rows_per_wg = (int64_t)DENSE_THREADS * R;
     dim3 grid((unsigned)((a.n + rows_per_wg - 1) / rows_per_wg), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
@@ -244,7 +244,8 @@ template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {
     constexpr int R = RowsFor<D>::value;
     const bool pow = a.hk->k.power != 1;
-    if (pow) return launch_dense_one<T, FAM, D, NR, R, true>(a);
+    if constexpr (!fam_is_expr<FAM>)   // composites apply Power per factor
+        if (pow) return launch_dense_one<T, FAM, D, NR, R, true>(a);
     return launch_dense_one<T, FAM, D, NR, R, false>(a);
 }
 

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wide_kernel(const T* __re
                                                                    const typename Pk<T>::V* __restrict__ P, int64_t m,
                                                                    T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
                                                                    int64_t jchunk, T alpha, T beta, int32_t final_store,
-                                                                   const KParams<T> kp) {
-    constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
+                                                                   const typename ParamsOf<FAM, T>::type kp) {
+    constexpr bool ISO = fam_is_iso<FAM>;
     using PK = Pk<T>;
     using V = typename PK::V;
     constexpr int JG = wide_jg<T>();
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wide_kernel(const T* __re
 
 template <typename T, int FAM, int NR>
 static int launch_dense_wide_NR(const DenseArgs& a) {
-    const KParams<T> kp = cast_params<T>(a.hk->kp);
+    const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     dim3 grid((unsigned)((a.n + DENSE_THREADS - 1) / DENSE_THREADS), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
     const bool pow = a.hk->k.power != 1;
@@ -154,7 +154,8 @@ static int launch_dense_wide_NR(const DenseArgs& a) {
     hipLaunchKernelGGL((dense_wide_kernel<T, FAM, NR, POWV>), grid, dim3(DENSE_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, a.Dpad, \
                        (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha, (T)a.beta,        \
                        final_store, kp)
-    if (pow) CG_WIDE_LAUNCH(true); else CG_WIDE_LAUNCH(false);
+    if constexpr (fam_is_expr<FAM>) CG_WIDE_LAUNCH(false);
+    else { if (pow) CG_WIDE_LAUNCH(true); else CG_WIDE_LAUNCH(false); }
 #undef CG_WIDE_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_wide launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }

@@ -44,13 +44,20 @@ constexpr int grad_min_waves() {
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 
-template <typename T, int FAM, int D, bool KEEP_R, bool POW>
+// VG = true is the ValueGradientKernel Gramian (src/gradient.jl:400-474, block mul! :319-351): blocks of d+1 with a value
+// row/column.  In the pre-scaled coordinates (a_j = (a0, av), t = r'.av or x'.av):
+//   isotropic:    bv = -2 gamma^2 (psi' av + (2 psi'' t - psi' a0 / gamma) r'),   b0 = psi a0 - 2 gamma psi' t
+//   dot product:  bv =    gamma^2 (phi' av + (  phi'' t + phi' a0 / gamma) y'),   b0 = phi a0 +   gamma phi' t
+// i.e. one extra FMA on c2 and one scalar accumulator; a0 streams from A0 (one scalar load per column, prefetched with
+// the column's first chunk), vg_c = -+1/gamma, vg_b = -2 gamma | gamma, and b0 is scaled by alpha0 = alpha * scale.
+template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG>
 __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
                                                                 const T* __restrict__ P, const T* __restrict__ P2,
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
                                                                 int64_t jchunk, T alpha, T beta, int32_t final_store,
-                                                                const KParams<T> kp) {
-    constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
+                                                                const T* __restrict__ A0, T alpha0, T vg_c, T vg_b,
+                                                                const typename ParamsOf<FAM, T>::type kp) {
+    constexpr bool ISO = fam_is_iso<FAM>;
     constexpr int DC = (64 / (int)sizeof(T) < D) ? 64 / (int)sizeof(T) : D;   // dims per chunk (one 64-byte s_load per operand)
     constexpr int NC = (D + DC - 1) / DC;
     constexpr bool NEED_Y2 = !ISO || !KEEP_R;                                    // sweep 2 needs y_j again
@@ -104,6 +111,9 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
     const T* __restrict__ p = P + j0 * (2 * D);
     const T* __restrict__ q = P2 + j0 * (2 * D);
     Chunk cur = load_ya(p, 0);
+    const T* __restrict__ a0p = VG ? A0 + j0 : nullptr;
+    T a0 = (T)0, a0n = (T)0, b0 = (T)0;
+    if constexpr (VG) a0 = a0p[0];
     for (int jj = 0; jj < cnt; ++jj, p += 2 * D, q += 2 * D) {
         T s = (T)0, t = (T)0;
         T r[(ISO && KEEP_R) ? D : 1];
@@ -136,9 +146,16 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
-        T k1, k2;
-        phi_derivs<FAM, T, POW>(s, kp, k1, k2);
-        const T c2 = ISO ? (T)2 * k2 * t : k2 * t;
+        T k1, k2, c2;
+        if constexpr (VG) {
+            T v;
+            phi_jet<FAM, T, POW>(s, kp, v, k1, k2);
+            c2 = cg_fma(vg_c * k1, a0, ISO ? (T)2 * k2 * t : k2 * t);
+            b0 = cg_fma(v, a0, cg_fma(vg_b * k1, t, b0));
+        } else {
+            phi_derivs<FAM, T, POW>(s, kp, k1, k2);
+            c2 = ISO ? (T)2 * k2 * t : k2 * t;
+        }
         // ---- sweep 2: b += k1 a + c2 r   (or k1 a + c2 y) --------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -160,43 +177,56 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
                 if (e == skip) {
                     __builtin_amdgcn_sched_barrier(0);
                     nxt = (c + 1 < NC) ? load_a(q, c + 1) : load_ya(p + 2 * D, 0);   // last chunk: next column (stream is padded)
+                    if constexpr (VG) { if (c + 1 == NC) a0n = a0p[jj + 1]; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
+        if constexpr (VG) a0 = a0n;
     }
 
     if (!live) return;
+    constexpr int VGI = VG ? 1 : 0;
     if (final_store) {
-        T* yp = out + row * (int64_t)d;
+        T* yp = out + row * (int64_t)(d + VGI);
+        if constexpr (VG) {
+            T v = alpha0 * b0;
+            if (beta != (T)0) v = cg_fma(beta, yp[0], v);
+            yp[0] = v;
+        }
 #pragma unroll
         for (int l = 0; l < D; ++l) {
             if (l < d) {
                 T v = alpha * b[l];
-                if (beta != (T)0) v = cg_fma(beta, yp[l], v);
-                yp[l] = v;
+                if (beta != (T)0) v = cg_fma(beta, yp[VGI + l], v);
+                yp[VGI + l] = v;
             }
         }
     } else {
-        // partial slab [jsplit][D][npad]: lane-contiguous rows -> coalesced stores
-        T* op = out + (int64_t)blockIdx.y * D * npad + row;
+        // partial slab [jsplit][D (+1: the value row)][npad]: lane-contiguous rows -> coalesced stores
+        T* op = out + (int64_t)blockIdx.y * (D + VGI) * npad + row;
 #pragma unroll
         for (int l = 0; l < D; ++l) op[(int64_t)l * npad] = b[l];
+        if constexpr (VG) op[(int64_t)D * npad] = b0;
     }
 }
 
-// y[i*d + l] = alpha * sum_s partial[s][l][i] + beta * y ; one thread per (i, l) with i fastest: coalesced slab reads
+// y[i*d + l] = alpha * sum_s partial[s][l][i] + beta * y ; one thread per (i, l) with i fastest: coalesced slab reads.
+// vg = 1: blocks of d+1 — output entry 0 is the value row (slab row D, scaled by alpha0), entry 1+l the gradient row l.
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partial, int64_t npad, int32_t D, int32_t jsplit,
-                                                          T* __restrict__ y, int64_t n, int32_t d, T alpha, T beta) {
+                                                          T* __restrict__ y, int64_t n, int32_t d, T alpha, T beta, int32_t vg,
+                                                          T alpha0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = blockIdx.y;
-    if (i >= n || l >= d) return;
+    const int e = blockIdx.y;                                  // output entry within the block
+    if (i >= n || e >= d + vg) return;
+    const int l = vg ? (e == 0 ? D : e - 1) : e;               // slab row
+    if (vg && e == 0) alpha = alpha0;
     T s = (T)0;
-    for (int sp = 0; sp < jsplit; ++sp) s += partial[((int64_t)sp * D + l) * npad + i];
-    T* yp = y + i * (int64_t)d + l;
+    for (int sp = 0; sp < jsplit; ++sp) s += partial[((int64_t)sp * (D + vg) + l) * npad + i];
+    T* yp = y + i * (int64_t)(d + vg) + e;
     T v = alpha * s;
     if (beta != (T)0) v = cg_fma(beta, *yp, v);
     *yp = v;
@@ -204,9 +234,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
 
 // P[j][0..D) = gamma * Y[j][0..d), P[j][D..2D) = a[j*d + 0..d)   (zero padded); record m (one past the end) is zeroed:
 // the kernel's software pipeline prefetches it and never consumes it.
+// vg = 1: A holds blocks of d+1 (value weight first); the value weights go to A0[0..m] (A0[m] = 0, prefetch only).
 template <typename T>
 __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
-                                                        T* __restrict__ P, int32_t D, T gamma) {
+                                                        T* __restrict__ P, int32_t D, T gamma, int32_t vg, T* __restrict__ A0) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (m + 1) * (int64_t)D) return;
     const int64_t j = e / D;
@@ -214,12 +245,13 @@ __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y,
     T* p = P + j * (int64_t)(2 * D);
     const bool real = (j < m) && (l < d);
     p[l] = real ? Y[j * (int64_t)d + l] * gamma : (T)0;
-    p[D + l] = real ? A[j * (int64_t)d + l] : (T)0;
+    p[D + l] = real ? A[j * (int64_t)(d + vg) + vg + l] : (T)0;
+    if (vg && l == 0) A0[j] = (j < m) ? A[j * (int64_t)(d + 1)] : (T)0;
 }
 
 template <typename T, int FAM, int D>
 static int launch_grad_one(const GradArgs& a) {
-    const KParams<T> kp = cast_params<T>(a.hk->kp);
+    const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     dim3 grid((unsigned)((a.n + GRAD_THREADS - 1) / GRAD_THREADS), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
     // keep r = x - y in registers (4 flops per dim and block) while 3 d-vectors of state leave >= 2 waves per SIMD,
@@ -231,18 +263,24 @@ static int launch_grad_one(const GradArgs& a) {
     bool keep = CAN_KEEP && (W3 <= 100);
     if (a.keep_r == 0) keep = false;
     if (a.keep_r == 1) keep = CAN_KEEP;
-    const bool pow = a.hk->k.power != 1;
-#define CG_GRAD_LAUNCH(KEEPV, POWV)                                                                                              \
-    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, \
-                       (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store, kp)
+    const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
+    constexpr bool POWT = !fam_is_expr<FAM>;   // composites apply Power per factor: no POW = true instantiation
+#define CG_GRAD_LAUNCH(KEEPV, POWV, VGV)                                                                                                \
+    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,  \
+                       (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,             \
+                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, kp)
     bool done = false;
+    if (a.vg) {   // the value-gradient variant always recomputes r (one instantiation per D)
+        if (pow) CG_GRAD_LAUNCH(false, POWT, true); else CG_GRAD_LAUNCH(false, false, true);
+        done = true;
+    }
     if constexpr (CAN_KEEP) {
-        if (keep) {
-            if (pow) CG_GRAD_LAUNCH(true, true); else CG_GRAD_LAUNCH(true, false);
+        if (!done && keep) {
+            if (pow) CG_GRAD_LAUNCH(true, POWT, false); else CG_GRAD_LAUNCH(true, false, false);
             done = true;
         }
     }
-    if (!done) { if (pow) CG_GRAD_LAUNCH(false, true); else CG_GRAD_LAUNCH(false, false); }
+    if (!done) { if (pow) CG_GRAD_LAUNCH(false, POWT, false); else CG_GRAD_LAUNCH(false, false, false); }
 #undef CG_GRAD_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }

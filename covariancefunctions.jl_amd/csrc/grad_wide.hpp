@@ -47,8 +47,8 @@ template <typename T, int FAM, bool POW>
 __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict__ X, int64_t n, int32_t d, int32_t dpad,
                                                             const typename Pk<T>::V* __restrict__ P,
                                                             typename Pk<T>::V* __restrict__ C1, typename Pk<T>::V* __restrict__ C2,
-                                                            int64_t npad, const KParams<T> kp) {
-    constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
+                                                            int64_t npad, const typename ParamsOf<FAM, T>::type kp) {
+    constexpr bool ISO = fam_is_iso<FAM>;
     using PK = Pk<T>;
     using V = typename PK::V;
     int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -182,12 +182,12 @@ struct GradWideArgs {
 template <typename T, int FAM>
 static int launch_grad_wide_T(const GradWideArgs& a) {
     using V = typename Pk<T>::V;
-    constexpr bool ISO = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT);
-    const KParams<T> kp = cast_params<T>(a.hk->kp);
+    constexpr bool ISO = fam_is_iso<FAM>;
+    const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     const unsigned rb = (unsigned)((a.n + 63) / 64);
-    const bool pow = a.hk->k.power != 1;
+    const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
     if (pow)
-        hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, true>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
+        hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, !fam_is_expr<FAM>>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
                            a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, kp);
     else
         hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, false>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,

@@ -102,8 +102,53 @@ struct Phi<COVGRAM_EXPDOT, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(s); }
 };
 
+// ---- runtime-family evaluation (dense instantiation, composite factors): a wave-uniform switch ------------------
+template <typename T>
+__device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
+    T v;
+    switch (family) {
+        case COVGRAM_EQ: v = Phi<COVGRAM_EQ, T, false>::eval(s, kp); break;
+        case COVGRAM_EXP: v = Phi<COVGRAM_EXP, T, false>::eval(s, kp); break;
+        case COVGRAM_RQ: v = Phi<COVGRAM_RQ, T, false>::eval(s, kp); break;
+        case COVGRAM_GAMMAEXP: v = Phi<COVGRAM_GAMMAEXP, T, false>::eval(s, kp); break;
+        case COVGRAM_CAUCHY: v = Phi<COVGRAM_CAUCHY, T, false>::eval(s, kp); break;
+        case COVGRAM_IMQ: v = Phi<COVGRAM_IMQ, T, false>::eval(s, kp); break;
+        case COVGRAM_MATERNP: v = Phi<COVGRAM_MATERNP, T, false>::eval(s, kp); break;
+        case COVGRAM_DOT: v = s; break;
+        case COVGRAM_EXPDOT: v = Phi<COVGRAM_EXPDOT, T, false>::eval(s, kp); break;
+        default: v = (T)1; break;                         // COVGRAM_CONSTANT: the factor is its scale
+    }
+    if (kp.power != 1) v = ipow(v, kp.power);
+    return v;
+}
+
+// composite value: sum over terms of the product of the factors; ISO factors see s / l_f^2
+template <typename T, bool ISO>
+__device__ __forceinline__ T expr_value(T s, const ExprParams<T>& ep) {
+    T total = (T)0;
+    int fi = 0;
+    for (int t = 0; t < ep.nterms; ++t) {
+        T prod = (T)1;
+        for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
+            const KParams<T>& q = ep.f[fi];
+            const T sf = ISO ? s * q.gamma2 : s;
+            prod *= q.scale * phi_any<T>(ep.fam[fi], sf, q);
+        }
+        total += prod;
+    }
+    return total;
+}
+template <typename T, bool F>
+struct Phi<FAM_EXPR_ISO, T, F> {
+    static __device__ __forceinline__ T eval(T s, const ExprParams<T>& ep) { return expr_value<T, true>(s, ep); }
+};
+template <typename T, bool F>
+struct Phi<FAM_EXPR_DOT, T, F> {
+    static __device__ __forceinline__ T eval(T s, const ExprParams<T>& ep) { return expr_value<T, false>(s, ep); }
+};
+
 template <int FAM, typename T, bool FOLDED, bool POW>
-__device__ __forceinline__ T phi_value(T s, const KParams<T>& kp) {
+__device__ __forceinline__ T phi_value(T s, const typename ParamsOf<FAM, T>::type& kp) {
     T v = Phi<FAM, T, FOLDED>::eval(s, kp);
     if constexpr (POW) v = ipow(v, kp.power);
     return v;   // Constant scale is folded into alpha by the host
@@ -201,21 +246,75 @@ struct DPhi<COVGRAM_EXPDOT, T> {
     }
 };
 
+// (phi^q, (phi^q)', (phi^q)'') from (phi, phi', phi'')
+template <typename T>
+__device__ __forceinline__ void power_jet(int q, T& v, T& d1, T& d2) {
+    T vq2 = (q >= 2) ? ((q == 2) ? (T)1 : ipow(v, q - 2)) : (T)0;
+    T vq1 = vq2 * v;
+    if (q < 2) vq1 = (T)1;
+    T n2 = (T)(q * (q - 1)) * vq2 * d1 * d1 + (T)q * vq1 * d2;
+    d1 = (T)q * vq1 * d1;
+    d2 = n2;
+    v = vq1 * v;
+}
+
+template <typename T>
+__device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+    switch (family) {
+        case COVGRAM_EQ: DPhi<COVGRAM_EQ, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_EXP: DPhi<COVGRAM_EXP, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_RQ: DPhi<COVGRAM_RQ, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_GAMMAEXP: DPhi<COVGRAM_GAMMAEXP, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_CAUCHY: DPhi<COVGRAM_CAUCHY, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_IMQ: DPhi<COVGRAM_IMQ, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_MATERNP: DPhi<COVGRAM_MATERNP, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_DOT: DPhi<COVGRAM_DOT, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_EXPDOT: DPhi<COVGRAM_EXPDOT, T>::eval(s, kp, v, d1, d2); break;
+        default: v = (T)1; d1 = (T)0; d2 = (T)0; break;   // COVGRAM_CONSTANT
+    }
+    if (kp.power != 1) power_jet(kp.power, v, d1, d2);
+}
+
+// composite jet w.r.t. the raw s: chain rule through each factor's 1/l^2, product rule within a term, sum over terms
+template <typename T, bool ISO>
+__device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) {
+    v = (T)0; d1 = (T)0; d2 = (T)0;
+    int fi = 0;
+    for (int t = 0; t < ep.nterms; ++t) {
+        T p0 = (T)1, p1 = (T)0, p2 = (T)0;
+        for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
+            const KParams<T>& q = ep.f[fi];
+            const T g2 = ISO ? q.gamma2 : (T)1;
+            T fv, f1, f2;
+            jet_any<T>(ep.fam[fi], s * g2, q, fv, f1, f2);
+            fv *= q.scale; f1 *= q.scale * g2; f2 *= q.scale * g2 * g2;
+            p2 = p2 * fv + (T)2 * p1 * f1 + p0 * f2;
+            p1 = p1 * fv + p0 * f1;
+            p0 = p0 * fv;
+        }
+        v += p0; d1 += p1; d2 += p2;
+    }
+}
+template <typename T>
+struct DPhi<FAM_EXPR_ISO, T> {
+    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, true>(s, ep, v, d1, d2); }
+};
+template <typename T>
+struct DPhi<FAM_EXPR_DOT, T> {
+    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, false>(s, ep, v, d1, d2); }
+};
+
 // POW = false compiles the Power chain rule away: the gradient kernel's software pipeline needs the derivative
 // evaluation to stay ONE basic block (a branch lets hipcc sink the prefetch loads past it, to their first use).
 template <int FAM, typename T, bool POW>
-__device__ __forceinline__ void phi_derivs(T s, const KParams<T>& kp, T& d1, T& d2) {
-    T v;
+__device__ __forceinline__ void phi_jet(T s, const typename ParamsOf<FAM, T>::type& kp, T& v, T& d1, T& d2) {
     DPhi<FAM, T>::eval(s, kp, v, d1, d2);
-    if constexpr (POW) {  // (phi^q)' , (phi^q)''
-        const int q = kp.power;
-        T vq2 = (q >= 2) ? ((q == 2) ? (T)1 : ipow(v, q - 2)) : (T)0;
-        T vq1 = vq2 * v;
-        if (q < 2) vq1 = (T)1;
-        T n2 = (T)(q * (q - 1)) * vq2 * d1 * d1 + (T)q * vq1 * d2;
-        d1 = (T)q * vq1 * d1;
-        d2 = n2;
-    }
+    if constexpr (POW) power_jet(kp.power, v, d1, d2);
+}
+template <int FAM, typename T, bool POW>
+__device__ __forceinline__ void phi_derivs(T s, const typename ParamsOf<FAM, T>::type& kp, T& d1, T& d2) {
+    T v;
+    phi_jet<FAM, T, POW>(s, kp, v, d1, d2);
 }
 
 }  // namespace covgram

@@ -13,6 +13,7 @@
  *   covgram_matrix         replaces  Base.Matrix(G::Gramian) / Matrix!                            src/gramian.jl:102-114
  *   covgram_grad_mvm       replaces  BlockFactorizations.blockmul!(y, G::Gramian, x, α, β)        src/gramian.jl:241-257
  *                          with the  GradientKernelElement mul! (isotropic / dot-product)         src/gradient.jl:86-92, 109-115
+ *   covgram_valgrad_mvm    the same  blockmul! with the ValueGradientKernel element                       src/gradient.jl:319-351, 400-474
  *   covgram_toeplitz_*     replaces  mul!(y, ::SymmetricToeplitz/Toeplitz/Circulant, a, α, β) of ToeplitzMatrices 0.7.1 as
  *                          constructed by gramian(k, x::StepRangeLen, y::StepRangeLen)            src/gramian.jl:167-189
  *   covgram_kron_mvm       replaces  mul!(y, ::KroneckerProduct, a) of KroneckerProducts 1.1.1 as constructed at
@@ -20,6 +21,7 @@
  *   covgram_lowrank_mvm    replaces  mul!(y, L::LazyMatrixProduct(U, V'), a, α, β)                src/lazy_linear_algebra.jl:78-85
  *                          as built by gramian(k::FiniteBasis, x, y)                              src/mercer.jl:61-70
  *   covgram_kernel         encodes   the kernel value k together with input_trait(k)              src/properties.jl:31-45
+ *   covgram_kernel_composite encodes Sum / Product / Power of same-trait kernels                  src/algebra.jl:5-63, src/properties.jl:47-63
  *
  * Conventions (same as the reference's at that boundary):
  *   - the caller owns every buffer it passes; handles own only what the library allocated;
@@ -64,7 +66,10 @@ typedef enum covgram_family {
     COVGRAM_MATERNP = 6,  /* Matern nu = p + 1/2, 0 <= p <= 8  src/stationary.jl:117-158 */
     COVGRAM_DOT = 7,      /* s                                 src/mercer.jl:6-9         */
     COVGRAM_EXPDOT = 8,   /* exp(s)                            src/mercer.jl:19-22       */
-    COVGRAM_NFAMILY = 9
+    COVGRAM_NFAMILY = 9,
+    /* only inside / as the head of a covgram_kernel_composite: */
+    COVGRAM_CONSTANT = 100, /* factor: the constant `scale`            src/stationary.jl:27-34   */
+    COVGRAM_COMPOSITE = 101 /* head of a covgram_kernel_composite      src/algebra.jl:5-63       */
 } covgram_family;
 
 /* input_trait(k), src/properties.jl:31-45.  Only the two traits with a device path are encoded;
@@ -85,6 +90,22 @@ typedef struct covgram_kernel {
     double lengthscale; /* Lengthscale(k, l): s <- s/l^2, isotropic only (src/transformation.jl:6-19); 1 = none */
     double scale;       /* Constant(c) * k (src/algebra.jl:23-25); 1 = none */
 } covgram_kernel;
+
+/* Sum / Product / Power of kernels that share one input trait (src/algebra.jl:5-63; the common trait is what
+ * src/properties.jl:47-63 computes, Constant arguments do not count):
+ *     k(x, y) = head.scale * sum_{t < nterms}  prod_{f < nfactors[t]}  factor(x, y)
+ * with the factors of term 0 first in `factors`, then term 1's, ...  Each factor is a simple covgram_kernel with its
+ * own scale, lengthscale and power (or family COVGRAM_CONSTANT: just `scale`).  Every entry point that takes a
+ * `const covgram_kernel*` accepts `&composite.head` (head.family == COVGRAM_COMPOSITE, head.trait = the common trait,
+ * head.power == 1, head.lengthscale == 1). */
+#define COVGRAM_COMPOSITE_MAX_TERMS 4
+#define COVGRAM_COMPOSITE_MAX_FACTORS 6
+typedef struct covgram_kernel_composite {
+    covgram_kernel head;
+    int32_t nterms;
+    int32_t nfactors[COVGRAM_COMPOSITE_MAX_TERMS];
+    covgram_kernel factors[COVGRAM_COMPOSITE_MAX_FACTORS];
+} covgram_kernel_composite;
 
 typedef struct covgram_ctx covgram_ctx;           /* one device + one stream + workspace + rocFFT plans */
 typedef struct covgram_points covgram_points;     /* device-resident point set (stays resident across MVMs) */
@@ -130,6 +151,13 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
  * a (length m*d) and y (length n*d). */
 int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,
                      const covgram_points* Y, const void* a, void* y, double alpha, double beta, int32_t loc);
+
+/* Value-and-gradient Gramian (n(d+1) × m(d+1)), src/gradient.jl:400-474 with the block mul! of :319-351: block (i,j) is
+ *     [ k(x_i,y_j)        (d/dy k)^T      ]
+ *     [ d/dx k            d/dx d/dy^T k   ]
+ * flat point-major block vectors: entry i*(d+1) is the value component, i*(d+1)+1+l the l-th gradient component. */
+int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,
+                        const covgram_points* Y, const void* a, void* y, double alpha, double beta, int32_t loc);
 
 /* Toeplitz T[i,j] = vc[i-j] (i >= j), vr[j-i] (i < j); vr == NULL: symmetric (vr = vc, m = n).
  * circulant != 0: T[i,j] = vc[(i-j) mod n] (vr must be NULL).  The spectrum of the circulant embedding

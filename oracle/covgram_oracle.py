@@ -29,6 +29,7 @@ import numpy as np
 EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT = range(9)
 FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT"]
 ISOTROPIC, DOTPRODUCT = 1, 2
+CONSTANT = 100   # a factor of a Composite that is just its `scale` (stationary.jl:27-34)
 
 
 @dataclass(frozen=True)
@@ -46,6 +47,16 @@ class Kernel:
         # properties.jl:39-43: IsotropicKernel -> IsotropicInput, Dot/ExponentialDot -> DotProductInput,
         # Power inherits the trait of its base kernel.
         return DOTPRODUCT if self.family in (DOT, EXPDOT) else ISOTROPIC
+
+
+@dataclass(frozen=True)
+class Composite:
+    """Sum (algebra.jl:27-47) of Products (algebra.jl:5-25) of kernels that share one input trait
+    (properties.jl:47-63): k = scale * sum_t prod_f terms[t][f].  Power(k, p) (algebra.jl:50-63) of a single
+    profile is that factor's `power`.  Mirrors include/covgram.h :: covgram_kernel_composite."""
+    terms: tuple           # tuple of tuples of Kernel
+    trait: int = ISOTROPIC
+    scale: float = 1.0
 
 
 # ----------------------------------------------------------------------------------------
@@ -128,9 +139,19 @@ def _maternp(s, p: int, dtype):
     return y
 
 
-def profile(k: Kernel, s, dtype=np.float64):
+def profile(k, s, dtype=np.float64):
     """phi(s) for every family in scope.  `dtype` only selects eps(T) for the MaternP guard."""
     s = np.asarray(s, dtype=np.float64)
+    if isinstance(k, Composite):
+        total = np.zeros_like(s)
+        for term in k.terms:                         # Sum: algebra.jl:36 (sum(h->h(x,y), S.args))
+            prod = np.ones_like(s)
+            for f in term:                           # Product: algebra.jl:17 (prod(h->h(x,y), P.args))
+                prod = prod * profile(f, s, dtype)
+            total = total + prod
+        return k.scale * total
+    if k.family == CONSTANT:
+        return np.full_like(s, k.scale)              # stationary.jl:30-32
     if k.trait == ISOTROPIC and k.lengthscale != 1.0:
         s = s / (k.lengthscale ** 2)                 # transformation.jl:19
     f = k.family
@@ -176,6 +197,18 @@ def profile_derivatives(k: Kernel, s, dtype=np.float64):
     at the same r = sqrt((2p+1)s), and the polynomial (Taylor) branch below eps^(1/p) exactly as
     ForwardDiff differentiates stationary.jl:139-146."""
     s = np.asarray(s, dtype=np.float64)
+    if isinstance(k, Composite):
+        # what ForwardDiff does to algebra.jl:17,36: linearity over the Sum, Leibniz over each Product
+        V = np.zeros_like(s); D1 = np.zeros_like(s); D2 = np.zeros_like(s)
+        for term in k.terms:
+            p0 = np.ones_like(s); p1 = np.zeros_like(s); p2 = np.zeros_like(s)
+            for f in term:
+                fv, f1, f2 = profile_derivatives(f, s, dtype)
+                p0, p1, p2 = p0 * fv, p1 * fv + p0 * f1, p2 * fv + 2 * p1 * f1 + p0 * f2
+            V = V + p0; D1 = D1 + p1; D2 = D2 + p2
+        return k.scale * V, k.scale * D1, k.scale * D2
+    if k.family == CONSTANT:
+        return np.full_like(s, k.scale), np.zeros_like(s), np.zeros_like(s)
     inner = 1.0
     if k.trait == ISOTROPIC and k.lengthscale != 1.0:
         inner = 1.0 / (k.lengthscale ** 2)
@@ -341,6 +374,72 @@ def grad_matrix(k: Kernel, X, Y=None, dtype=np.float64):
         for j in range(m):
             M[i * d:(i + 1) * d, j * d:(j + 1) * d] = grad_block(k, X[i], Y[j], dtype)
     return M
+
+
+# ----------------------------------------------------------------------------------------
+# ValueGradientKernel (gradient.jl:400-474): blocks of d+1, value component first
+# ----------------------------------------------------------------------------------------
+def valgrad_block(k, x, y, dtype=np.float64):
+    """Dense (d+1)×(d+1) block, laid out as Matrix(::DerivativeKernelElement) does (gradient.jl:353-375):
+    [value_value, value_gradient'; gradient_value, gradient_gradient] with the closed forms of
+    value_gradient_kernel! (gradient.jl:441-463)."""
+    x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    d = x.shape[0]
+    M = np.zeros((d + 1, d + 1))
+    if k.trait == ISOTROPIC:
+        r = x - y
+        k0, k1, _ = profile_derivatives(k, float(r @ r), dtype)
+        M[0, 0] = k0
+        M[0, 1:] = -2 * k1 * r                                   # value_gradient (gradient.jl:459-460)
+        M[1:, 0] = 2 * k1 * r                                    # gradient_value (gradient.jl:461)
+    else:
+        k0, k1, _ = profile_derivatives(k, float(x @ y), dtype)
+        M[0, 0] = k0
+        M[0, 1:] = k1 * x                                        # gradient.jl:446
+        M[1:, 0] = k1 * y                                        # gradient.jl:447
+    M[1:, 1:] = grad_block(k, x, y, dtype)
+    return M
+
+
+def valgrad_matrix(k, X, Y=None, dtype=np.float64):
+    X = as_points(X); Y = as_points(X if Y is None else Y)
+    n, d = X.shape; m = Y.shape[0]
+    b = d + 1
+    M = np.zeros((n * b, m * b))
+    for i in range(n):
+        for j in range(m):
+            M[i * b:(i + 1) * b, j * b:(j + 1) * b] = valgrad_block(k, X[i], Y[j], dtype)
+    return M
+
+
+def valgrad_mul(yv, k, X, Y, a, alpha=1.0, beta=0.0, dtype=np.float64, chunk=256):
+    """blockmul! (gramian.jl:241-253) with the DerivativeKernelElement mul! (gradient.jl:319-351):
+    y[1] += α (vv a[1] + value_gradient·a_g);  y_g += α (gradient_value a[1] + gradient_gradient a_g)."""
+    X = as_points(X).astype(np.float64); Y = as_points(X if Y is None else Y).astype(np.float64)
+    n, d = X.shape; m = Y.shape[0]
+    A = np.asarray(a, dtype=np.float64).reshape(m, d + 1)
+    a0, Ag = A[:, 0], A[:, 1:]
+    out = np.zeros((n, d + 1))
+    if beta != 0:
+        out += beta * np.asarray(yv, dtype=np.float64).reshape(n, d + 1)
+    for i0 in range(0, n, chunk):
+        Xi = X[i0:i0 + chunk]
+        if k.trait == ISOTROPIC:
+            R = Xi[:, None, :] - Y[None, :, :]
+            s = np.einsum("ijl,ijl->ij", R, R)
+            k0, k1, k2 = profile_derivatives(k, s, dtype)
+            ra = np.einsum("ijl,jl->ij", R, Ag)
+            val = k0 @ a0 + (-2 * k1 * ra).sum(axis=1)
+            blk = (2 * k1 * a0[None, :])[:, :, None] * R - 2 * (k1[:, :, None] * Ag[None] + 2 * (k2 * ra)[:, :, None] * R)
+            out[i0:i0 + chunk, 0] += alpha * val
+            out[i0:i0 + chunk, 1:] += alpha * blk.sum(axis=1)
+        else:
+            s = Xi @ Y.T
+            k0, k1, k2 = profile_derivatives(k, s, dtype)
+            xa = Xi @ Ag.T
+            out[i0:i0 + chunk, 0] += alpha * (k0 @ a0 + (k1 * xa).sum(axis=1))
+            out[i0:i0 + chunk, 1:] += alpha * ((k1 * a0[None, :]) @ Y + k1 @ Ag + (k2 * xa) @ Y)
+    return out.reshape(-1)
 
 
 # ----------------------------------------------------------------------------------------

@@ -49,6 +49,10 @@ def kernel_fields(k):
 # ---- independent mpmath evaluation ------------------------------------------------------------
 def mp_phi(k, s):
     s = mp.mpf(s)
+    if isinstance(k, o.Composite):   # src/algebra.jl:17,36
+        return mp.mpf(k.scale) * sum(mp.fprod(mp_phi(f, s) for f in term) for term in k.terms)
+    if k.family == o.CONSTANT:
+        return mp.mpf(k.scale)
     if k.trait == o.ISOTROPIC:
         s = s / mp.mpf(k.lengthscale) ** 2
     f = k.family
@@ -112,6 +116,51 @@ def mp_grad_mul(k, X, Y, a, y0, alpha, beta):
                     acc[l] += mp.mpf(alpha) * (k1 * aj[l] + k2 * yj[l] * xa)
         out[i] = [float(v) for v in acc]
     return out.reshape(-1)
+
+
+def mp_valgrad_mul(k, X, Y, a, y0, alpha, beta):
+    """50-digit ValueGradientKernel MVM: value / gradient covariances of src/gradient.jl:441-463 with k0, k1, k2 by
+    numerical differentiation of the profile, blocks applied as src/gradient.jl:319-351."""
+    n, d = X.shape; m = Y.shape[0]
+    A = a.reshape(m, d + 1)
+    out = np.zeros((n, d + 1))
+    for i in range(n):
+        acc = [mp.mpf(beta) * mp.mpf(float(y0.reshape(n, d + 1)[i, l])) if beta != 0 else mp.mpf(0) for l in range(d + 1)]
+        xi = [mp.mpf(float(t)) for t in X[i]]
+        for j in range(m):
+            yj = [mp.mpf(float(t)) for t in Y[j]]; aj = [mp.mpf(float(t)) for t in A[j]]
+            a0, ag = aj[0], aj[1:]
+            s = mp_arg(k, X[i], Y[j])
+            k0 = mp_phi(k, s)
+            k1 = mp.diff(lambda t: mp_phi(k, t), s)
+            k2 = mp.diff(lambda t: mp_phi(k, t), s, 2)
+            al = mp.mpf(alpha)
+            if k.trait == o.ISOTROPIC:
+                r = [p_ - q_ for p_, q_ in zip(xi, yj)]
+                ra = sum(p_ * q_ for p_, q_ in zip(r, ag))
+                acc[0] += al * (k0 * a0 - 2 * k1 * ra)
+                for l in range(d):
+                    acc[1 + l] += al * (2 * k1 * r[l] * a0 - 2 * (k1 * ag[l] + 2 * k2 * r[l] * ra))
+            else:
+                xa = sum(p_ * q_ for p_, q_ in zip(xi, ag))
+                acc[0] += al * (k0 * a0 + k1 * xa)
+                for l in range(d):
+                    acc[1 + l] += al * (k1 * yj[l] * a0 + k1 * ag[l] + k2 * yj[l] * xa)
+        out[i] = [float(v) for v in acc]
+    return out.reshape(-1)
+
+
+# composite kernels (src/algebra.jl:5-63) and the kernels of the value-gradient fixtures
+COMPOSITES = {
+    # 1.7 * (1.3 MaternP(2; l=0.8) * RQ(1.5)^2 + EQ(l=2) + 0.5)
+    "iso_sum_of_products": o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=0.8, scale=1.3), o.Kernel(o.RQ, param=1.5, power=2)),
+                                        (o.Kernel(o.EQ, lengthscale=2.0),), (o.Kernel(o.CONSTANT, scale=0.5),)), o.ISOTROPIC, 1.7),
+    # EQ * Cauchy (test/algebra.jl-style product of two isotropic kernels)
+    "iso_product": o.Composite(((o.Kernel(o.EQ), o.Kernel(o.CAUCHY, lengthscale=1.5)),), o.ISOTROPIC, 1.0),
+    # Dot^2 + 0.3 * ExponentialDot  (test/gradient_algebra.jl:33-47 style sum of dot-product kernels)
+    "dot_sum": o.Composite(((o.Kernel(o.DOT, power=2),), (o.Kernel(o.EXPDOT, scale=0.3),)), o.DOTPRODUCT, 1.0),
+}
+VALGRAD_KERNELS = ["EQ", "RQ1", "MaternP2", "Dot3", "ExpDot", "EQ_l07"]
 
 
 def rel(a, b):
@@ -214,6 +263,35 @@ def main():
     xs = rng.standard_normal(3); v = rng.standard_normal(9)
     kr.update(B=B, xs=xs, v=v, sep_b=np.kron(o.matrix(KERNELS["EQ"], xs, xs), B) @ v)
     np.savez_compressed(os.path.join(OUT, "kronecker.npz"), **kr)
+
+    # ---- (5) composite kernels and ValueGradientKernel (mirrors test/gradient.jl:87-125, test/gradient_algebra.jl:13-47) ----
+    comp = {"names": np.array(list(COMPOSITES)), "valgrad_names": np.array(VALGRAD_KERNELS)}
+    for d in (1, 3, 8):
+        for (n, m) in ((4, 6), (65, 33)):
+            rng = np.random.default_rng(0xC0F * 5000 + 100 * d + n)
+            X = rng.standard_normal((n, d)) / math.sqrt(d); Y = rng.standard_normal((m, d)) / math.sqrt(d)
+            a = rng.standard_normal(m); y0 = rng.standard_normal(n)
+            ag = rng.standard_normal(m * d); yg0 = rng.standard_normal(n * d)
+            av = rng.standard_normal(m * (d + 1)); yv0 = rng.standard_normal(n * (d + 1))
+            alpha, beta = (float(v) for v in rng.standard_normal(2))
+            tag = f"d{d}_n{n}_m{m}"
+            for key, val in (("X", X), ("Y", Y), ("a", a), ("y0", y0), ("ag", ag), ("yg0", yg0), ("av", av), ("yv0", yv0),
+                             ("ab", np.array([alpha, beta]))):
+                comp[f"{tag}_{key}"] = val
+            kernels = dict(COMPOSITES); kernels.update({nm: KERNELS[nm] for nm in VALGRAD_KERNELS})
+            for name, k in kernels.items():
+                b = o.mul(y0, k, X, Y, a, alpha, beta)
+                bg = o.grad_mul(yg0, k, X, Y, ag, alpha, beta)
+                bv = o.valgrad_mul(yv0, k, X, Y, av, alpha, beta)
+                if n == 4 and d <= 3:
+                    for got, want in ((b, mp_mul(k, X, Y, a, y0, alpha, beta)), (bg, mp_grad_mul(k, X, Y, ag, yg0, alpha, beta)),
+                                      (bv, mp_valgrad_mul(k, X, Y, av, yv0, alpha, beta))):
+                        e = rel(got, want); worst = max(worst, e)
+                        assert e < 1e-12, (name, tag, e)
+                if name in COMPOSITES:
+                    comp[f"{tag}_{name}_b"], comp[f"{tag}_{name}_bg"] = b, bg
+                comp[f"{tag}_{name}_bv"] = bv
+    np.savez_compressed(os.path.join(OUT, "composite.npz"), **comp)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)}
     print("worst oracle-vs-mpmath relative error:", worst)

@@ -24,6 +24,27 @@ def cases(cg):
     ]
 
 
+# Sum / Product / Power of kernels sharing one input trait (src/algebra.jl:5-63): same definitions as
+# oracle/make_golden.py::COMPOSITES, written with the host algebra on one side and the oracle dataclass on the other
+def composite_cases(cg):
+    return [
+        ("iso_sum_of_products",
+         1.7 * (1.3 * cg.Lengthscale(cg.MaternP(2), 0.8) * cg.RQ(1.5) ** 2 + cg.Lengthscale(cg.EQ(), 2.0) + 0.5),
+         o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=0.8, scale=1.3), o.Kernel(o.RQ, param=1.5, power=2)),
+                      (o.Kernel(o.EQ, lengthscale=2.0),), (o.Kernel(o.CONSTANT, scale=0.5),)), o.ISOTROPIC, 1.7)),
+        ("iso_product", cg.EQ() * cg.Lengthscale(cg.Cauchy(), 1.5),
+         o.Composite(((o.Kernel(o.EQ), o.Kernel(o.CAUCHY, lengthscale=1.5)),), o.ISOTROPIC, 1.0)),
+        ("dot_sum", cg.Dot() ** 2 + 0.3 * cg.ExponentialDot(),
+         o.Composite(((o.Kernel(o.DOT, power=2),), (o.Kernel(o.EXPDOT, scale=0.3),)), o.DOTPRODUCT, 1.0)),
+    ]
+
+
+def valgrad_cases(cg):
+    keep = {"EQ", "RQ(1.0)", "MaternP(2)", "Dot()^3", "ExponentialDot", "Lengthscale(EQ,0.7)", "Cauchy", "EQ^2",
+            "2.5*Lengthscale(MaternP(2),1.3)"}
+    return [c for c in cases(cg) if c[0] in keep] + composite_cases(cg)
+
+
 # kernels whose phi', phi'' are finite at s = 0 (gradient Gramian well defined on the diagonal)
 def grad_cases(cg):
     keep = {"EQ", "RQ(1.0)", "RQ(0.37)", "Cauchy", "IMQ(0.8)", "MaternP(2)", "MaternP(3)", "Lengthscale(EQ,0.7)",

@@ -382,3 +382,111 @@ def test_gradient_wide_dimensions(cg, oracle, dtype, d):
         rows = np.sort(rng.choice(nb, 8, replace=False))
         ref = oracle.grad_mul(None, oracle.Kernel(oracle.MATERNP, p=2), Xb[rows], Xb, ab, dtype=npdt(dtype)).reshape(8, db)
         assert relerr(got[rows], ref) <= tol
+
+
+# ---- (f)-2: composite kernels and ValueGradientKernel -------------------------------------------------------------------
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [1, 3, 8, 70])
+def test_composite_kernels_dense_gradient_matrix(cg, oracle, dtype, d):
+    """Sum / Product / Power of same-trait kernels (src/algebra.jl:5-63) through every entry point: mul! (vector, 3 RHS),
+    Matrix(G), the GradientKernel Gramian; d = 70 takes the wide kernels."""
+    tol = TOL[dtype]
+    gtol = 3e-5 if dtype == torch.float32 else 1e-12
+    rng = np.random.default_rng(0xC0F + 50 + d)
+    n, m = 131, 77
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype)); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+    a = rng.standard_normal(m).astype(npdt(dtype)); A3 = rng.standard_normal((m, 3)).astype(npdt(dtype)); y0 = rng.standard_normal(n).astype(npdt(dtype))
+    ag = rng.standard_normal(m * d).astype(npdt(dtype)); yg0 = rng.standard_normal(n * d).astype(npdt(dtype))
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    for name, k, ko in kernel_cases.composite_cases(cg):
+        assert isinstance(cg.device_spec(k), cg._ffi.covgram_kernel_composite)
+        G = cg.gramian(k, Xd, Yd)
+        yd = torch.from_numpy(y0.copy()).cuda()
+        cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
+        assert relerr(yd.cpu().numpy(), oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, npdt(dtype))) <= tol, (name, d)
+        assert relerr((G @ torch.from_numpy(A3).cuda()).cpu().numpy(), oracle.mul(None, ko, X, Y, A3, dtype=npdt(dtype))) <= tol, (name, d)
+        assert relerr(G.to_dense().cpu().numpy(), oracle.matrix(ko, X, Y, npdt(dtype))) <= tol, (name, d)
+        K = cg.gramian(cg.GradientKernel(k), Xd, Yd)
+        bd = torch.from_numpy(yg0.copy()).cuda()
+        cg.mul_(bd, K, torch.from_numpy(ag).cuda(), 0.6, -0.4)
+        ref = oracle.grad_mul(yg0, ko, X, Y, ag, 0.6, -0.4, npdt(dtype))
+        assert relerr(bd.cpu().numpy(), ref) <= gtol, (name, d, relerr(bd.cpu().numpy(), ref))
+
+
+def test_composite_golden_and_toeplitz(cg, oracle):
+    g = np.load(f"{GOLD}/composite.npz")
+    for d in (1, 3, 8):
+        for (n, m) in ((4, 6), (65, 33)):
+            tag = f"d{d}_n{n}_m{m}"
+            X, Y, a, y0, ag, yg0 = (g[f"{tag}_{s}"] for s in ("X", "Y", "a", "y0", "ag", "yg0"))
+            alpha, beta = g[f"{tag}_ab"]
+            Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+            for name, k, ko in kernel_cases.composite_cases(cg):
+                yd = torch.from_numpy(y0.copy()).cuda()
+                cg.mul_(yd, cg.gramian(k, Xd, Yd), torch.from_numpy(a).cuda(), alpha, beta)
+                assert relerr(yd.cpu().numpy(), g[f"{tag}_{name}_b"]) <= 1e-12, (name, tag)
+                bd = torch.from_numpy(yg0.copy()).cuda()
+                cg.mul_(bd, cg.gramian(cg.GradientKernel(k), Xd, Yd), torch.from_numpy(ag).cuda(), alpha, beta)
+                assert relerr(bd.cpu().numpy(), g[f"{tag}_{name}_bg"]) <= 1e-12, (name, tag)
+    # a composite isotropic kernel on a range is still a SymmetricToeplitz (src/gramian.jl:167-176)
+    name, k, ko = kernel_cases.composite_cases(cg)[0]
+    n = 2000
+    T = cg.gramian(k, cg.srange(-1, 1, n))
+    assert isinstance(T, cg.SymmetricToeplitz)
+    a = np.random.default_rng(5).standard_normal(n)
+    x = oracle.srange_points(oracle.srange(-1, 1, n))
+    assert relerr((T @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.mul(None, ko, x, x, a)) <= 1e-10
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [1, 3, 8, 32])
+def test_value_gradient_kernel(cg, oracle, dtype, d):
+    """ValueGradientKernel Gramian (src/gradient.jl:400-474), blocks of d+1 — test/gradient.jl:87-125: mul! with α, β
+    against the explicit block matrix, symmetric and rectangular, single-chunk and split-J launches."""
+    tol = 3e-5 if dtype == torch.float32 else 1e-12
+    for (n, m) in ((2, 2), (33, 33), (300, 700)):
+        rng = np.random.default_rng(1000 * d + n)
+        X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype))
+        Y = X if n == m and n < 100 else (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+        a = rng.standard_normal(m * (d + 1)).astype(npdt(dtype)); b0 = rng.standard_normal(n * (d + 1)).astype(npdt(dtype))
+        alpha, beta = rng.standard_normal(2)
+        Xd = torch.from_numpy(X).cuda(); Yd = Xd if Y is X else torch.from_numpy(Y).cuda()
+        for name, k, ko in kernel_cases.valgrad_cases(cg):
+            K = cg.gramian(cg.ValueGradientKernel(k), Xd, None if Y is X else Yd)
+            assert isinstance(K, cg.BlockGramian) and tuple(K.shape) == (n * (d + 1), m * (d + 1))
+            ref = oracle.valgrad_mul(b0, ko, X, Y, a, alpha, beta, npdt(dtype))
+            bd = torch.from_numpy(b0.copy()).cuda()
+            cg.mul_(bd, K, torch.from_numpy(a).cuda(), alpha, beta)
+            assert relerr(bd.cpu().numpy(), ref) <= tol, (name, d, n, relerr(bd.cpu().numpy(), ref))
+            if n == 2 and d <= 3:
+                MK = oracle.valgrad_matrix(ko, X, Y, npdt(dtype))
+                assert relerr((K @ torch.from_numpy(a).cuda()).cpu().numpy(), MK @ a.astype(np.float64)) <= 10 * tol
+                assert relerr(K.to_dense().cpu().numpy(), MK) <= 10 * tol
+            # beta == 0 ignores NaN in the output
+            yn = torch.full((n * (d + 1),), float("nan"), dtype=dtype, device="cuda")
+            cg.mul_(yn, K, torch.from_numpy(a).cuda(), 1.0, 0.0)
+            assert relerr(yn.cpu().numpy(), oracle.valgrad_mul(None, ko, X, Y, a, 1.0, 0.0, npdt(dtype))) <= tol, (name, d, n)
+
+
+def test_value_gradient_golden_and_limits(cg, oracle):
+    g = np.load(f"{GOLD}/composite.npz")
+    byname = {c[0]: c for c in kernel_cases.valgrad_cases(cg)}
+    alias = {"EQ": "EQ", "RQ1": "RQ(1.0)", "MaternP2": "MaternP(2)", "Dot3": "Dot()^3", "ExpDot": "ExponentialDot", "EQ_l07": "Lengthscale(EQ,0.7)"}
+    for d in (1, 3, 8):
+        for (n, m) in ((4, 6), (65, 33)):
+            tag = f"d{d}_n{n}_m{m}"
+            X, Y, av, yv0 = (g[f"{tag}_{s}"] for s in ("X", "Y", "av", "yv0"))
+            alpha, beta = g[f"{tag}_ab"]
+            Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+            for gname in list(g["valgrad_names"]) + list(g["names"]):
+                k = byname[alias.get(str(gname), str(gname))][1]
+                bd = torch.from_numpy(yv0.copy()).cuda()
+                cg.mul_(bd, cg.gramian(cg.ValueGradientKernel(k), Xd, Yd), torch.from_numpy(av).cuda(), alpha, beta)
+                assert relerr(bd.cpu().numpy(), g[f"{tag}_{gname}_bv"]) <= 1e-12, (gname, tag)
+    # beyond the lane-per-row limit there is no value-gradient kernel yet: loud, not silent
+    Xw = torch.randn(10, 70, dtype=torch.float64, device="cuda")
+    with pytest.raises(cg.UnsupportedKernel):
+        cg.gramian(cg.ValueGradientKernel(cg.EQ()), Xw) @ torch.randn(10 * 71, dtype=torch.float64, device="cuda")

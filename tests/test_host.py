@@ -28,8 +28,22 @@ def test_library_exports_every_header_symbol(cg):
     assert os.path.exists(cg._ffi.LIB_PATH)
 
 
-def test_struct_layout_matches_header(cg):
+def test_struct_layout_matches_header(cg, tmp_path):
     assert C.sizeof(cg._ffi.covgram_kernel) == 4 * 4 + 3 * 8
+    # the C compiler's view of both structs (sizes, offsets, limits) against the ctypes mirror
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "covgram.h"\nint main(void){printf("%zu %zu %zu %zu %zu %d %d %d %d\\n",'
+                   'sizeof(covgram_kernel), sizeof(covgram_kernel_composite), offsetof(covgram_kernel_composite, nterms),'
+                   'offsetof(covgram_kernel_composite, nfactors), offsetof(covgram_kernel_composite, factors),'
+                   'COVGRAM_COMPOSITE_MAX_TERMS, COVGRAM_COMPOSITE_MAX_FACTORS, (int)COVGRAM_CONSTANT, (int)COVGRAM_COMPOSITE);return 0;}\n')
+    exe = tmp_path / "layout"
+    import subprocess
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    f = cg._ffi
+    comp = f.covgram_kernel_composite
+    assert got == [C.sizeof(f.covgram_kernel), C.sizeof(comp), comp.nterms.offset, comp.nfactors.offset, comp.factors.offset,
+                   f.COMPOSITE_MAX_TERMS, f.COMPOSITE_MAX_FACTORS, f.CONSTANT, f.COMPOSITE]
 
 
 def test_kernel_parameter_tables_match_exact_rationals(cg):
@@ -95,7 +109,7 @@ def test_kernel_lowering_and_folding(cg):
     assert s.power == 3 and s.scale == 8.0
     s = cg.device_spec(cg.Lengthscale(cg.Lengthscale(cg.EQ(), 2.0), 3.0))
     assert s.lengthscale == 6.0
-    assert cg.device_spec(cg.EQ() + cg.RQ(1.0)) is None and cg.device_spec(cg.Matern(2.7)) is None
+    assert cg.device_spec(cg.Matern(2.7)) is None
     assert cg.device_spec(cg.RQ(0.3)).param == 0.3 and cg.device_spec(cg.InverseMultiQuadratic(1.5)).param == 1.5
     with pytest.raises(cg.DomainError):
         cg.RQ(-1.0)
@@ -105,6 +119,40 @@ def test_kernel_lowering_and_folding(cg):
         cg.Lengthscale(cg.EQ(), 0.0)
     with pytest.raises(cg.DomainError):
         cg.GammaExp(2.5)
+
+
+def test_composite_lowering(cg):
+    """Sum / Product / Power of same-trait kernels lower to a sum of products (src/algebra.jl:5-63); mixed traits and
+    profiles without a device form stay GenericInput (src/properties.jl:47-63) -> None."""
+    f = cg._ffi
+    c = cg.device_spec(cg.EQ() + cg.RQ(1.0))
+    assert isinstance(c, f.covgram_kernel_composite) and c.head.family == f.COMPOSITE and c.head.trait == f.ISOTROPIC
+    assert c.nterms == 2 and list(c.nfactors)[:2] == [1, 1] and [c.factors[i].family for i in range(2)] == [f.EQ, f.RQ]
+    # product distributes over the sum; the term coefficient rides on the first factor of each term
+    c = cg.device_spec(2.0 * (cg.EQ() + 3.0 * cg.Lengthscale(cg.RQ(1.0), 0.5)) * cg.Cauchy())
+    assert c.nterms == 2 and list(c.nfactors)[:2] == [2, 2]
+    assert [(c.factors[i].family, c.factors[i].scale) for i in range(4)] == [(f.EQ, 2.0), (f.CAUCHY, 1.0), (f.RQ, 6.0), (f.CAUCHY, 1.0)]
+    assert c.factors[2].lengthscale == 0.5
+    # Power of a composite multiplies out; constants merge into one CONSTANT term
+    c = cg.device_spec((cg.EQ() + 1.0) ** 2)
+    assert c.nterms == 3 and sorted(c.factors[i].family for i in range(4)) == [f.EQ, f.EQ, f.EQ, f.CONSTANT]
+    assert list(c.nfactors)[:3] == [2, 1, 1] and [c.factors[i].scale for i in range(4)] == [1.0, 1.0, 2.0, 1.0]   # k² + 2k + 1
+    c = cg.device_spec(cg.Dot() ** 2 + 0.3 * cg.ExponentialDot())
+    assert c.head.trait == f.DOTPRODUCT and c.factors[0].power == 2 and c.factors[1].scale == 0.3
+    assert isinstance(cg.input_trait(cg.EQ() * cg.RQ(1.0)), cg.IsotropicInput)
+    # outside the device set
+    assert cg.device_spec(cg.EQ() + cg.Dot()) is None and isinstance(cg.input_trait(cg.EQ() + cg.Dot()), cg.GenericInput)
+    assert cg.device_spec(cg.EQ() + cg.Matern(2.7)) is None
+    five = cg.EQ() + cg.RQ(1.0) + cg.Cauchy() + cg.Exp() + cg.MaternP(1)
+    assert cg.device_spec(five) is None                                # more than COVGRAM_COMPOSITE_MAX_TERMS
+    seven = cg.EQ() * cg.RQ(1.0) * cg.Cauchy() * cg.Exp() * cg.MaternP(1) * cg.MaternP(2) * cg.MaternP(3)
+    assert cg.device_spec(seven) is None                               # more than COVGRAM_COMPOSITE_MAX_FACTORS
+    # host evaluation of the algebra agrees with the oracle's composite
+    import kernel_cases
+    rng = np.random.default_rng(11)
+    for name, k, ko in kernel_cases.composite_cases(cg):
+        x, y = rng.standard_normal(3), rng.standard_normal(3)
+        assert np.isclose(k(x, y), float(o.matrix(ko, x[None], y[None])[0, 0]), rtol=1e-13), name
 
 
 def test_host_kernel_call_matches_oracle_profiles(cg):

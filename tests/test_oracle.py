@@ -151,6 +151,54 @@ def test_relations_test_gradient_jl():
     assert np.isclose(a @ o.grad_mul(None, k, X, X, b), b @ o.grad_mul(None, k, X, X, a), rtol=1e-12)
 
 
+def test_golden_composite_and_value_gradient():
+    """Composite (Sum/Product/Power) kernels and ValueGradientKernel blocks: fixtures (mpmath-checked at generation),
+    the block MVM against the explicit block matrix (test/gradient.jl:87-125 relations), and every block entry against
+    numerical differentiation of k(x, y) itself."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import make_golden as mg
+    g = np.load(f"{GOLD}/composite.npz")
+    kernels = dict(mg.COMPOSITES); kernels.update({nm: mg.KERNELS[nm] for nm in mg.VALGRAD_KERNELS})
+    for d in (1, 3, 8):
+        for (n, m) in ((4, 6), (65, 33)):
+            tag = f"d{d}_n{n}_m{m}"
+            X, Y, a, y0, ag, yg0, av, yv0 = (g[f"{tag}_{s}"] for s in ("X", "Y", "a", "y0", "ag", "yg0", "av", "yv0"))
+            alpha, beta = g[f"{tag}_ab"]
+            for name, k in kernels.items():
+                assert rel(o.valgrad_mul(yv0, k, X, Y, av, alpha, beta), g[f"{tag}_{name}_bv"]) < 1e-14
+                if name in mg.COMPOSITES:
+                    assert rel(o.mul(y0, k, X, Y, a, alpha, beta), g[f"{tag}_{name}_b"]) < 1e-14
+                    assert rel(o.grad_mul(yg0, k, X, Y, ag, alpha, beta), g[f"{tag}_{name}_bg"]) < 1e-14
+                if n == 4:
+                    M = o.valgrad_matrix(k, X, Y)
+                    assert rel(alpha * (M @ av) + beta * yv0, g[f"{tag}_{name}_bv"]) < 1e-13
+                    # the gradient-gradient sub-blocks are the GradientKernel Gramian
+                    b = d + 1
+                    idx = np.array([i * b + 1 + l for i in range(n) for l in range(d)]); jdx = np.array([j * b + 1 + l for j in range(m) for l in range(d)])
+                    assert rel(M[np.ix_(idx, jdx)], o.grad_matrix(k, X, Y)) < 1e-15
+    # entries of a block by central differences of the kernel function (independent of every closed form)
+    rng = np.random.default_rng(3)
+    h = 1e-5
+    for name, k in kernels.items():
+        x, y = rng.standard_normal(3) * 0.6, rng.standard_normal(3) * 0.6
+        kf = lambda u, v: float(o.matrix(k, u[None], v[None])[0, 0])
+        B = o.valgrad_block(k, x, y)
+        E = np.eye(3)
+        gx = np.array([(kf(x + h * e, y) - kf(x - h * e, y)) / (2 * h) for e in E])
+        gy = np.array([(kf(x, y + h * e) - kf(x, y - h * e)) / (2 * h) for e in E])
+        gxy = np.array([[(kf(x + h * e, y + h * f) - kf(x + h * e, y - h * f) - kf(x - h * e, y + h * f) + kf(x - h * e, y - h * f)) / (4 * h * h)
+                         for f in E] for e in E])
+        sc = max(1.0, np.abs(B).max())
+        assert abs(B[0, 0] - kf(x, y)) < 1e-14 * sc and np.abs(B[1:, 0] - gx).max() < 1e-8 * sc
+        assert np.abs(B[0, 1:] - gy).max() < 1e-8 * sc and np.abs(B[1:, 1:] - gxy).max() < 1e-4 * sc, name
+    # symmetric case: the value-gradient Gramian is symmetric (test/gradient.jl:100-104)
+    Xs = rng.standard_normal((5, 2))
+    for k in kernels.values():
+        M = o.valgrad_matrix(k, Xs, Xs)
+        assert np.abs(M - M.T).max() < 1e-12 * max(1.0, np.abs(M).max())
+
+
 def test_profile_derivatives_against_mpmath():
     import mpmath as mp
     mp.mp.dps = 40
