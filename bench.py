@@ -136,6 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = cg.kernel_time()
     cg.set_option("time_kernels", 0)
+    dense_path = cg.get_info("last_dense_path")
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
@@ -164,12 +165,27 @@ def main():
         kern_s = kern_avg_ms * 1e-3
         achieved_tflops = flops_launch / kern_s * 1e-12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_dense_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_dense_mfma_pmc.json" if dense_path == 2 else "r01_dense_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # which kernel ran (the library picks the matrix-core EQ path when its norm bound holds)
+        if dense_path == 2:
+            kname = "covgram::dense_mfma_eq_kernel<K2=2, RT=2> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + 1 v_fma_f32 per pair)"
+            ceiling = 1024 * 2.4e9 * 64 / 12.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (4 cyc) per 64 pairs per SIMD
+            note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
+                    "products), the VALU does 1 v_exp_f32 (8 issue cycles) + 1 v_fma_f32 (4) per 64 pairs per SIMD -> ceiling "
+                    "1.31e13 pairs/s at 2.4 GHz; rocprof SQ counters show the VALU ~100% busy at the ~1.85 GHz the chip sustains "
+                    "under this load (profiles/r01_mfma_eq_counters.txt). 'achieved' uses the reference's algorithmic 3d+3 flops per "
+                    "pair (SURVEY.md §8d), not the instructions executed. 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
+        else:
+            kname = "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>"
+            ceiling = 7.15e12
+            note = ("FP32 VALU + transcendental issue bound (12 flop + 1 v_exp_f32 per pair, O(n) bytes for O(n^2) work); "
+                    "'mfma'/'hbm' do not bound this kernel (SURVEY.md §8d, DESIGN.md §4). Issue-slot ceiling with the measured "
+                    "costs (7 plain VALU at 2 cyc + 1 v_exp_f32 at 8 cyc per 64 pairs per SIMD, 2.4 GHz) = 7.15e12 pairs/s.")
         line = {
             "metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (+ achieved HBM GB/s in roofline.hbm_*)",
             "value": mvms, "unit": "MVM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,16 +198,14 @@ def main():
             "pairs_per_s": mvms * float(n) * m,
             "rel_err_vs_fp64_oracle": rel_err,
             "roofline": {
-                "bound": "valu", "kernel": "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>",
+                "bound": "valu", "kernel": kname,
                 "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,
                 "kernel_avg_ms": kern_avg_ms, "launches": int(launches),
                 "algorithmic_flops_per_launch": flops_launch,
-                "note": "FP32 VALU + transcendental issue bound (12 flop + 1 v_exp_f32 per pair, O(n) bytes for O(n^2) work); "
-                        "'mfma'/'hbm' do not bound this kernel (SURVEY.md §8d, DESIGN.md §4). Issue-slot ceiling with the measured "
-                        "costs (7 plain VALU at 2 cyc + 1 v_exp_f32 at 8 cyc per 64 pairs per SIMD, 2.4 GHz) = 7.15e12 pairs/s.",
-                "issue_roofline_frac": (float(n_local) * m / kern_s) / 7.15e12,
+                "note": note,
+                "issue_roofline_frac": (float(n_local) * m / kern_s) / ceiling,
                 "hbm_algorithmic_bytes_per_launch": bytes_launch,
                 "hbm_achieved_GBps": bytes_launch / kern_s * 1e-9,
                 "hbm_frac": bytes_launch / kern_s * 1e-9 / HBM_PEAK_GBPS,

@@ -20,7 +20,7 @@ from .kernels import (AbstractKernel, MercerKernel, StationaryKernel, IsotropicK
                       device_spec, DomainError)
 from .gramian import (Gramian, BlockGramian, SymmetricToeplitz, Toeplitz, Circulant, KroneckerProduct, kronecker,
                       SeparableGramian, LazyMatrixProduct, LazyMatrixSum, Fill, LazyOperator, LazyGrid, StepRangeLen,
-                      srange, gramian, mul_, get_ctx, set_option, kernel_time)
+                      srange, gramian, mul_, get_ctx, set_option, get_info, kernel_time)
 from .dist import ShardedGramian, shard_bounds
 from .solve import cg, solve
 

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "covgram_ctx_set_stream": (C.c_int, [_P, _P]),
     "covgram_ctx_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "covgram_ctx_set_option": (C.c_int, [_P, C.c_char_p, _I64]),
+    "covgram_ctx_get_info": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64)]),
     "covgram_sync": (C.c_int, [_P]),
     "covgram_ctx_kernel_time": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), _I32]),
     "covgram_points_create": (C.c_int, [_P, C.POINTER(_P), _P, _I64, _I32, _I32, _I32]),

@@ -74,6 +74,13 @@ def set_option(key: str, value: int, device=None):
     get_ctx(device).set_option(key, value)
 
 
+def get_info(key: str, device=None) -> int:
+    """covgram_ctx_get_info: e.g. "last_dense_path" (1 lane-per-row direct differences, 2 matrix-core EQ, 3 wide rows)."""
+    v = C.c_int64(0)
+    _ffi.check(_ffi.lib().covgram_ctx_get_info(get_ctx(device).handle, key.encode(), C.byref(v)))
+    return v.value
+
+
 def _dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return _ffi.F32

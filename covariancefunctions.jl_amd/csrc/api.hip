@@ -117,25 +117,29 @@ static int make_composite_kernel(const covgram_kernel_composite* c, int dtype, H
     out->eq_folded = false;
     out->tu_family = (h.trait == COVGRAM_ISOTROPIC) ? FAM_EXPR_ISO : FAM_EXPR_DOT;
     out->nterms = c->nterms;
-    int nf = 0;
+    int nin = 0, nf = 0;   // factors consumed from the descriptor / profile factors kept for the device
     for (int t = 0; t < c->nterms; ++t) {
         CG_REQUIRE(c->nfactors[t] >= 1, COVGRAM_EINVAL, "composite: term %d has no factors", t);
-        out->nfac[t] = c->nfactors[t];
-        for (int f = 0; f < c->nfactors[t]; ++f, ++nf) {
-            CG_REQUIRE(nf < EXPR_MAXF, COVGRAM_EUNSUPPORTED, "composite: more than %d factors", EXPR_MAXF);
-            const covgram_kernel& fk = c->factors[nf];
-            if (fk.family == COVGRAM_CONSTANT) {
-                out->ffam[nf] = COVGRAM_CONSTANT;
-                out->fkp[nf].gamma = out->fkp[nf].gamma2 = 1.0; out->fkp[nf].scale = fk.scale; out->fkp[nf].power = 1;
+        out->nfac[t] = 0;
+        out->coef[t] = 1.0;
+        for (int f = 0; f < c->nfactors[t]; ++f, ++nin) {
+            CG_REQUIRE(nin < EXPR_MAXF, COVGRAM_EUNSUPPORTED, "composite: more than %d factors", EXPR_MAXF);
+            const covgram_kernel& fk = c->factors[nin];
+            if (fk.family == COVGRAM_CONSTANT) {   // Constants fold into the term's coefficient
+                out->coef[t] *= fk.scale;
                 continue;
             }
             CG_REQUIRE(fk.trait == h.trait, COVGRAM_EINVAL, "composite: factor %d has trait %d, head has %d (GenericInput is not a device path)",
-                       nf, fk.trait, h.trait);
+                       nin, fk.trait, h.trait);
             HostKernel one;
             int rc = make_simple_kernel(&fk, dtype, true, &one);
             if (rc) return rc;
+            double sc = fk.scale;                  // (scale * phi)^1 only: a factor's scale multiplies the term once
+            out->coef[t] *= sc;
             out->ffam[nf] = fk.family;
             out->fkp[nf] = one.kp;
+            out->fkp[nf].scale = 1.0;
+            ++out->nfac[t]; ++nf;
         }
     }
     return COVGRAM_OK;
@@ -390,6 +394,14 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     return COVGRAM_OK;
 }
 
+int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
+    CG_REQUIRE(ctx && key && value, COVGRAM_EINVAL, "NULL argument");
+    if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
+    else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
+    else { set_error("unknown info key '%s'", key); return COVGRAM_EINVAL; }
+    return COVGRAM_OK;
+}
+
 int covgram_ctx_kernel_time(covgram_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset) {
     CG_REQUIRE(ctx && total_ms && launches, COVGRAM_EINVAL, "NULL argument");
     CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -432,6 +444,8 @@ int covgram_points_create(covgram_ctx* ctx, covgram_points** out, const void* x,
         }
         p->owns = true;
     }
+    int rc = points_max_norm2(p);      // one reduction + 4-byte read-back: gates the matrix-core EQ path (dense_mfma.hip)
+    if (rc) { if (p->owns && p->dptr) (void)hipFree(p->dptr); delete p; return rc; }
     ctx->live_handles++;
     *out = p;
     return COVGRAM_OK;
@@ -535,7 +549,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const int64_t rowblocks = (n + rows_per_wg - 1) / rows_per_wg;
     const int64_t npad = rowblocks * rows_per_wg;
 
-    for (int c0 = 0; c0 < nrhs; c0 += 4) {
+    const bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
+    if (m > 0) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
+    if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
+    for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NRpad = (nr == 1) ? 1 : 4;
         const char* a_c = (const char*)a_dev + (size_t)c0 * lda_d * ts;

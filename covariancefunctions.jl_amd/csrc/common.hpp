@@ -74,9 +74,10 @@ struct ExprParams {
     T gamma;                     // coordinate pre-scale of the rows: always 1 (every factor scales s by its own gamma2)
     int32_t power;               // always 1 (Power is applied per factor)
     int32_t nterms;
-    int32_t nfac[EXPR_MAXT];     // factors per term, stored consecutively in f[]
-    int32_t fam[EXPR_MAXF];      // covgram_family of each factor (COVGRAM_CONSTANT allowed)
-    KParams<T> f[EXPR_MAXF];     // per factor: gamma2 = 1/l^2, scale, power and the profile constants
+    int32_t nfac[EXPR_MAXT];     // profile factors per term, stored consecutively in f[] (0: the term is its coefficient)
+    T coef[EXPR_MAXT];           // product of the term's scales and Constant factors (folded by the host)
+    int32_t fam[EXPR_MAXF];      // covgram_family of each profile factor
+    KParams<T> f[EXPR_MAXF];     // per factor: gamma2 = 1/l^2, power and the profile constants (scale is in coef)
 };
 
 template <int FAM, typename T> struct ParamsOf { using type = KParams<T>; };
@@ -92,6 +93,7 @@ struct HostKernel {
     int tu_family;        // launcher index: k.family, or FAM_EXPR_ISO / FAM_EXPR_DOT
     int nterms;           // composite only
     int nfac[EXPR_MAXT];
+    double coef[EXPR_MAXT];
     int ffam[EXPR_MAXF];
     KParams<double> fkp[EXPR_MAXF];
 };
@@ -115,7 +117,7 @@ inline typename ParamsOf<FAM, T>::type make_params(const HostKernel& hk) {
         ExprParams<T> e;
         memset(&e, 0, sizeof(e));
         e.gamma = (T)1; e.power = 1; e.nterms = hk.nterms;
-        for (int t = 0; t < EXPR_MAXT; ++t) e.nfac[t] = hk.nfac[t];
+        for (int t = 0; t < EXPR_MAXT; ++t) { e.nfac[t] = hk.nfac[t]; e.coef[t] = (T)hk.coef[t]; }
         for (int f = 0; f < EXPR_MAXF; ++f) { e.fam[f] = hk.ffam[f]; e.f[f] = cast_params<T>(hk.fkp[f]); }
         return e;
     } else {
@@ -139,7 +141,7 @@ struct covgram_ctx {
     bool own_stream = false;
     covgram::Workspace ws[4];  // 0: packed tile stream, 1: split-J partials, 2/3: host staging (device copies of a / y)
     // options
-    int64_t dense_variant = 0;   // 0 scalar-cache broadcast (SMEM), 1 LDS-staged tiles
+    int64_t dense_variant = 0;   // 0 auto (fp32 EQ on the matrix cores when the norm bound allows), 1 direct differences, 2 MFMA whenever the shape allows
     int64_t rows_per_lane = 0;   // 0 = auto
     int64_t jsplit = 0;          // 0 = auto
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
@@ -147,6 +149,7 @@ struct covgram_ctx {
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int num_cus = 256;
     int live_handles = 0;
+    int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
     int64_t time_kernels = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;
@@ -160,6 +163,7 @@ struct covgram_points {
     int32_t d = 0;
     int32_t dtype = 0;
     bool owns = false;
+    double max_norm2 = 0;  // max_i |x_i|^2 (upper bound; slices inherit the parent's), computed once at creation
 };
 
 namespace covgram {
@@ -201,6 +205,13 @@ struct GradArgs {
 };
 typedef int (*grad_launch_fn)(const GradArgs&, int dtype);
 grad_launch_fn grad_launcher(int family);
+
+// fp32 EQ on the matrix cores (dense_mfma.hip)
+constexpr double MFMA_GATE = 64.0;   // max |x~| |y~| for which the expanded exponent keeps entry errors ~<= 4e-6
+int points_max_norm2(covgram_points* p);
+bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
+int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,
+                double alpha, double beta);
 
 int pad_dim(int d);          // next compiled D >= d, or -1
 extern const int kDims[];    // compiled D list

@@ -1,0 +1,308 @@
+// dense_mfma.hip — the fp32 ExponentiatedQuadratic Gramian MVM on the matrix cores.
+//
+// The lane-per-row kernel of dense_mvm.hpp spends 23 issue cycles per 64 pairs, two thirds of them on the distance
+// (3 d packed VALU ops per column pair): it sits on the VALU issue ceiling.  For the EQ profile the
+// distance can leave the VALU altogether:
+//     exp(-|x-y|^2 / (2 l^2)) = exp2(-|x~|^2/2) * exp2(x~ . y~) * exp2(-|y~|^2/2),      x~ = sqrt(log2 e) x / l
+// so that   b_i = alpha * e_i * sum_j w_j exp2(x~_i . y~_j),   e_i = exp2(-|x~_i|^2/2),  w_j = a_j exp2(-|y~_j|^2/2):
+// a 32 x 32 GEMM tile per wave and 32 rows, then ONE v_exp_f32 and ONE v_fma_f32 per pair.
+//
+// Which MFMA.  v_mfma_f32_32x32x2_f32 is exact but shares the fp32 FMA datapath with the VALU: measured on C2 it added
+// its full 64 cycles per instruction to the VALU time (2.66 ms, no gain; profiles/r01_mfma_eq_variants.txt).  The bf16
+// matrix pipe does run beside the VALU (it holds vector issue for 8 of its 32 cycles), so the fp32 dot product is
+// rebuilt on it from a three-way bf16 split of every coordinate, x~ = x1 + x2 + x3 (8 + 8 + 8 mantissa bits, bf16 keeps
+// the fp32 exponent range): the eight products x1y1, x1y2, x2y1, x1y3, x2y2, x3y1, x2y3, x3y2 (everything down to
+// 2^-24 |x~||y~|; only x3y3 ~ 2^-32 is dropped) are exact in the fp32 accumulator, and they fill exactly the 8 K-slots a
+// lane owns in v_mfma_f32_32x32x16_bf16: one MFMA covers two coordinates (lane half h takes coordinate 2 mm + h).
+//
+// Tile orientation: D = X~tile (32 rows i) * Y~tile^T (32 columns j).  A lane holds column j = lane & 31 and the 16 rows
+// i = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) of the result, so the column weight w_j is ONE per-lane register per tile and
+// the 16 accumulators of a lane collect "row i, columns == lane (mod 32)" over all column tiles; the sum over the 32
+// lanes happens once per wave, at the end (5 butterfly steps).  RT row tiles per wave share every B fragment.
+//
+// Numerics.  This is NOT the reference's direct-difference r^2 (src/util.jl:40-47): the exponent x~.y~ - (|x~|^2+|y~|^2)/2
+// is formed from O(|x~||y~|) terms, so its absolute error is ~1e-7 |x~||y~| and the relative error of an entry
+// ~0.7e-7 |x~||y~|.  The path is therefore taken only when the host-side bound  max|x~| max|y~| <= MFMA_GATE (= 64,
+// entry error <= ~4e-6 worst case against the 1e-5 fp32 tolerance of BASELINE.json) holds — the point-set norms are
+// computed once when the covgram_points handle is created — and otherwise the exact direct-difference kernel runs.
+// Option "dense_variant": 0 = this rule, 1 = always direct differences, 2 = MFMA whenever the shape allows (tests).
+#include "dense_mvm.hpp"
+
+namespace covgram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+// round-to-nearest-even bf16 of a finite float, as its 16-bit pattern
+__device__ __forceinline__ unsigned bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// f = p1 + p2 + p3 (+ O(2^-27 f)) with bf16 pieces
+__device__ __forceinline__ void split3(float f, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = bf16_bits(f);
+    const float r1 = f - __uint_as_float(p1 << 16);
+    p2 = bf16_bits(r1);
+    const float r2 = r1 - __uint_as_float(p2 << 16);
+    p3 = bf16_bits(r2);
+}
+
+// B fragments of every column tile in MFMA lane order + the folded weights.  Lane (r, h) of MFMA mm of tile T holds, for
+// coordinate c = 2 mm + h of column j = 32 T + r, the eight K-slots  [y1, y2, y1, y3, y2, y1, y3, y2]  (16 bytes), which
+// meet the row side's  [x1, x1, x2, x1, x2, x3, x2, x3].
+//   PB[(T * K2 + mm) * 64 + l] = that fragment (zero outside the point set / dimension)
+//   W[32 T + r]                = a_j * exp2(-|g y_j|^2 / 2)                     (0 for padding columns)
+__global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
+                                                        uint4* __restrict__ PB, float* __restrict__ W, int32_t K2, float g) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
+    const int64_t ntile = (m + 31) / 32;
+    if (e >= ntile * K2 * 64) return;
+    const int l = (int)(e & 63);
+    const int64_t q = e >> 6;
+    const int mm = (int)(q % K2);
+    const int64_t T = q / K2;
+    const int64_t j = 32 * T + (l & 31);
+    const int c = 2 * mm + (l >> 5);
+    const float yt = (j < m && c < d) ? g * Y[j * (int64_t)d + c] : 0.0f;
+    unsigned y1, y2, y3;
+    split3(yt, y1, y2, y3);
+    PB[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
+    if (mm == 0 && l < 32) {
+        float w = 0.0f;
+        if (j < m) {
+            float ny = 0.0f;
+            for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+            w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
+        }
+        W[j] = w;
+    }
+}
+
+union Frag {
+    uint4 u;
+    bf16x8 v;
+};
+
+template <int K2, int RT>
+__global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+                                                           const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
+                                                           float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
+                                                           float alpha, float beta, int32_t final_store) {
+    const int l = threadIdx.x, t = l & 31, h = l >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * (32 * RT);
+    // A fragments: lane (t, h) holds the split of x~[row][c = 2 mm + h]; the row norm from the same fp32 values
+    Frag a[RT][K2];
+    float nx[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        int64_t row = i0 + 32 * r + t;
+        if (row >= n) row = n - 1;                               // clamp: computed, never stored
+        const float* __restrict__ xr = X + row * (int64_t)d;
+        float part = 0.0f;
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) {
+            const int c = 2 * mm + h;
+            const float xt = (c < d) ? g * xr[c] : 0.0f;
+            part = __builtin_fmaf(xt, xt, part);
+            unsigned x1, x2, x3;
+            split3(xt, x1, x2, x3);
+            a[r][mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+        }
+        nx[r] = part + __shfl_xor(part, 32);
+    }
+
+    const int64_t T0 = (int64_t)blockIdx.y * tchunk;
+    const int64_t T1 = (T0 + tchunk < ntile) ? (T0 + tchunk) : ntile;
+    float acc[RT][16];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
+
+    // Column tiles in pairs with two operand buffers (no register copies); the prefetch of a tile past the chunk is clamped
+    // to the last tile (a harmless re-read) instead of branching.  Uniform base + 32-bit lane offset -> saddr loads.
+    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
+    const float* __restrict__ wbase = W + T0 * 32;
+    const int nt = (int)(T1 - T0);
+    auto load_tile = [&](int ti, Frag (&f)[K2], float& w) {
+        const int tc = ti < nt ? ti : nt - 1;
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) f[mm].u = pbase[(tc * K2 + mm) * 64 + l];
+        w = wbase[tc * 32 + t];
+    };
+    auto process = [&](const Frag (&f)[K2], float w) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][v] = __builtin_fmaf(w, __builtin_amdgcn_exp2f(D[v]), acc[r][v]);
+        }
+    };
+    Frag f0[K2], f1[K2];
+    float w0, w1;
+    load_tile(0, f0, w0);
+    for (int ti = 0; ti < nt; ti += 2) {
+        load_tile(ti + 1, f1, w1);
+        process(f0, w0);
+        load_tile(ti + 2, f0, w0);
+        if (ti + 1 < nt) process(f1, w1);
+    }
+
+    // lane (t, h) owns output row t of each row tile iff bit 2 of t equals h; its register is v = (t & 3) + 4 (t >> 3)
+    const int vsel = (t & 3) + 4 * (t >> 3);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        // sum over the 32 column lanes of each half: afterwards every lane of half h holds the totals of rows i(v, h)
+        float tot = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float s = acc[r][v];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            tot = (vsel == v) ? s : tot;
+        }
+        const int64_t i = i0 + 32 * r + t;
+        if (((t >> 2) & 1) != h || i >= n) continue;
+        const float res = __builtin_amdgcn_exp2f(-0.5f * nx[r]) * tot;
+        if (final_store) {
+            float v = alpha * res;
+            if (beta != 0.0f) v = __builtin_fmaf(beta, out[i], v);
+            out[i] = v;
+        } else {
+            out[(int64_t)blockIdx.y * npad + i] = res;
+        }
+    }
+}
+
+// max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
+template <typename T>
+__global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.0f;
+    if (i < n) {
+        double s = 0;
+        for (int c = 0; c < d; ++c) { const double xc = (double)X[i * (int64_t)d + c]; s += xc * xc; }
+        v = (float)s;
+        if (!(v >= 0.0f)) v = __builtin_inff();                  // NaN / overflow: never eligible
+        v *= 1.000001f;                                          // round up: the bound must not under-estimate
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(outbits, __float_as_uint(v));
+}
+
+int points_max_norm2(covgram_points* p) {
+    p->max_norm2 = 0.0;
+    if (p->n == 0) return COVGRAM_OK;
+    unsigned* dbits = nullptr;
+    CG_CHECK_HIP(hipMalloc(&dbits, sizeof(unsigned)));
+    hipStream_t st = p->ctx->stream;
+    hipError_t e = hipMemsetAsync(dbits, 0, sizeof(unsigned), st);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((p->n + 255) / 256);
+        if (p->dtype == COVGRAM_F32) hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits);
+        else hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits);
+        e = hipGetLastError();
+    }
+    unsigned bits = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, dbits, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dbits);
+    if (e != hipSuccess) { set_error("max-norm reduction failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    float f;
+    memcpy(&f, &bits, sizeof(f));
+    p->max_norm2 = (double)f;
+    return COVGRAM_OK;
+}
+
+bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
+    if (ctx->dense_variant == 1) return false;
+    if (hk.tu_family != COVGRAM_EQ || hk.k.power != 1 || X->dtype != COVGRAM_F32 || nrhs != 1) return false;
+    if (X->d > 32 || Y->n == 0) return false;                   // beyond d = 32 the fragments leave one wave per SIMD
+    if (ctx->dense_variant == 2) return true;
+    const double g2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale);   // |x~|^2 = g2 |x|^2
+    return g2 * sqrt(X->max_norm2) * sqrt(Y->max_norm2) <= MFMA_GATE;
+}
+
+// resident single-wave workgroups per CU of the kernel instance (register-limited), for the grid sizing below
+template <int K2, int RT>
+static int mfma_blocks_per_cu() {
+    static int cached = 0;
+    if (!cached) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_mfma_eq_kernel<K2, RT>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
+        cached = nb;
+    }
+    return cached;
+}
+template <int K2>
+static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : mfma_blocks_per_cu<K2, 1>(); }
+
+template <int K2>
+static void launch_mfma(int rt, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
+                        float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store) {
+    if (rt == 2)
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store);
+    else
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store);
+}
+
+// y <- alpha * scale * G a + beta * y for ONE right-hand side (device pointers)
+int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,
+                double alpha, double beta) {
+    const int64_t n = X->n, m = Y->n;
+    const int d = X->d;
+    const int D = pad_dim(d);
+    const int K2 = (D + 1) / 2;
+    const int64_t ntile = (m + 31) / 32;
+    const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
+    void* P;
+    int rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + 32 * sizeof(float)), &P);
+    if (rc) return rc;
+    uint4* PB = (uint4*)P;
+    float* W = (float*)(PB + ntile * K2 * 64);
+    const int64_t pe = ntile * K2 * 64;
+    hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, PB, W, K2, g);
+    // split the column tiles so that the grid holds ~CUs * 128 waves (as the lane-per-row kernel, profiles/r01_quickbench_wg64.txt)
+    // row tiles per wave: two share every B fragment while the state fits (d <= 8); option "rows_per_lane" = 1 / 2 forces it
+    const int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= 4 ? 2 : 1));
+    const int64_t rowtiles = (n + 32 * rt - 1) / (32 * rt);
+    const int64_t npad = rowtiles * 32 * rt;
+    // grid = a whole number (4) of rounds of resident waves: a fractional last round costs up to one round of idle SIMDs
+    int nb = 16;
+    switch (K2) {
+        case 1: nb = mfma_blocks<1>(rt); break; case 2: nb = mfma_blocks<2>(rt); break; case 3: nb = mfma_blocks<3>(rt); break;
+        case 4: nb = mfma_blocks<4>(rt); break; case 6: nb = mfma_blocks<6>(rt); break; case 8: nb = mfma_blocks<8>(rt); break;
+        case 12: nb = mfma_blocks<12>(rt); break; case 16: nb = mfma_blocks<16>(rt); break; default: break;
+    }
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
+    int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
+    js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));     // >= 8 tiles (256 columns) per wave
+    const int64_t tchunk = (ntile + js - 1) / js;
+    js = (ntile + tchunk - 1) / tchunk;
+    const double alpha_eff = alpha * hk.kp.scale;
+    float* out = y;
+    if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
+    const dim3 grid((unsigned)rowtiles, (unsigned)js);
+    const int fs = js == 1 ? 1 : 0;
+    auto* tm = timer_next(ctx);
+    if (tm) (void)hipEventRecord(tm->first, ctx->stream);
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs); break;
+    switch (K2) {
+        CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
+        default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
+    }
+#undef CG_MFMA_CASE
+    if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+    if (js > 1)
+        hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
+                           (int)js, y, n, n, 1, (float)alpha_eff, (float)beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense_mfma launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+}  // namespace covgram

@@ -32,27 +32,6 @@ namespace covgram {
 constexpr int DENSE_THREADS = CG_DENSE_THREADS;
 constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, so column pairs never straddle chunks
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// columns per stream element: 2 for float (packed math), 1 for double
-template <typename T> struct Pk;
-template <> struct Pk<float> {
-    using V = v2f;
-    static constexpr int N = 2;
-    static __device__ __forceinline__ V splat(float x) { return (V){x, x}; }
-    static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
-    static __device__ __forceinline__ float hsum(V a) { return a.x + a.y; }
-    template <class F> static __device__ __forceinline__ V map(V s, F f) { return (V){f(s.x), f(s.y)}; }
-};
-template <> struct Pk<double> {
-    using V = double;
-    static constexpr int N = 1;
-    static __device__ __forceinline__ V splat(double x) { return x; }
-    static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_fma(a, b, c); }
-    static __device__ __forceinline__ double hsum(V a) { return a; }
-    template <class F> static __device__ __forceinline__ V map(V s, F f) { return f(s); }
-};
-
 // Dimensions are consumed in chunks of one 64-byte scalar load; for rows wider than a chunk a scheduling
 // barrier after each chunk keeps hipcc from hoisting every s_load of a column group to the top, which would
 // overflow the ~100 usable SGPRs and spill them through v_writelane.
@@ -61,6 +40,44 @@ struct DenseBody {
     using PK = Pk<T>;
     using V = typename PK::V;
     static constexpr int DC = 64 / (int)sizeof(V);
+
+    // s[r] = |x_r - y|^2 (or x_r . y) for one column group
+    static __device__ __forceinline__ void dist(const V* __restrict__ p, const T (&x)[R][D], V (&s)[R]) {
+#pragma unroll
+        for (int c0 = 0; c0 < D; c0 += DC) {
+#pragma unroll
+            for (int l = c0; l < ((c0 + DC < D) ? c0 + DC : D); ++l) {
+                const V yl = p[l];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const V xl = PK::splat(x[r][l]);
+                    if constexpr (ISO) {
+                        const V dl = xl - yl;
+                        s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
+                    } else {
+                        s[r] = (l == 0) ? xl * yl : PK::fma(xl, yl, s[r]);
+                    }
+                }
+            }
+            if constexpr (D > DC) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // Composite kernels: BG column groups at once, so that the interpreter's scalar loads and branches (one set per
+    // factor) are paid per block instead of per pair (profiles.hpp: expr_value_block).
+    template <int BG>
+    static __device__ __forceinline__ void step_block(const V* __restrict__ p, const T (&x)[R][D], V (&acc)[R][NR],
+                                                      const typename ParamsOf<FAM, T>::type& kp) {
+        static_assert(R == 1, "block evaluation is written for one row per lane");
+        V s[BG];
+#pragma unroll
+        for (int g = 0; g < BG; ++g) {
+            V sg[R];
+            dist(p + g * (D + NR), x, sg);
+            s[g] = sg[0];
+        }
+        expr_accumulate_block<T, ISO, BG, NR>(s, kp, p + D, D + NR, acc[0]);
+    }
 
     // One column group (PK::N columns) against R rows.  p points at the (uniform) packed record of the group.
     static __device__ __forceinline__ void step(const V* __restrict__ p, const T (&x)[R][D], V (&acc)[R][NR],
@@ -148,9 +165,14 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
             for (int c = 0; c < NR; ++c) acc[r][c] = PK::splat((T)0);
         const V* __restrict__ p = P + gb * S;               // uniform address -> s_load_dwordxN
         int g = 0;
-        for (; g + GU <= cnt; g += GU, p += GU * S) {
+        if constexpr (fam_is_expr<FAM>) {
+            constexpr int BG = 4;
+            for (; g + BG <= cnt; g += BG, p += BG * S) Body::template step_block<BG>(p, x, acc, kp);
+        } else {
+            for (; g + GU <= cnt; g += GU, p += GU * S) {
 #pragma unroll
-            for (int u = 0; u < GU; ++u) Body::step(p + u * S, x, acc, kp);
+                for (int u = 0; u < GU; ++u) Body::step(p + u * S, x, acc, kp);
+            }
         }
         for (; g < cnt; ++g, p += S) Body::step(p, x, acc, kp);
 #pragma unroll

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
+#include "pack.hpp"
 
 namespace covgram {
 
@@ -36,6 +37,12 @@ __device__ __forceinline__ T horner(const T* h, int deg, T r) {
     T acc = h[deg];
     for (int m = deg - 1; m >= 0; --m) acc = cg_fma(acc, r, h[m]);
     return acc;
+}
+
+// degree-3 Horner on a table that is zero beyond its true degree
+template <typename T>
+__device__ __forceinline__ T horner3(const T* h, T r) {
+    return cg_fma(cg_fma(cg_fma(h[3], r, h[2]), r, h[1]), r, h[0]);
 }
 
 // integer power by repeated multiplication (uniform exponent)
@@ -88,9 +95,16 @@ template <typename T, bool F>
 struct Phi<COVGRAM_MATERNP, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         T r = cg_sqrt(kp.mp_c * s);
-        T v = horner(kp.h0, kp.p, r) * cg_exp(-r);
-        T t = horner(kp.ty, kp.p, s);                   // Taylor branch (src/stationary.jl:139-146)
-        return (s < kp.mp_bound) ? t : v;
+        T e = cg_exp(-r);
+        T q, t;                                         // t: Taylor branch (src/stationary.jl:139-146)
+        if (kp.p <= 3) {   // nu <= 7/2: fixed-degree Horner on the zero-padded tables (same values, no loop, no indexed loads)
+            q = horner3(kp.h0, r);
+            t = horner3(kp.ty, s);
+        } else {
+            q = horner(kp.h0, kp.p, r);
+            t = horner(kp.ty, kp.p, s);
+        }
+        return (s < kp.mp_bound) ? t : q * e;
     }
 };
 template <typename T, bool F>
@@ -122,22 +136,72 @@ __device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
     return v;
 }
 
-// composite value: sum over terms of the product of the factors; ISO factors see s / l_f^2
+// composite value: sum over terms of coef_t * product of the term's profile factors; ISO factors see s / l_f^2
 template <typename T, bool ISO>
 __device__ __forceinline__ T expr_value(T s, const ExprParams<T>& ep) {
     T total = (T)0;
     int fi = 0;
     for (int t = 0; t < ep.nterms; ++t) {
-        T prod = (T)1;
+        T prod = ep.coef[t];
         for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
             const KParams<T>& q = ep.f[fi];
-            const T sf = ISO ? s * q.gamma2 : s;
-            prod *= q.scale * phi_any<T>(ep.fam[fi], sf, q);
+            prod *= phi_any<T>(ep.fam[fi], ISO ? s * q.gamma2 : s, q);
         }
         total += prod;
     }
     return total;
 }
+
+// The same composite for a block of BG column groups, factor-outer: the factor's parameters are read (scalar loads)
+// and its family dispatched (scalar branch) once per block; the inner loops are straight-line math over the block.
+// Each finished term goes straight into the NR accumulators: acc[c] += w[g][c] * term[g], w[g][c] = wts[g * wstride + c].
+template <typename T, bool ISO, int BG, int NR>
+__device__ __forceinline__ void expr_accumulate_block(const typename Pk<T>::V (&s)[BG], const ExprParams<T>& ep,
+                                                      const typename Pk<T>::V* __restrict__ wts, int wstride,
+                                                      typename Pk<T>::V (&acc)[NR]) {
+    using PK = Pk<T>;
+    using V = typename PK::V;
+    int fi = 0;
+    for (int t = 0; t < ep.nterms; ++t) {
+        V prod[BG];
+        const V coef = PK::splat(ep.coef[t]);
+#pragma unroll
+        for (int g = 0; g < BG; ++g) prod[g] = coef;
+        for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
+            const KParams<T>& q = ep.f[fi];
+            const V g2 = PK::splat(ISO ? q.gamma2 : (T)1);
+            const int pw = q.power;
+#define CG_EXPR_CASE(F)                                                                                                          \
+    case F:                                                                                                                      \
+        if (pw == 1) {                                                                                                           \
+            _Pragma("unroll") for (int g = 0; g < BG; ++g)                                                                       \
+                prod[g] = prod[g] * PK::map(s[g] * g2, [&](T sv) { return Phi<F, T, false>::eval(sv, q); });                     \
+        } else {                                                                                                                 \
+            _Pragma("unroll") for (int g = 0; g < BG; ++g)                                                                       \
+                prod[g] = prod[g] * PK::map(s[g] * g2, [&](T sv) { return ipow(Phi<F, T, false>::eval(sv, q), pw); });           \
+        }                                                                                                                        \
+        break;
+            switch (ep.fam[fi]) {
+                CG_EXPR_CASE(COVGRAM_EQ)
+                CG_EXPR_CASE(COVGRAM_EXP)
+                CG_EXPR_CASE(COVGRAM_RQ)
+                CG_EXPR_CASE(COVGRAM_GAMMAEXP)
+                CG_EXPR_CASE(COVGRAM_CAUCHY)
+                CG_EXPR_CASE(COVGRAM_IMQ)
+                CG_EXPR_CASE(COVGRAM_MATERNP)
+                CG_EXPR_CASE(COVGRAM_EXPDOT)
+                default:                                           // COVGRAM_DOT
+                    CG_EXPR_CASE(COVGRAM_DOT)
+            }
+#undef CG_EXPR_CASE
+        }
+#pragma unroll
+        for (int g = 0; g < BG; ++g)
+#pragma unroll
+            for (int c = 0; c < NR; ++c) acc[c] = PK::fma(wts[g * wstride + c], prod[g], acc[c]);
+    }
+}
+
 template <typename T, bool F>
 struct Phi<FAM_EXPR_ISO, T, F> {
     static __device__ __forceinline__ T eval(T s, const ExprParams<T>& ep) { return expr_value<T, true>(s, ep); }
@@ -215,15 +279,27 @@ struct DPhi<COVGRAM_MATERNP, T> {
         const int p = kp.p;
         T r = cg_sqrt(kp.mp_c * s);
         T e = cg_exp(-r);
-        v = horner(kp.h0, p, r) * e;
         if (p == 0) {                                     // Exp profile (singular at 0)
             T ir = cg_rcp(r);
+            v = e;
             d1 = (T)-0.5 * e * ir; d2 = (T)0.25 * e * (ir * ir + ir * ir * ir);
             return;
         }
+        if (p <= 3) {                                     // fixed-degree forms on the zero-padded tables
+            v = horner3(kp.h0, r) * e;
+            d1 = kp.mp_d1 * horner3(kp.h1, r) * e;        // d/dr[r^nu K_nu] = -r^nu K_{nu-1}
+            if (p >= 2) d2 = kp.mp_d2 * horner3(kp.h2, r) * e;
+            else d2 = -kp.mp_d1 * e * kp.mp_c * (T)0.5 * cg_rcp(r);
+            if (s < kp.mp_bound) {                        // polynomial branch, differentiated termwise
+                v = horner3(kp.ty, s);
+                d1 = cg_fma(cg_fma((T)3 * kp.ty[3], s, (T)2 * kp.ty[2]), s, kp.ty[1]);
+                d2 = cg_fma((T)6 * kp.ty[3], s, (T)2 * kp.ty[2]);
+            }
+            return;
+        }
+        v = horner(kp.h0, p, r) * e;
         d1 = kp.mp_d1 * horner(kp.h1, p - 1, r) * e;      // d/dr[r^nu K_nu] = -r^nu K_{nu-1}
-        if (p >= 2) d2 = kp.mp_d2 * horner(kp.h2, p - 2, r) * e;
-        else d2 = -kp.mp_d1 * e * kp.mp_c * (T)0.5 * cg_rcp(r);
+        d2 = kp.mp_d2 * horner(kp.h2, p - 2, r) * e;
         if (s < kp.mp_bound) {                            // polynomial branch, differentiated termwise
             v = horner(kp.ty, p, s);
             T t1 = (T)0, t2 = (T)0;
@@ -281,13 +357,13 @@ __device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& 
     v = (T)0; d1 = (T)0; d2 = (T)0;
     int fi = 0;
     for (int t = 0; t < ep.nterms; ++t) {
-        T p0 = (T)1, p1 = (T)0, p2 = (T)0;
+        T p0 = ep.coef[t], p1 = (T)0, p2 = (T)0;
         for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
             const KParams<T>& q = ep.f[fi];
             const T g2 = ISO ? q.gamma2 : (T)1;
             T fv, f1, f2;
             jet_any<T>(ep.fam[fi], s * g2, q, fv, f1, f2);
-            fv *= q.scale; f1 *= q.scale * g2; f2 *= q.scale * g2 * g2;
+            f1 *= g2; f2 *= g2 * g2;
             p2 = p2 * fv + (T)2 * p1 * f1 + p0 * f2;
             p1 = p1 * fv + p0 * f1;
             p0 = p0 * fv;

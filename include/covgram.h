@@ -121,8 +121,13 @@ int covgram_ctx_create(covgram_ctx** ctx, int device_id, void* hip_stream);
 int covgram_ctx_destroy(covgram_ctx* ctx);
 int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream);
 int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
-/* tuning / A-B knobs, e.g. "dense_variant" (0 = scalar-cache broadcast, 1 = LDS-staged), "rows_per_lane", "jsplit". */
+/* tuning / A-B knobs: "dense_variant" (0 = auto: fp32 EQ runs on the matrix cores when the norm bound of dense_mfma.hip
+ * holds, 1 = always the direct-difference kernel, 2 = matrix cores whenever the shape allows), "rows_per_lane", "jsplit",
+ * "target_wgs", "grad_keep_r", "time_kernels". */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
+/* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
+ * 2 matrix-core EQ, 3 wide rows), "num_cus". */
+int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
 /* With option "time_kernels" = 1 every dense / gradient MVM brackets its dominant kernel with HIP events on the
  * ctx stream; this returns the summed device time and the number of launches since the last reset. */

@@ -490,3 +490,60 @@ def test_value_gradient_golden_and_limits(cg, oracle):
     Xw = torch.randn(10, 70, dtype=torch.float64, device="cuda")
     with pytest.raises(cg.UnsupportedKernel):
         cg.gramian(cg.ValueGradientKernel(cg.EQ()), Xw) @ torch.randn(10 * 71, dtype=torch.float64, device="cuda")
+
+
+# ---- the matrix-core EQ path (dense_mfma.hip) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16, 32])
+def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
+    """fp32 EQ: the bf16x3-split MFMA path against the fp64 oracle and against the direct-difference kernel, ragged
+    shapes (tile padding on both sides), one and two row tiles per wave, alpha/beta, lengthscale and scale."""
+    rng = np.random.default_rng(77 + d)
+    k = 1.7 * cg.Lengthscale(cg.EQ(), 0.9)
+    ko = oracle.Kernel(oracle.EQ, lengthscale=0.9, scale=1.7)
+    try:
+        for (n, m) in ((1, 1), (33, 31), (257, 1000), (1500, 700)):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+            a = rng.standard_normal(m).astype(np.float32); y0 = rng.standard_normal(n).astype(np.float32)
+            G = cg.gramian(k, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+            ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, np.float32)
+            outs = {}
+            for variant, rpl in ((1, 0), (2, 1), (2, 2), (0, 0)):
+                cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl)
+                yd = torch.from_numpy(y0.copy()).cuda()
+                cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
+                assert cg.get_info("last_dense_path") == (1 if variant == 1 else 2), (variant, d)
+                outs[(variant, rpl)] = yd.cpu().numpy()
+                assert relerr(outs[(variant, rpl)], ref) <= 1e-5, (variant, rpl, d, n, m, relerr(outs[(variant, rpl)], ref))
+            assert relerr(outs[(2, 2)], outs[(1, 0)]) <= 5e-6
+            # beta == 0 ignores NaN in y
+            cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", 0)
+            yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+            cg.mul_(yn, G, torch.from_numpy(a).cuda(), 1.0, 0.0)
+            assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, Y, a, 1.0, 0.0, np.float32)) <= 1e-5
+    finally:
+        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0)
+
+
+def test_eq_matrix_core_gate(cg, oracle):
+    """The expanded exponent is only used while max|x~| max|y~| <= 64; far-from-origin or short-lengthscale data falls back
+    to direct differences (and stays accurate); fp64, other profiles, several right-hand sides never take it."""
+    rng = np.random.default_rng(5)
+    n, d = 600, 3
+    X0 = rng.standard_normal((n, d)).astype(np.float32)
+    a = rng.standard_normal(n).astype(np.float32)
+    ad = torch.from_numpy(a).cuda()
+    # centred unit-scale data: eligible
+    G = cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X0, X0, a, dtype=np.float32)) <= 1e-5
+    # the same cloud shifted far from the origin: |x|^2 ~ 3e4 -> cancellation would cost ~1e-3; the gate sends it to the exact kernel
+    Xs = (X0 + 100.0).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(Xs).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 1 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xs, Xs, a, dtype=np.float32)) <= 1e-5
+    # short lengthscale: |x/l| large
+    G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.05), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 1
+    assert relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.05), X0, X0, a, dtype=np.float32)) <= 1e-5
+    # a row shard inherits the parent's bound; other profiles / fp64 / 3 right-hand sides use the lane-per-row kernel
+    (cg.gramian(cg.RQ(1.0), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.EQ(), torch.from_numpy(X0.astype(np.float64)).cuda()) @ ad.double()); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()) @ torch.randn(n, 3, device="cuda")); assert cg.get_info("last_dense_path") == 1

@@ -137,6 +137,24 @@ def main():
          rel_err_vs_fp64_oracle=rel(yl.cpu().numpy(), o.lowrank_mul(None, U, U, al.cpu().numpy())),
          roofline={"bound": "hbm", "achieved_GBps": bytes_l / (med * 1e-3) * 1e-9, "peak_GBps": HBM_PEAK * 1e-9, "frac": bytes_l / (med * 1e-3) / HBM_PEAK,
                    "algorithmic_bytes": bytes_l})
+    del Gl, al, yl, xs
+    # ---- composite kernels and ValueGradientKernel ------------------------------------------------
+    kc = 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
+    kco = o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=0.7, scale=1.5),), (o.Kernel(o.EQ, lengthscale=2.0, scale=0.5),)), o.ISOTROPIC, 1.0)
+    dense("F2-composite", kc, kco, 131072, 3, torch.float32, note="; composite 1.5*MaternP(2; l=0.7) + 0.5*EQ(l=2) interpreted per pair")
+    for tag, kern, ko, mul_o, blk in (("F2-valgrad", cg.ValueGradientKernel(cg.EQ()), o.Kernel(o.EQ), o.valgrad_mul, d4 + 1),
+                                      ("F2-composite-grad", cg.GradientKernel(cg.EQ() * cg.RQ(1.0)), o.Composite(((o.Kernel(o.EQ), o.Kernel(o.RQ, param=1.0)),)), o.grad_mul, d4)):
+        rng = np.random.default_rng(0xC0F + 7)
+        Xh = rng.standard_normal((n4, d4)); ah = rng.standard_normal(n4 * blk)
+        X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda()
+        K = cg.gramian(kern, X); y = torch.empty(n4 * blk, dtype=torch.float64, device="cuda")
+        med, mn = timeit(lambda: K.mul_(y, a), warm=2, reps=6)
+        rows = np.sort(np.random.default_rng(1).choice(n4, 64, replace=False))
+        ref = mul_o(None, ko, Xh[rows], Xh, ah)
+        got = y.cpu().numpy().reshape(n4, blk)[rows].reshape(-1)
+        emit(config=tag, what=f"{type(kern).__name__} of {type(kern.k).__name__} mul!, d=32, n=16384, fp64", ms_median=med, ms_min=mn,
+             blocks_per_s=float(n4) * n4 / (med * 1e-3), rel_err_vs_fp64_oracle=rel(got, ref), checked_rows=64)
+        del K, X, a, y
 
 
 if __name__ == "__main__":
