@@ -207,7 +207,10 @@ typedef int (*grad_launch_fn)(const GradArgs&, int dtype);
 grad_launch_fn grad_launcher(int family);
 
 // fp32 EQ on the matrix cores (dense_mfma.hip)
-constexpr double MFMA_GATE = 64.0;   // max |x~| |y~| for which the expanded exponent keeps entry errors ~<= 4e-6
+// P = max|x~| max|y~| up to which the expanded exponent is used.  Its absolute error is a few fp32 roundings of O(P):
+// measured contribution to the MVM's 2-norm relative error ~4e-9 P (C2: P = 40, +0.7e-7; P = 125: 5e-7, tests), against
+// the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is ~1.7e-7 P per entry.
+constexpr double MFMA_GATE = 128.0;
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,

@@ -122,6 +122,33 @@ function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFac
                        device_gradmul!(y, G, a, α, β, spec)
 end
 
+# --- src/gradient.jl:400-474 (ValueGradientKernel), block mul! :319-351: blocks of d+1, value component first ----
+function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:CovarianceFunctions.ValueGradientKernel}},
+                            a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: Union{Float32, Float64}}
+    G = B.A
+    spec = ENABLED[] && input_trait(G.k) isa Union{IsotropicInput, DotProductInput} ? lower(G.k.k) : nothing
+    spec === nothing && return invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β)
+    X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
+    check(ccall((:covgram_valgrad_mvm, libcovgram), Cint,
+                (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
+                ctx(), spec, X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+    return y
+end
+
+# --- Sum / Product / Power with a common trait (src/algebra.jl:5-63, src/properties.jl:47-63) ---------------------
+# mirrors `covgram_kernel_composite`: k = head.scale * sum_t prod_f factors; every entry point above accepts a pointer to
+# its first member (`head`, family = 101) in place of a CKernel.  Lowering = flatten the Sum/Product tree to a sum of
+# products of `lower`-able leaves (covgram/kernels.py::device_spec is the executed version of this), e.g.
+#     k = 1.5 * Lengthscale(MaternP(2), 0.7) + 0.5 * EQ()   ->   nterms = 2, nfactors = (1, 1, 0, 0),
+#         factors = (CKernel(F_MATERNP, ISO, 2, 1, 0.0, 0.7, 1.5), CKernel(F_EQ, ISO, 0, 1, 0.0, 1.0, 0.5), ...)
+struct CComposite
+    head::CKernel                       # family = 101 (COVGRAM_COMPOSITE), trait = common trait, power = 1, lengthscale = 1
+    nterms::Int32
+    nfactors::NTuple{4, Int32}
+    factors::NTuple{6, CKernel}         # family 100 (COVGRAM_CONSTANT) = a bare constant factor
+end
+# ccall signature: replace `Ref{CKernel}` by `Ref{CComposite}` (same address as its head).
+
 # --- Toeplitz (src/gramian.jl:167-189): handle caches the plan and spectrum -------------------------------------
 mutable struct DeviceToeplitz{T}
     handle::Ptr{Cvoid}; n::Int; m::Int

@@ -525,7 +525,7 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
 
 
 def test_eq_matrix_core_gate(cg, oracle):
-    """The expanded exponent is only used while max|x~| max|y~| <= 64; far-from-origin or short-lengthscale data falls back
+    """The expanded exponent is only used while max|x~| max|y~| <= 128; far-from-origin or short-lengthscale data falls back
     to direct differences (and stays accurate); fp64, other profiles, several right-hand sides never take it."""
     rng = np.random.default_rng(5)
     n, d = 600, 3
@@ -535,6 +535,11 @@ def test_eq_matrix_core_gate(cg, oracle):
     # centred unit-scale data: eligible
     G = cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X0, X0, a, dtype=np.float32)) <= 1e-5
+    # right below the gate (P = max|x~| max|y~| = 125): still far inside the fp32 tolerance
+    s = np.sqrt(125.0 / (1.4426950408889634 * float((X0.astype(np.float64) ** 2).sum(1).max())))
+    Xg = (X0 * s).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(Xg).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xg, Xg, a, dtype=np.float32)) <= 2e-6
     # the same cloud shifted far from the origin: |x|^2 ~ 3e4 -> cancellation would cost ~1e-3; the gate sends it to the exact kernel
     Xs = (X0 + 100.0).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xs).cuda()); b = (G @ ad).cpu().numpy()
