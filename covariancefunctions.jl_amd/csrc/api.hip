@@ -549,9 +549,13 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const int64_t rowblocks = (n + rows_per_wg - 1) / rows_per_wg;
     const int64_t npad = rowblocks * rows_per_wg;
 
-    const bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
-    if (m > 0) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
+    bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
     if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
+    else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
+        mfma = true;
+        rc = mvm_mfma_gen(ctx, k, X, Y, (const float*)a_dev, lda_d, (float*)y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
+    }
+    if (m > 0) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NRpad = (nr == 1) ? 1 : 4;

@@ -215,6 +215,10 @@ int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,
                 double alpha, double beta);
+// the other smooth fp32 profiles, dot-product kernels and several right-hand sides (dense_mfma.hpp)
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
+int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
+                 float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);
 
 int pad_dim(int d);          // next compiled D >= d, or -1
 extern const int kDims[];    // compiled D list

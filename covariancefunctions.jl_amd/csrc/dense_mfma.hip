@@ -27,28 +27,9 @@
 // tolerance of BASELINE.json; common.hpp) holds — the point-set norms are computed once when the covgram_points handle
 // is created — and otherwise the exact direct-difference kernel runs.
 // Option "dense_variant": 0 = this rule, 1 = always direct differences, 2 = MFMA whenever the shape allows (tests).
-#include "dense_mvm.hpp"
+#include "dense_mfma.hpp"
 
 namespace covgram {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-// round-to-nearest-even bf16 of a finite float, as its 16-bit pattern
-__device__ __forceinline__ unsigned bf16_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-// f = p1 + p2 + p3 (+ O(2^-27 f)) with bf16 pieces
-__device__ __forceinline__ void split3(float f, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = bf16_bits(f);
-    const float r1 = f - __uint_as_float(p1 << 16);
-    p2 = bf16_bits(r1);
-    const float r2 = r1 - __uint_as_float(p2 << 16);
-    p3 = bf16_bits(r2);
-}
 
 // B fragments of every column tile in MFMA lane order + the folded weights.  Lane (r, h) of MFMA mm of tile T holds, for
 // coordinate c = 2 mm + h of column j = 32 T + r, the eight K-slots  [y1, y2, y1, y3, y2, y1, y3, y2]  (16 bytes), which
@@ -80,11 +61,6 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
         W[j] = w;
     }
 }
-
-union Frag {
-    uint4 u;
-    bf16x8 v;
-};
 
 template <int K2, int RT>
 __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
@@ -176,6 +152,41 @@ __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restri
             out[(int64_t)blockIdx.y * npad + i] = res;
         }
     }
+}
+
+// Column tiles for the generic kernel.  Lane (r, h) of MFMA mm of tile T holds coordinate c = 2 mm + h of column
+// j = 32 T + r:  c < d: the split of (iso ? -2 g y_c : g y_c) as [y1, y2, y1, y3, y2, y1, y3, y2];  c == d (iso): the norm
+// slots [1, 1, 1, n1, n2, n3, 0, 0] with n = |g y|^2;  beyond: zeros.   W[(T * NR + c) * 32 + r] = A[j + c lda].
+__global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
+                                                            int64_t lda, int32_t nrhs, int32_t c0, uint4* __restrict__ PB,
+                                                            float* __restrict__ W, int32_t K2, int32_t NR, float g, int32_t iso) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
+    const int64_t ntile = (m + 31) / 32;
+    if (e >= ntile * K2 * 64) return;
+    const int l = (int)(e & 63);
+    const int64_t q = e >> 6;
+    const int mm = (int)(q % K2);
+    const int64_t T = q / K2;
+    const int64_t j = 32 * T + (l & 31);
+    const int c = 2 * mm + (l >> 5);
+    uint4 frag = make_uint4(0, 0, 0, 0);
+    if (j < m) {
+        if (c < d) {
+            const float yt = (iso ? -2.0f : 1.0f) * (g * Y[j * (int64_t)d + c]);
+            unsigned y1, y2, y3;
+            split3(yt, y1, y2, y3);
+            frag = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
+        } else if (iso && c == d) {
+            float ny = 0.0f;
+            for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+            unsigned n1, n2, n3;
+            split3(ny, n1, n2, n3);
+            frag = make_uint4(BF16_ONE | (BF16_ONE << 16), BF16_ONE | (n1 << 16), n2 | (n3 << 16), 0);
+        }
+    }
+    PB[e] = frag;
+    if (mm == 0 && l < 32)
+        for (int cr = 0; cr < NR; ++cr) W[(T * NR + cr) * 32 + l] = (j < m && c0 + cr < nrhs) ? A[j + (int64_t)(c0 + cr) * lda] : 0.0f;
 }
 
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
@@ -301,6 +312,112 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (js > 1)
         hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
                            (int)js, y, n, n, 1, (float)alpha_eff, (float)beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense_mfma launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// generic profiles / several right-hand sides (dense_mfma.hpp)
+// ------------------------------------------------------------------------------------------------------------------------
+#define CG_DECL(n) int launch_mfma_family_##n(const MfmaArgs&, bool query);
+CG_DECL(0) CG_DECL(2) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
+#undef CG_DECL
+
+mfma_launch_fn mfma_launcher(int family) {
+    switch (family) {
+        case COVGRAM_EQ: return launch_mfma_family_0;
+        case COVGRAM_RQ: return launch_mfma_family_2;
+        case COVGRAM_CAUCHY: return launch_mfma_family_4;
+        case COVGRAM_IMQ: return launch_mfma_family_5;
+        case COVGRAM_MATERNP: return launch_mfma_family_6;
+        case COVGRAM_DOT: return launch_mfma_family_7;
+        case COVGRAM_EXPDOT: return launch_mfma_family_8;
+        default: return nullptr;
+    }
+}
+
+static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coordinates, from the compiled set
+    static const int ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int need = (dims + 1) / 2;
+    for (int k : ks) if (k >= need) return k;
+    return -1;
+}
+
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y) {
+    if (ctx->dense_variant == 1 || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
+    if (hk.tu_family >= COVGRAM_NFAMILY || mfma_launcher(hk.tu_family) == nullptr) return false;
+    if (hk.tu_family == COVGRAM_MATERNP && hk.k.p < 1) return false;          // MaternP(0) = Exp: not differentiable in s at 0
+    const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
+    if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
+    if (ctx->dense_variant == 2) return true;
+    const double P = sqrt(X->max_norm2) * sqrt(Y->max_norm2) / (hk.k.lengthscale * hk.k.lengthscale);
+    if (!(P < 1e30)) return false;
+    if (!iso) return true;                                                     // x.y itself: no cancellation to gate
+    // relative sensitivity of the profile to an absolute error in s (natural units): |phi'/phi| at its maximum
+    double sens = 1.0;
+    switch (hk.tu_family) {
+        case COVGRAM_EQ: case COVGRAM_RQ: sens = 0.5; break;
+        case COVGRAM_CAUCHY: sens = 1.0; break;
+        case COVGRAM_IMQ: sens = 0.5 / (hk.k.param * hk.k.param); break;   // 1/sqrt(s + c^2) at s = 0 (s already / l^2)
+        case COVGRAM_MATERNP: sens = fabs(hk.kp.mp_d1) > 0.5 ? fabs(hk.kp.mp_d1) : 0.5; break;
+        default: break;
+    }
+    return sens * hk.k.power * P <= 0.5 * MFMA_GATE / 1.4426950408889634074;   // the EQ gate in natural units
+}
+
+// y[:, 0..nrhs) <- alpha * scale * G a + beta * y (device pointers, column-major with lda / ldy)
+int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
+                 float* y, int64_t ldy, int32_t nrhs, double alpha, double beta) {
+    HostKernel hk;
+    int rc = make_host_kernel(k, COVGRAM_F32, true, &hk);     // gamma = 1/l, unfolded EQ: the profile sees s / l^2
+    if (rc) return rc;
+    const int64_t n = X->n, m = Y->n;
+    const int d = X->d;
+    const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
+    const int K2 = mfma_k2_for(d + (iso ? 1 : 0));
+    const int64_t ntile = (m + 31) / 32;
+    mfma_launch_fn launch = mfma_launcher(hk.tu_family);
+    const double alpha_eff = alpha * hk.kp.scale;
+    for (int c0 = 0; c0 < nrhs; c0 += 4) {
+        const int nr = std::min(4, nrhs - c0);
+        const int NR = nr == 1 ? 1 : 4;
+        const float* a_c = a + (size_t)c0 * lda;
+        float* y_c = y + (size_t)c0 * ldy;
+        void* P;
+        rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + (size_t)NR * 32 * sizeof(float)), &P);
+        if (rc) return rc;
+        uint4* PB = (uint4*)P;
+        float* W = (float*)(PB + ntile * K2 * 64);
+        const int64_t pe = ntile * K2 * 64;
+        hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a_c,
+                           lda, nr, 0, PB, W, K2, NR, (float)hk.kp.gamma, iso ? 1 : 0);
+        MfmaArgs ma;
+        ma.K2 = K2; ma.NR = NR;
+        ma.RT = (NR == 1 && K2 <= 4 && ctx->rows_per_lane != 1) ? 2 : 1;
+        ma.hk = &hk; ma.stream = ctx->stream;
+        const int nb = launch(ma, true);
+        const int64_t rowtiles = (n + 32 * ma.RT - 1) / (32 * ma.RT);
+        const int64_t npad = rowtiles * 32 * ma.RT;
+        int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
+        int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
+        js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));
+        const int64_t tchunk = (ntile + js - 1) / js;
+        js = (ntile + tchunk - 1) / tchunk;
+        float* out = y_c;
+        if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * NR * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
+        ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PB; ma.W = W; ma.ntile = ntile; ma.out = out; ma.npad = npad; ma.ldy = ldy;
+        ma.nrhs = nr; ma.tchunk = tchunk; ma.alpha = (float)alpha_eff; ma.beta = (float)beta; ma.final_store = js == 1 ? 1 : 0;
+        ma.grid = dim3((unsigned)rowtiles, (unsigned)js);
+        auto* tm = timer_next(ctx);
+        if (tm) (void)hipEventRecord(tm->first, ctx->stream);
+        rc = launch(ma, false);
+        if (rc) return rc;
+        if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+        if (js > 1)
+            hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream, (const float*)out, npad,
+                               NR, (int)js, y_c, n, ldy, nr, (float)alpha_eff, (float)beta);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

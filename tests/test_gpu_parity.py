@@ -548,7 +548,45 @@ def test_eq_matrix_core_gate(cg, oracle):
     G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.05), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 1
     assert relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.05), X0, X0, a, dtype=np.float32)) <= 1e-5
-    # a row shard inherits the parent's bound; other profiles / fp64 / 3 right-hand sides use the lane-per-row kernel
-    (cg.gramian(cg.RQ(1.0), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1
+    # fp64 and the profiles that are not differentiable in s at 0 always use the lane-per-row kernel; the smooth fp32
+    # profiles, dot-product kernels and several right-hand sides take the generic matrix-core kernel (dense_mfma.hpp)
     (cg.gramian(cg.EQ(), torch.from_numpy(X0.astype(np.float64)).cuda()) @ ad.double()); assert cg.get_info("last_dense_path") == 1
-    (cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()) @ torch.randn(n, 3, device="cuda")); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.Exp(), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.MaternP(0), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.GammaExp(1.5), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1
+    (cg.gramian(cg.InverseMultiQuadratic(0.01), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1   # 1/c^2 sensitivity
+    (cg.gramian(cg.RQ(1.0), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 2
+    (cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()) @ torch.randn(n, 3, device="cuda")); assert cg.get_info("last_dense_path") == 2
+
+
+@pytest.mark.parametrize("d", [1, 3, 4, 8, 16, 31])
+def test_generic_matrix_core_path(cg, oracle, d):
+    """fp32: RQ, Cauchy, IMQ, MaternP(1..3), Dot^p, ExponentialDot and multi-RHS EQ on the matrix cores against the fp64 oracle and
+    against the direct-difference kernel (dense_variant = 1), ragged shapes, 1 / 3 / 9 right-hand sides, alpha / beta."""
+    rng = np.random.default_rng(900 + d)
+    wanted = {"EQ", "RQ(1.0)", "RQ(0.37)", "Cauchy", "IMQ(0.8)", "MaternP(1)", "MaternP(2)", "MaternP(3)", "2.5*Lengthscale(MaternP(2),1.3)",
+              "Dot()^3", "Dot()", "ExponentialDot", "EQ^2", "Lengthscale(EQ,0.7)"}
+    cases = [c for c in kernel_cases.cases(cg) if c[0] in wanted]
+    try:
+        for (n, m) in ((33, 31), (300, 1000)):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+            Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+            for p in (1, 3, 9):
+                A = rng.standard_normal((m, p)).astype(np.float32); Y0 = rng.standard_normal((n, p)).astype(np.float32)
+                if p == 1: A, Y0 = A[:, 0], Y0[:, 0]
+                for name, k, ko in cases:
+                    if p == 1 and name in ("EQ", "Lengthscale(EQ,0.7)"):
+                        continue                                   # single-RHS EQ has its own kernel and test
+                    G = cg.gramian(k, Xd, Yd)
+                    ref = oracle.mul(Y0, ko, X, Y, A, -0.7, 1.3, np.float32)
+                    got = {}
+                    for variant in (1, 2):
+                        cg.set_option("dense_variant", variant)
+                        yd = torch.from_numpy(Y0.copy()).cuda()
+                        cg.mul_(yd, G, torch.from_numpy(A).cuda(), -0.7, 1.3)
+                        assert cg.get_info("last_dense_path") == variant, (name, variant)
+                        got[variant] = yd.cpu().numpy()
+                        assert relerr(got[variant], ref) <= 1e-5, (name, d, n, p, variant, relerr(got[variant], ref))
+                    assert relerr(got[2], got[1]) <= 5e-6, (name, d, n, p)
+    finally:
+        cg.set_option("dense_variant", 0)
