@@ -557,3 +557,92 @@ def lowrank_mul(y, U, V, a, alpha=1.0, beta=0.0):
     if beta != 0:
         out = out + beta * np.asarray(y, dtype=np.float64)
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# Toeplitz direct solvers (src/toeplitz.jl:12-145) — SURVEY §8(f)-4.  Sequential O(n^2) recurrences; restated so that
+# the device's PCG-over-the-FFT-MVM solver (covgram.solve.toeplitz_solve) has a reference-faithful checker.
+# ----------------------------------------------------------------------------------------
+def durbin(r):
+    """toeplitz.jl:14-27: y = K \\ (-r), K = SymmetricToeplitz([1, r[1:end-1]]) (Golub & Van Loan alg. 4.7.1)."""
+    r = np.asarray(r, dtype=np.float64)
+    n = r.shape[0]
+    y = np.zeros(n)
+    y[0] = -r[0]
+    alpha, beta = -r[0], 1.0
+    for k in range(1, n):
+        beta *= (1 - alpha * alpha)
+        alpha = -(r[k] + np.dot(r[:k], y[:k][::-1])) / beta          # reverse_dot (toeplitz.jl:114-122)
+        y[:k] = y[:k] + alpha * y[:k][::-1]                          # reverse_increment! (toeplitz.jl:125-145)
+        y[k] = alpha
+    return y
+
+
+def levinson(r, b):
+    """toeplitz.jl:77-98: x = K \\ b, K = SymmetricToeplitz([1; r]) positive definite."""
+    r = np.asarray(r, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    n = r.shape[0] + 1
+    x = np.zeros(n); y = np.zeros(n)
+    y[0] = -r[0]; x[0] = b[0]
+    alpha, beta = -r[0], 1.0
+    for k in range(1, n):
+        beta *= (1 - alpha * alpha)
+        mu = (b[k] - np.dot(r[:k], x[:k][::-1])) / beta
+        x[:k] = x[:k] + mu * y[:k][::-1]
+        x[k] = mu
+        if k < n - 1:
+            alpha = -(r[k] + np.dot(r[:k], y[:k][::-1])) / beta
+            y[:k] = y[:k] + alpha * y[:k][::-1]
+            y[k] = alpha
+    return x
+
+
+def levinson_toeplitz(vc, b):
+    """toeplitz.jl:100-111 with the diagonal normalisation done right (the reference tests `r_0 == 1` where it means
+    `r_0 != 1`): T = r_0 * SymmetricToeplitz([1; vc[1:]/r_0])  =>  x = levinson(vc[1:]/r_0, b) / r_0."""
+    vc = np.asarray(vc, dtype=np.float64)
+    r0 = vc[0]
+    return levinson(vc[1:] / r0, b) / r0
+
+
+def trench(r):
+    """toeplitz.jl:57-71: inverse of K = SymmetricToeplitz([1; r]) (Golub & Van Loan alg. 4.7.3), full symmetric matrix."""
+    r = np.asarray(r, dtype=np.float64)
+    n = r.shape[0] + 1
+    y = durbin(r)
+    gamma = 1.0 / (1 + np.dot(r, y))
+    nu = gamma * y[::-1]
+    B = np.zeros((n, n))
+    B[0, 0] = gamma
+    B[0, 1:] = gamma * y
+    for j in range(1, n):
+        for i in range(1, j + 1):
+            B[i, j] = B[i - 1, j - 1] + (nu[n - 1 - j] * nu[n - 1 - i] - nu[i - 1] * nu[j - 1]) / gamma
+    return np.triu(B) + np.triu(B, 1).T
+
+
+# ----------------------------------------------------------------------------------------
+# Pivoted Cholesky (src/gramian.jl:192-213: cholesky(G, Val(true); tol) = LAPACK pstrf on Matrix(G)) — SURVEY §8(f)-3
+# ----------------------------------------------------------------------------------------
+def pivoted_cholesky(A, tol=0.0, max_rank=None):
+    """P' A P = L L' by diagonal pivoting, stopping when the largest remaining diagonal is <= tol (LAPACK dpstrf's rule for
+    a user tolerance >= 0).  Returns (L in ORIGINAL row order, n x rank; piv; rank)."""
+    A = np.array(A, dtype=np.float64)
+    n = A.shape[0]
+    max_rank = n if max_rank is None else min(max_rank, n)
+    d = np.diag(A).copy()
+    piv = np.arange(n)
+    L = np.zeros((n, max_rank))
+    rank = 0
+    for k in range(max_rank):
+        j = k + int(np.argmax(d[piv[k:]]))
+        if d[piv[j]] <= tol:
+            break
+        piv[[k, j]] = piv[[j, k]]
+        p = piv[k]
+        col = A[:, p] - L[:, :k] @ L[p, :k]
+        L[:, k] = col / np.sqrt(d[p])
+        d = d - L[:, k] ** 2
+        d[piv[:k + 1]] = 0.0
+        rank = k + 1
+    return L[:, :rank], piv, rank

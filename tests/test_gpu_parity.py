@@ -590,3 +590,62 @@ def test_generic_matrix_core_path(cg, oracle, d):
                     assert relerr(got[2], got[1]) <= 5e-6, (name, d, n, p)
     finally:
         cg.set_option("dense_variant", 0)
+
+
+# ---- (f)-3 / (f)-4: factorizations and Toeplitz solves on top of the hot path -------------------------------------------
+def test_cholesky_factorize_and_lazy_pivoted_cholesky(cg, oracle):
+    """cholesky / factorize (src/gramian.jl:192-213): dense tile + rocSOLVER, and the lazy pivoted variant that only ever
+    evaluates the diagonal and one Gramian column per step, against the oracle's dense pivoted Cholesky."""
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((300, 2))
+    Xd = torch.from_numpy(X).cuda()
+    G = cg.gramian(cg.EQ(), Xd)
+    M = oracle.matrix(oracle.Kernel(oracle.EQ), X)
+    P = cg.cholesky(G, pivoted=True, tol=1e-6)
+    Lo, pivo, ranko = oracle.pivoted_cholesky(M, tol=1e-6)
+    assert P.rank == ranko and P.piv.cpu().numpy()[:ranko].tolist() == pivo[:ranko].tolist()
+    assert np.abs(P.L.cpu().numpy() - Lo).max() <= 1e-8
+    assert np.abs(P.to_dense().cpu().numpy() - M).max() <= 300 * 1e-6
+    F = cg.factorize(G)                                          # n <= 2^14: pivoted Cholesky with tol = 1e-6
+    assert isinstance(F, cg.PivotedCholesky) and F.rank == ranko
+    assert cg.factorize(G, max_cholesky_size=100) is G           # too large to instantiate: stays lazy
+    # exact low rank is detected: Dot kernel in d = 3
+    Gd = cg.gramian(cg.Dot(), torch.from_numpy(rng.standard_normal((200, 3))).cuda())
+    assert cg.cholesky(Gd, pivoted=True, tol=1e-10).rank == 3
+    assert np.allclose(cg.diagonal(Gd).cpu().numpy(), np.diag(oracle.matrix(oracle.Kernel(oracle.DOT), Gd.x.cpu().numpy())), rtol=1e-13)
+    # plain Cholesky of a well-conditioned Gramian, and a solve through it
+    Xs = rng.standard_normal((200, 3))
+    Ge = cg.gramian(cg.Exp(), torch.from_numpy(Xs).cuda())
+    C = cg.cholesky(Ge)
+    Me = oracle.matrix(oracle.Kernel(oracle.EXP), Xs)
+    assert np.abs(C.L.cpu().numpy() - np.linalg.cholesky(Me)).max() <= 1e-10
+    b = rng.standard_normal(200)
+    assert relerr(C.solve(torch.from_numpy(b).cuda()).cpu().numpy(), np.linalg.solve(Me, b)) <= 1e-9
+    with pytest.raises(ValueError):                              # PosDefException with check = true (rank-deficient Dot Gramian)
+        cg.cholesky(Gd)
+
+
+@pytest.mark.parametrize("n", [257, 4096])
+def test_toeplitz_solve_pcg_vs_levinson(cg, oracle, n):
+    """T \\ b for SPD Toeplitz Gramians: PCG over the FFT MVM with a circulant preconditioner against the oracle's
+    restatement of the reference's Levinson recursion (src/toeplitz.jl:77-111), diagonal != 1 included."""
+    rng = np.random.default_rng(n)
+    b = rng.standard_normal(n)
+    bd = torch.from_numpy(b).cuda()
+    for k, ko in ((cg.Exp(), oracle.Kernel(oracle.EXP)), (2.5 * cg.Lengthscale(cg.Exp(), 0.3), oracle.Kernel(oracle.EXP, lengthscale=0.3, scale=2.5))):
+        T = cg.gramian(k, cg.srange(-1, 1, n))
+        assert isinstance(T, cg.SymmetricToeplitz)
+        x, info = cg.toeplitz_solve(T, bd, reltol=1e-13)
+        vc, _ = oracle.toeplitz_vectors(ko, oracle.srange(-1, 1, n))
+        ref = oracle.levinson_toeplitz(vc, b)
+        assert info["converged"] and info["iterations"] <= 25, info     # the circulant preconditioner clusters the spectrum
+        assert relerr(x.cpu().numpy(), ref) <= 1e-8, (n, relerr(x.cpu().numpy(), ref), info)
+        r = (T @ x).cpu().numpy() - b                                  # residual through the hot path
+        assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)
+    # a smoother kernel plus a nugget (the GP-regression system K + sigma^2 I): built from its first column directly
+    ko = oracle.Kernel(oracle.MATERNP, p=1, lengthscale=0.3)
+    vc, _ = oracle.toeplitz_vectors(ko, oracle.srange(-1, 1, n))
+    vc = vc.copy(); vc[0] += 0.05
+    T = cg.SymmetricToeplitz(torch.from_numpy(vc).cuda())
+    x, info = cg.toeplitz_solve(T, bd, reltol=1e-12)
+    assert info["converged"] and relerr(x.cpu().numpy(), oracle.levinson_toeplitz(vc, b)) <= 1e-8, info

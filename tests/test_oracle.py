@@ -199,6 +199,35 @@ def test_golden_composite_and_value_gradient():
         assert np.abs(M - M.T).max() < 1e-12 * max(1.0, np.abs(M).max())
 
 
+def test_toeplitz_direct_solvers_and_pivoted_cholesky():
+    """test/toeplitz.jl:7-42 on the restated durbin / trench / levinson (src/toeplitz.jl:12-111), plus the diagonal
+    normalisation the reference gets wrong (r_0 != 1), and the pivoted-Cholesky restatement (src/gramian.jl:192-199)."""
+    n = 16
+    x = np.linspace(-1, 1, n + 1)
+    rng = np.random.default_rng(2)
+    for a in (rng.random(n + 1) / n, np.exp(-np.abs(x[0] - x)), np.exp(-np.abs(x[0] - x) ** 2) / 2):
+        a = a.copy(); a[0] = 1.0
+        r = a[1:]
+        K = o.toeplitz_dense(np.concatenate([[1.0], r[:-1]]))
+        assert np.allclose(-np.linalg.solve(K, r), o.durbin(r), rtol=1e-9, atol=1e-12)              # test/toeplitz.jl:21-25
+        assert np.allclose(o.trench(r[:-1]), np.linalg.inv(K), rtol=1e-8, atol=1e-10)               # :27-29
+        r2 = a[:-1][1:]; b = rng.standard_normal(n)
+        K2 = o.toeplitz_dense(np.concatenate([[1.0], r2]))
+        assert np.allclose(np.linalg.solve(K2, b), o.levinson(r2, b), rtol=1e-9, atol=1e-12)        # :31-40
+        vc = 2.5 * np.concatenate([[1.0], r2])                                                      # r_0 != 1
+        assert np.allclose(np.linalg.solve(2.5 * K2, b), o.levinson_toeplitz(vc, b), rtol=1e-9, atol=1e-12)
+    X = rng.standard_normal((60, 2))
+    G = o.matrix(o.Kernel(o.EQ), X)
+    L, piv, rank = o.pivoted_cholesky(G, tol=1e-6)
+    assert rank < 60 and sorted(piv.tolist()) == list(range(60))
+    assert np.abs(G - L @ L.T).max() <= 60 * 1e-6                                                  # every remaining diagonal <= tol
+    assert np.allclose(np.triu(L[piv][:rank], 1), 0)                                                # P'L is lower trapezoidal
+    Gd = o.matrix(o.Kernel(o.DOT), rng.standard_normal((30, 3)))                                   # exact rank 3
+    assert o.pivoted_cholesky(Gd, tol=1e-10)[2] == 3
+    Lf, _, rf = o.pivoted_cholesky(G + 1e-3 * np.eye(60), tol=0.0)                                  # full rank: plain Cholesky up to P
+    assert rf == 60 and np.allclose(Lf @ Lf.T, G + 1e-3 * np.eye(60), atol=1e-12)
+
+
 def test_profile_derivatives_against_mpmath():
     import mpmath as mp
     mp.mp.dps = 40
