@@ -682,8 +682,6 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(hk.tu_family);
-    CG_REQUIRE(!(vg && wide), COVGRAM_EUNSUPPORTED, "valgrad_mvm: d = %d exceeds the lane-per-row limit %d of this dtype", d,
-               dtype == COVGRAM_F64 ? 48 : 64);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return COVGRAM_OK;
 
@@ -723,16 +721,21 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         for (int64_t col0 = 0; col0 < mpad; col0 += panel) {
             const int64_t pc = std::min<int64_t>(panel, mpad - col0);
             void *P, *C;
-            rc = ws_reserve(ctx, 0, (size_t)pc * D * 2 * ts, &P); if (rc) return rc;
-            rc = ws_reserve(ctx, 1, (size_t)pc * npad64 * 2 * ts, &C); if (rc) return rc;
+            // stream + (value-gradient) the columns' value weights; coefficient slabs C1, C2 + the value row's block partials C0
+            rc = ws_reserve(ctx, 0, (size_t)pc * (D * 2 + vg) * ts, &P); if (rc) return rc;
+            rc = ws_reserve(ctx, 1, ((size_t)pc * 2 + (vg ? (size_t)(pc / BC) : 0)) * npad64 * ts, &C); if (rc) return rc;
+            void* A0P = vg ? (void*)((char*)P + (size_t)pc * D * 2 * ts) : nullptr;
+            void* C0 = vg ? (void*)((char*)C + (size_t)pc * 2 * npad64 * ts) : nullptr;
             const int64_t pe = pc * (int64_t)D;
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(grad_wide_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const float*)Y->dptr, m, d, D, (const float*)a_dev, col0, pc, (float*)P, PKN, (float)hk.kp.gamma);
+                                   (const float*)Y->dptr, m, d, D, (const float*)a_dev, col0, pc, (float*)P, PKN, (float)hk.kp.gamma, vg, (float*)A0P);
             else
                 hipLaunchKernelGGL(grad_wide_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma);
+                                   (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma, vg, (double*)A0P);
             GradWideArgs wa;
+            wa.vg = vg; wa.A0P = A0P; wa.C0 = C0; wa.alpha0 = alpha0;
+            wa.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma; wa.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
             wa.X = X->dptr; wa.n = n; wa.d = d; wa.dpad = D; wa.P = P; wa.C1 = C; wa.C2 = (char*)C + (size_t)pc * npad64 * ts;
             wa.npad = npad64; wa.nblocks = pc / BC; wa.y = y_dev; wa.alpha = alpha_eff; wa.beta = beta; wa.accumulate = col0 > 0 ? 1 : 0;
             wa.hk = &hk; wa.stream = ctx->stream;

@@ -23,7 +23,7 @@ constexpr int GJG = 16;   // column groups per block (fp32: 32 columns, fp64: 16
 template <typename T>
 __global__ __launch_bounds__(256) void grad_wide_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, int32_t dpad,
                                                              const T* __restrict__ A, int64_t col0, int64_t pcols,
-                                                             T* __restrict__ P, int32_t PKN, T gamma) {
+                                                             T* __restrict__ P, int32_t PKN, T gamma, int32_t vg, T* __restrict__ A0P) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (panel column, coordinate)
     if (e >= pcols * (int64_t)dpad) return;
     const int64_t jp = e / dpad;
@@ -40,14 +40,19 @@ __global__ __launch_bounds__(256) void grad_wide_pack_kernel(const T* __restrict
     T* base = P + blk * (int64_t)nch * 2 * GJG * WIDE_CH * PKN;
     const bool real = sl < d;
     base[(((int64_t)(ch * 2 + 0) * GJG + g) * WIDE_CH + ll) * PKN + h] = real ? Y[j * (int64_t)d + sl] * gamma : (T)0;
-    base[(((int64_t)(ch * 2 + 1) * GJG + g) * WIDE_CH + ll) * PKN + h] = (real && !pad) ? A[j * (int64_t)d + sl] : (T)0;
+    base[(((int64_t)(ch * 2 + 1) * GJG + g) * WIDE_CH + ll) * PKN + h] = (real && !pad) ? A[j * (int64_t)(d + vg) + vg + sl] : (T)0;
+    // value-gradient blocks: the value weight of each column, [block][group][packed column]
+    if (vg && sl == 0) A0P[(blk * GJG + g) * PKN + h] = pad ? (T)0 : A[j * (int64_t)(d + 1)];
 }
 
-template <typename T, int FAM, bool POW>
+// VG: ValueGradientKernel blocks (grad_mvm.hpp): c2 gets + vg_c k1 a0, and the value row's partial sum of this column
+// block, sum_j (k0 a0 + vg_b k1 t), goes to C0[block][row] for the apply kernel to add up.
+template <typename T, int FAM, bool POW, bool VG>
 __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict__ X, int64_t n, int32_t d, int32_t dpad,
                                                             const typename Pk<T>::V* __restrict__ P,
                                                             typename Pk<T>::V* __restrict__ C1, typename Pk<T>::V* __restrict__ C2,
-                                                            int64_t npad, const typename ParamsOf<FAM, T>::type kp) {
+                                                            int64_t npad, const typename Pk<T>::V* __restrict__ A0P, T* __restrict__ C0,
+                                                            T vg_c, T vg_b, const typename ParamsOf<FAM, T>::type kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -96,25 +101,37 @@ __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict_
         }
     }
     if (srow >= n) return;
+    T b0 = (T)0;
 #pragma unroll
     for (int g = 0; g < GJG; ++g) {
         V c1, c2;
+        const T f = ISO ? (T)2 : (T)1;
         if constexpr (PK::N == 2) {
-            T k1x, k2x, k1y, k2y;
-            phi_derivs<FAM, T, POW>(s[g].x, kp, k1x, k2x);
-            phi_derivs<FAM, T, POW>(s[g].y, kp, k1y, k2y);
-            const T f = ISO ? (T)2 : (T)1;
+            T k0x, k0y, k1x, k2x, k1y, k2y;
+            phi_jet<FAM, T, POW>(s[g].x, kp, k0x, k1x, k2x);
+            phi_jet<FAM, T, POW>(s[g].y, kp, k0y, k1y, k2y);
             c1 = V{k1x, k1y};
             c2 = V{f * k2x * t[g].x, f * k2y * t[g].y};
+            if constexpr (VG) {
+                const V a0 = A0P[b * GJG + g];
+                c2 = V{cg_fma(vg_c * k1x, a0.x, c2.x), cg_fma(vg_c * k1y, a0.y, c2.y)};
+                b0 += cg_fma(k0x, a0.x, vg_b * k1x * t[g].x) + cg_fma(k0y, a0.y, vg_b * k1y * t[g].y);
+            }
         } else {
-            T k1, k2;
-            phi_derivs<FAM, T, POW>(s[g], kp, k1, k2);
+            T k0, k1, k2;
+            phi_jet<FAM, T, POW>(s[g], kp, k0, k1, k2);
             c1 = k1;
-            c2 = (ISO ? (T)2 : (T)1) * k2 * t[g];
+            c2 = f * k2 * t[g];
+            if constexpr (VG) {
+                const V a0 = A0P[b * GJG + g];
+                c2 = cg_fma(vg_c * k1, a0, c2);
+                b0 += cg_fma(k0, a0, vg_b * k1 * t[g]);
+            }
         }
         C1[(b * GJG + g) * npad + srow] = c1;
         C2[(b * GJG + g) * npad + srow] = c2;
     }
+    if constexpr (VG) C0[b * npad + srow] = b0;
 }
 
 template <typename T, bool ISO>
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
                                                              const typename Pk<T>::V* __restrict__ C1,
                                                              const typename Pk<T>::V* __restrict__ C2, int64_t npad,
                                                              int64_t nblocks, T* __restrict__ y, T alpha, T beta, int32_t accumulate,
-                                                             T gamma) {
+                                                             T gamma, int32_t vg, const T* __restrict__ C0, T alpha0) {
     using PK = Pk<T>;
     using V = typename PK::V;
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -159,7 +176,16 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
             }
         }
     }
-    T* yp = y + row * (int64_t)d + l0;
+    if (vg && ch == 0) {                                    // value row: add up the column blocks' partial sums
+        T b0 = (T)0;
+        for (int64_t b = 0; b < nblocks; ++b) b0 += C0[b * npad + row];
+        T* y0 = y + row * (int64_t)(d + 1);
+        T v = alpha0 * b0;
+        if (accumulate) v += *y0;
+        else if (beta != (T)0) v = cg_fma(beta, *y0, v);
+        *y0 = v;
+    }
+    T* yp = y + row * (int64_t)(d + vg) + vg + l0;
 #pragma unroll
     for (int l = 0; l < WIDE_CH; ++l) {
         if (l0 + l < d) {
@@ -175,6 +201,7 @@ struct GradWideArgs {
     const void* X; int64_t n; int32_t d; int32_t dpad;
     const void* P; void* C1; void* C2; int64_t npad; int64_t nblocks;
     void* y; double alpha, beta; int32_t accumulate;
+    int32_t vg = 0; const void* A0P = nullptr; void* C0 = nullptr; double alpha0 = 0, vg_c = 0, vg_b = 0;
     const HostKernel* hk;
     hipStream_t stream;
 };
@@ -186,15 +213,16 @@ static int launch_grad_wide_T(const GradWideArgs& a) {
     const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     const unsigned rb = (unsigned)((a.n + 63) / 64);
     const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
-    if (pow)
-        hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, !fam_is_expr<FAM>>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
-                           a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, kp);
-    else
-        hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, false>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
-                           a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, kp);
+    constexpr bool POWT = !fam_is_expr<FAM>;
+#define CG_COEF_LAUNCH(POWV, VGV)                                                                                                       \
+    hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, POWV, VGV>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, \
+                       a.d, a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, (const V*)a.A0P, (T*)a.C0, (T)a.vg_c, (T)a.vg_b, kp)
+    if (a.vg) { if (pow) CG_COEF_LAUNCH(POWT, true); else CG_COEF_LAUNCH(false, true); }
+    else { if (pow) CG_COEF_LAUNCH(POWT, false); else CG_COEF_LAUNCH(false, false); }
+#undef CG_COEF_LAUNCH
     hipLaunchKernelGGL((grad_wide_apply_kernel<T, ISO>), dim3(rb, (unsigned)(a.dpad / WIDE_CH)), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
                        a.dpad, (const V*)a.P, (const V*)a.C1, (const V*)a.C2, a.npad, a.nblocks, (T*)a.y, (T)a.alpha, (T)a.beta,
-                       a.accumulate, kp.gamma);
+                       a.accumulate, kp.gamma, a.vg, (const T*)a.C0, (T)a.alpha0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_wide launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -486,10 +486,20 @@ def test_value_gradient_golden_and_limits(cg, oracle):
                 bd = torch.from_numpy(yv0.copy()).cuda()
                 cg.mul_(bd, cg.gramian(cg.ValueGradientKernel(k), Xd, Yd), torch.from_numpy(av).cuda(), alpha, beta)
                 assert relerr(bd.cpu().numpy(), g[f"{tag}_{gname}_bv"]) <= 1e-12, (gname, tag)
-    # beyond the lane-per-row limit there is no value-gradient kernel yet: loud, not silent
-    Xw = torch.randn(10, 70, dtype=torch.float64, device="cuda")
-    with pytest.raises(cg.UnsupportedKernel):
-        cg.gramian(cg.ValueGradientKernel(cg.EQ()), Xw) @ torch.randn(10 * 71, dtype=torch.float64, device="cuda")
+    # beyond the lane-per-row limit (d > 48 fp64 / 64 fp32) the panel kernels of grad_wide.hpp carry the value row as well
+    rng = np.random.default_rng(31)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 3e-5)):
+        for d in (70, 130):
+            n, m = 90, 150
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(dt)
+            a = rng.standard_normal(m * (d + 1)).astype(dt); b0 = rng.standard_normal(n * (d + 1)).astype(dt)
+            for name in ("EQ", "MaternP(2)", "Dot()^3", "iso_sum_of_products"):
+                _, k, ko = byname[name]
+                K = cg.gramian(cg.ValueGradientKernel(k), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+                bd = torch.from_numpy(b0.copy()).cuda()
+                cg.mul_(bd, K, torch.from_numpy(a).cuda(), 0.8, -0.3)
+                ref = oracle.valgrad_mul(b0, ko, X, Y, a, 0.8, -0.3, dt)
+                assert relerr(bd.cpu().numpy(), ref) <= tol, (name, d, dt, relerr(bd.cpu().numpy(), ref))
 
 
 # ---- the matrix-core EQ path (dense_mfma.hip) ---------------------------------------------------------------------------
