@@ -102,10 +102,32 @@ __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict_
     }
     if (srow >= n) return;
     T b0 = (T)0;
+    const T f = ISO ? (T)2 : (T)1;
+    if constexpr (fam_is_expr<FAM>) {
+        // composites: the jets of 4 column groups at a time, factor-outer (profiles.hpp: expr_jet_block)
+        constexpr int BG = 4;
+#pragma unroll
+        for (int g0 = 0; g0 < GJG; g0 += BG) {
+            V sb[BG], k0[BG], k1[BG], k2[BG];
+#pragma unroll
+            for (int g = 0; g < BG; ++g) sb[g] = s[g0 + g];
+            expr_jet_block<T, ISO, BG>(sb, kp, k0, k1, k2);
+#pragma unroll
+            for (int g = 0; g < BG; ++g) {
+                V c2 = PK::splat(f) * k2[g] * t[g0 + g];
+                if constexpr (VG) {
+                    const V a0 = A0P[b * GJG + g0 + g];
+                    c2 = PK::fma(PK::splat(vg_c) * k1[g], a0, c2);
+                    b0 += PK::hsum(PK::fma(k0[g], a0, PK::splat(vg_b) * k1[g] * t[g0 + g]));
+                }
+                C1[(b * GJG + g0 + g) * npad + srow] = k1[g];
+                C2[(b * GJG + g0 + g) * npad + srow] = c2;
+            }
+        }
+    } else {
 #pragma unroll
     for (int g = 0; g < GJG; ++g) {
         V c1, c2;
-        const T f = ISO ? (T)2 : (T)1;
         if constexpr (PK::N == 2) {
             T k0x, k0y, k1x, k2x, k1y, k2y;
             phi_jet<FAM, T, POW>(s[g].x, kp, k0x, k1x, k2x);
@@ -130,6 +152,7 @@ __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict_
         }
         C1[(b * GJG + g) * npad + srow] = c1;
         C2[(b * GJG + g) * npad + srow] = c2;
+    }
     }
     if constexpr (VG) C0[b * npad + srow] = b0;
 }

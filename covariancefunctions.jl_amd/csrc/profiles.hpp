@@ -371,6 +371,57 @@ __device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& 
         v += p0; d1 += p1; d2 += p2;
     }
 }
+// The composite jet for a block of BG column groups, factor-outer (the gradient counterpart of expr_accumulate_block):
+// parameters and family dispatch once per factor and block.
+template <typename T, bool ISO, int BG>
+__device__ __forceinline__ void expr_jet_block(const typename Pk<T>::V (&s)[BG], const ExprParams<T>& ep,
+                                               typename Pk<T>::V (&v)[BG], typename Pk<T>::V (&d1)[BG], typename Pk<T>::V (&d2)[BG]) {
+    using PK = Pk<T>;
+    using V = typename PK::V;
+#pragma unroll
+    for (int g = 0; g < BG; ++g) { v[g] = PK::splat((T)0); d1[g] = PK::splat((T)0); d2[g] = PK::splat((T)0); }
+    int fi = 0;
+    for (int t = 0; t < ep.nterms; ++t) {
+        V p0[BG], p1[BG], p2[BG];
+#pragma unroll
+        for (int g = 0; g < BG; ++g) { p0[g] = PK::splat(ep.coef[t]); p1[g] = PK::splat((T)0); p2[g] = PK::splat((T)0); }
+        for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
+            const KParams<T>& q = ep.f[fi];
+            const T g2 = ISO ? q.gamma2 : (T)1;
+            const int pw = q.power;
+#define CG_JET_CASE(F)                                                                                              \
+    case F:                                                                                                         \
+        _Pragma("unroll") for (int g = 0; g < BG; ++g) {                                                            \
+            V fv, f1, f2;                                                                                           \
+            PK::map3(s[g], [&](T sv, T& a0, T& a1, T& a2) {                                                         \
+                DPhi<F, T>::eval(sv * g2, q, a0, a1, a2);                                                           \
+                if (pw != 1) power_jet(pw, a0, a1, a2);                                                             \
+                a1 *= g2; a2 *= g2 * g2;                                                                            \
+            }, fv, f1, f2);                                                                                         \
+            p2[g] = p2[g] * fv + PK::splat((T)2) * p1[g] * f1 + p0[g] * f2;                                         \
+            p1[g] = p1[g] * fv + p0[g] * f1;                                                                        \
+            p0[g] = p0[g] * fv;                                                                                     \
+        }                                                                                                           \
+        break;
+            switch (ep.fam[fi]) {
+                CG_JET_CASE(COVGRAM_EQ)
+                CG_JET_CASE(COVGRAM_EXP)
+                CG_JET_CASE(COVGRAM_RQ)
+                CG_JET_CASE(COVGRAM_GAMMAEXP)
+                CG_JET_CASE(COVGRAM_CAUCHY)
+                CG_JET_CASE(COVGRAM_IMQ)
+                CG_JET_CASE(COVGRAM_MATERNP)
+                CG_JET_CASE(COVGRAM_EXPDOT)
+                default:
+                    CG_JET_CASE(COVGRAM_DOT)
+            }
+#undef CG_JET_CASE
+        }
+#pragma unroll
+        for (int g = 0; g < BG; ++g) { v[g] = v[g] + p0[g]; d1[g] = d1[g] + p1[g]; d2[g] = d2[g] + p2[g]; }
+    }
+}
+
 template <typename T>
 struct DPhi<FAM_EXPR_ISO, T> {
     static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, true>(s, ep, v, d1, d2); }
