@@ -360,6 +360,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     CG_REQUIRE(ctx->live_handles == 0, COVGRAM_EINVAL, "ctx destroyed with %d live handles", ctx->live_handles);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx_blas_destroy(ctx);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
     for (auto& t : ctx->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

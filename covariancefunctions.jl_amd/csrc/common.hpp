@@ -148,6 +148,7 @@ struct covgram_ctx {
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int num_cus = 256;
+    void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
@@ -219,6 +220,8 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);
+
+void ctx_blas_destroy(covgram_ctx* ctx);
 
 int pad_dim(int d);          // next compiled D >= d, or -1
 extern const int kDims[];    // compiled D list

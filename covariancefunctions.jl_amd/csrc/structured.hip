@@ -5,103 +5,18 @@
 // (src/separable.jl:33-42); the MVM is KroneckerProducts 1.1.1 (third party, source not in the
 // reference tree) — restated from the identity it implements: with a viewed as a c_1×...×c_q tensor
 // (first factor = slowest index), (F_1 ⊗ ... ⊗ F_q) a = a ×_1 F_1 ×_2 F_2 ... ×_q F_q (mode products).
-// Each mode product is a batched small GEMM  Out[b] (r_k × post) = F_k (r_k × c_k) · T[b] (c_k × post).
+// Each mode product is a batched small GEMM  Out[b] (r_k × post) = F_k (r_k × c_k) · T[b] (c_k × post): rocBLAS.
 //
 // Low rank: gramian(k::FiniteBasis, x, y) = LazyMatrixProduct(U, V') (src/mercer.jl:61-70) whose
 // mul! applies the factors right to left (src/lazy_linear_algebra.jl:78-85): y = α U (Vᵀ a) + β y.
 // For a vector right-hand side both products are GEMVs, i.e. HBM-streaming of U and V.
 #include <algorithm>
 
+#include <rocblas/rocblas.h>
+
 #include "common.hpp"
 
 namespace covgram {
-
-// Mode product as a batched GEMM with generic strides:
-//     C[b][i][j] = sum_k F[i + k*ldf] * B[b*sBb + k*sBk + j*sBj],      C address = b*sCb + i*sCi + j*sCj
-// 64×64 output tile per workgroup, 4×4 outputs per thread, K in slabs of 16 staged through LDS.  JCONTIG selects the
-// thread->element map of the B-tile loads and C-tile stores so that the unit-stride index runs along the lanes:
-//   JCONTIG = true : sBj == sCj == 1 (all modes but the last: "post" is contiguous)
-//   JCONTIG = false: sBk == sCi == 1 (the last mode, post == 1: the mode's own index is contiguous; columns j are the batches)
-// HBM-bound for the small factors of a Kronecker Gramian (each mode reads and writes the whole tensor once).
-template <typename T, bool JCONTIG>
-__global__ __launch_bounds__(256) void mode_product_kernel(const T* __restrict__ F, int64_t ldf, int64_t M, int64_t K,
-                                                           const T* __restrict__ B, T* __restrict__ C, int64_t N, int64_t sBb,
-                                                           int64_t sBk, int64_t sBj, int64_t sCb, int64_t sCi, int64_t sCj) {
-    constexpr int BM = 64, BN = 64, BK = 16;
-    __shared__ T sF[BK][BM + 1];
-    __shared__ T sB[BK][BN + 1];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;                  // 16 × 16 threads, each a 4×4 micro-tile (strided by 16)
-    const int64_t b = blockIdx.z;
-    const int64_t i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
-    const T* Bb = B + b * sBb;
-    T* Cb = C + b * sCb;
-    T acc[4][4];
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = (T)0;
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        // F tile: i fastest (column-major F)
-#pragma unroll
-        for (int e = tid; e < BM * BK; e += 256) {
-            const int i = e & (BM - 1), k = e >> 6;
-            sF[k][i] = (i0 + i < M && k0 + k < K) ? F[(i0 + i) + (k0 + k) * ldf] : (T)0;
-        }
-        // B tile
-#pragma unroll
-        for (int e = tid; e < BN * BK; e += 256) {
-            int j, k;
-            if constexpr (JCONTIG) { j = e & (BN - 1); k = e >> 6; }
-            else { k = e & (BK - 1); j = e >> 4; }
-            sB[k][j] = (j0 + j < N && k0 + k < K) ? Bb[(k0 + k) * sBk + (j0 + j) * sBj] : (T)0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            T fv[4], bv[4];
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) fv[ii] = sF[k][ty + 16 * ii];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bv[jj] = sB[k][tx + 16 * jj];
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_fma(fv[ii], bv[jj], acc[ii][jj]);
-        }
-        __syncthreads();
-    }
-    if constexpr (JCONTIG) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int64_t i = i0 + ty + 16 * ii, j = j0 + tx + 16 * jj;      // tx (lanes) along j: unit stride
-                if (i < M && j < N) Cb[i * sCi + j * sCj] = acc[ii][jj];
-            }
-    } else {
-        // unit stride is along i: transpose the micro-tiles through LDS so that lanes run along i
-        __shared__ T sC[BN][BM + 1];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) sC[tx + 16 * jj][ty + 16 * ii] = acc[ii][jj];
-        __syncthreads();
-        for (int e = tid; e < BM * BN; e += 256) {
-            const int i = e & (BM - 1), j = e >> 6;
-            if (i0 + i < M && j0 + j < N) Cb[(i0 + i) * sCi + (j0 + j) * sCj] = sC[j][i];
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ t, T* __restrict__ y, int64_t n, T alpha, T beta) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    T v = alpha * t[i];
-    if (beta != (T)0) v = __builtin_fma(beta, y[i], v);
-    y[i] = v;
-}
 
 // z[k] (+)= sum_{j in slab} V[j + k*ldv] a[j]; one workgroup per (column k, row slab); deterministic two-stage sum
 template <typename T>
@@ -141,12 +56,46 @@ __global__ __launch_bounds__(256) void lowrank_uz_kernel(const T* __restrict__ U
     y[i] = v;
 }
 
+// rocBLAS handle of a ctx (created on first use; every call re-binds the ctx stream)
+static int blas_handle(covgram_ctx* ctx, rocblas_handle* out) {
+    if (!ctx->blas) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return COVGRAM_EHIP; }
+        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+        ctx->blas = h;
+    }
+    *out = (rocblas_handle)ctx->blas;
+    if (rocblas_set_stream(*out, ctx->stream) != rocblas_status_success) { set_error("rocblas_set_stream failed"); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+void ctx_blas_destroy(covgram_ctx* ctx) {
+    if (ctx->blas) { (void)rocblas_destroy_handle((rocblas_handle)ctx->blas); ctx->blas = nullptr; }
+}
+
+static rocblas_status gemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int64_t m, int64_t n, int64_t k, float alpha,
+                              const float* A, int64_t lda, int64_t sa, const float* B, int64_t ldb, int64_t sb, float beta, float* C, int64_t ldc,
+                              int64_t sc, int64_t batch) {
+    return rocblas_sgemm_strided_batched(h, ta, tb, (rocblas_int)m, (rocblas_int)n, (rocblas_int)k, &alpha, A, (rocblas_int)lda, sa, B,
+                                         (rocblas_int)ldb, sb, &beta, C, (rocblas_int)ldc, sc, (rocblas_int)batch);
+}
+static rocblas_status gemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int64_t m, int64_t n, int64_t k, double alpha,
+                              const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C,
+                              int64_t ldc, int64_t sc, int64_t batch) {
+    return rocblas_dgemm_strided_batched(h, ta, tb, (rocblas_int)m, (rocblas_int)n, (rocblas_int)k, &alpha, A, (rocblas_int)lda, sa, B,
+                                         (rocblas_int)ldb, sb, &beta, C, (rocblas_int)ldc, sc, (rocblas_int)batch);
+}
+
+// (F_1 (x) ... (x) F_q) a by successive mode products.  Each one is a plain strided-batched GEMM — the tensor viewed as
+// [pre][K][post] with `post` contiguous is, per `pre`, a column-major (post x K) matrix S, and the product is S F_k^T — so it
+// goes to rocBLAS (the first version used a hand-written 64x64 register-tiled kernel: 47 us per mode on the README's 128^3
+// fp64 case, 15 % of the fp64 peak).  The last mode applies alpha / beta and writes y directly.
 template <typename T>
 static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols, const int64_t* lds,
                     int q, const T* a_dev, T* y_dev, T alpha, T beta, T* bufA, T* bufB) {
-    // current tensor dims: first the already-multiplied modes (rows), then the remaining (cols)
-    int64_t cur = 1;
-    for (int i = 0; i < q; ++i) cur *= cols[i];
+    rocblas_handle h;
+    int rc = blas_handle(ctx, &h);
+    if (rc) return rc;
     const T* src = a_dev;
     T* dst = bufA;
     for (int k = 0; k < q; ++k) {
@@ -154,30 +103,19 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
         for (int i = 0; i < k; ++i) pre *= rows[i];
         for (int i = k + 1; i < q; ++i) post *= cols[i];
         const int64_t M = rows[k], K = cols[k];
-        if (post >= 16 || pre == 1) {
-            // tensor viewed as [pre][K][post]: columns j = the contiguous trailing index, batches = pre
-            dim3 grid((unsigned)((post + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)pre);
-            hipLaunchKernelGGL((mode_product_kernel<T, true>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
-                               post, K * post, post, (int64_t)1, M * post, post, (int64_t)1);
-        } else if (post == 1) {
-            // last mode: [pre][K] -> [pre][M]; columns j = the batches, unit stride along the mode's own index
-            dim3 grid((unsigned)((pre + 63) / 64), (unsigned)((M + 63) / 64), 1u);
-            hipLaunchKernelGGL((mode_product_kernel<T, false>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
-                               pre, (int64_t)0, (int64_t)1, K, (int64_t)0, (int64_t)1, M);
-        } else {
-            // small trailing extent (tiny tensors): same kernel, short rows
-            dim3 grid((unsigned)((post + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)pre);
-            hipLaunchKernelGGL((mode_product_kernel<T, true>), grid, dim3(256), 0, ctx->stream, (const T*)factors[k], lds[k], M, K, src, dst,
-                               post, K * post, post, (int64_t)1, M * post, post, (int64_t)1);
-        }
+        const bool last = (k == q - 1);
+        T* out = last ? y_dev : dst;
+        const T al = last ? alpha : (T)1, be = last ? beta : (T)0;
+        rocblas_status st;
+        if (post == 1)      // [pre][K] -> [pre][M]: one GEMM  out (M x pre) = F (M x K) * src (K x pre)
+            st = gemm_sb(h, rocblas_operation_none, rocblas_operation_none, M, pre, K, al, (const T*)factors[k], lds[k], 0, src, K, 0, be, out, M, 0, 1);
+        else                // per pre: out (post x M) = S (post x K) * F^T
+            st = gemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, post, M, K, al, src, post, K * post, (const T*)factors[k], lds[k], 0,
+                         be, out, post, M * post, pre);
+        if (st != rocblas_status_success) { set_error("kron_mvm: rocBLAS gemm failed with status %d (mode %d)", (int)st, k); return COVGRAM_EHIP; }
         src = dst;
         dst = (dst == bufA) ? bufB : bufA;
     }
-    int64_t nout = 1;
-    for (int i = 0; i < q; ++i) nout *= rows[i];
-    hipLaunchKernelGGL(axpby_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, ctx->stream, src, y_dev, nout, alpha, beta);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("kron_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
 }
 
