@@ -719,6 +719,14 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         int64_t panel = (((int64_t)256 << 20) / (npad64 * 2 * (int64_t)ts)) / BC * BC;   // coefficient slab <= 256 MB
         panel = std::max<int64_t>(BC, std::min<int64_t>(panel, mpad));
         grad_wide_launch_fn wlaunch = grad_wide_launcher(hk.tu_family);
+        // (row blocks x dimension chunks) waves may not fill the chip: split each panel's column blocks over z slices that
+        // accumulate raw sums into their own output slabs, reduced in fixed order after the last panel
+        const int64_t waves = (npad64 / 64) * (D / 32);
+        int zs = (int)std::min<int64_t>(16, std::max<int64_t>(1, ((int64_t)ctx->num_cus * 16 + waves - 1) / waves));
+        zs = (int)std::min<int64_t>(zs, std::max<int64_t>(1, panel / BC));
+        void* zslab = nullptr;
+        const int64_t total = n * (int64_t)bd;
+        if (zs > 1) { rc = ws_reserve(ctx, 4, (size_t)zs * total * ts, &zslab); if (rc) return rc; }
         for (int64_t col0 = 0; col0 < mpad; col0 += panel) {
             const int64_t pc = std::min<int64_t>(panel, mpad - col0);
             void *P, *C;
@@ -735,15 +743,25 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
                 hipLaunchKernelGGL(grad_wide_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                    (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma, vg, (double*)A0P);
             GradWideArgs wa;
-            wa.vg = vg; wa.A0P = A0P; wa.C0 = C0; wa.alpha0 = alpha0;
+            wa.vg = vg; wa.A0P = A0P; wa.C0 = C0; wa.alpha0 = zs > 1 ? 1.0 : alpha0;
             wa.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma; wa.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
             wa.X = X->dptr; wa.n = n; wa.d = d; wa.dpad = D; wa.P = P; wa.C1 = C; wa.C2 = (char*)C + (size_t)pc * npad64 * ts;
             wa.npad = npad64; wa.nblocks = pc / BC; wa.y = y_dev; wa.alpha = alpha_eff; wa.beta = beta; wa.accumulate = col0 > 0 ? 1 : 0;
+            if (zs > 1) { wa.zs = zs; wa.zstride = total; wa.y = zslab; wa.alpha = 1.0; wa.beta = 0.0; }
             wa.hk = &hk; wa.stream = ctx->stream;
             auto* tm = timer_next(ctx);
             if (tm) (void)hipEventRecord(tm->first, ctx->stream);
             rc = wlaunch(wa, dtype); if (rc) return rc;
             if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+        }
+        if (zs > 1) {
+            const dim3 zg((unsigned)((n + 255) / 256), (unsigned)bd);
+            if (dtype == COVGRAM_F32)
+                hipLaunchKernelGGL(grad_wide_reduce_kernel<float>, zg, dim3(256), 0, ctx->stream, (const float*)zslab, zs, total, n, (float*)y_dev,
+                                   (float)alpha_eff, (float)beta, vg, bd, (float)alpha0);
+            else
+                hipLaunchKernelGGL(grad_wide_reduce_kernel<double>, zg, dim3(256), 0, ctx->stream, (const double*)zslab, zs, total, n, (double*)y_dev,
+                                   alpha_eff, beta, vg, bd, alpha0);
         }
     } else {
         void* P;

@@ -139,7 +139,7 @@ struct covgram_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    covgram::Workspace ws[4];  // 0: packed tile stream, 1: split-J partials, 2/3: host staging (device copies of a / y)
+    covgram::Workspace ws[5];  // 0: packed tile stream, 1: split-J partials, 2/3: host staging (device copies of a / y), 4: wide-gradient slices
     // options
     int64_t dense_variant = 0;   // 0 auto (fp32 EQ on the matrix cores when the norm bound allows), 1 direct differences, 2 MFMA whenever the shape allows
     int64_t rows_per_lane = 0;   // 0 = auto

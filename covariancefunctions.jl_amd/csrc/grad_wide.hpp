@@ -163,11 +163,16 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
                                                              const typename Pk<T>::V* __restrict__ C1,
                                                              const typename Pk<T>::V* __restrict__ C2, int64_t npad,
                                                              int64_t nblocks, T* __restrict__ y, T alpha, T beta, int32_t accumulate,
-                                                             T gamma, int32_t vg, const T* __restrict__ C0, T alpha0) {
+                                                             T gamma, int32_t vg, const T* __restrict__ C0, T alpha0, int64_t zstride) {
     using PK = Pk<T>;
     using V = typename PK::V;
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (row >= n) return;                                   // no barriers, no cross-lane traffic below
+    // gridDim.z > 1: the panel's column blocks are split over z and each slice accumulates RAW sums into its own output
+    // slab (y + z * zstride); grad_wide_reduce_kernel adds the slices in fixed order and applies alpha / beta.  This is what
+    // fills the chip when (row blocks x dimension chunks) alone are too few waves (n = 16384, d = 128: 1024).
+    const int64_t b_begin = nblocks * blockIdx.z / gridDim.z, b_end = nblocks * (blockIdx.z + 1) / gridDim.z;
+    y += (int64_t)blockIdx.z * zstride;
     const int ch = blockIdx.y;
     const int l0 = ch * WIDE_CH;
     const int nch = dpad / WIDE_CH;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
         x[l] = (l0 + l < d) ? xr[l0 + l] * gamma : (T)0;
         bv[l] = PK::splat((T)0);
     }
-    for (int64_t b = 0; b < nblocks; ++b) {
+    for (int64_t b = b_begin; b < b_end; ++b) {
         const V* __restrict__ py = P + (b * nch + ch) * (int64_t)(2 * GJG * WIDE_CH);
         const V* __restrict__ pa = py + GJG * WIDE_CH;
 #pragma unroll 1
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
     }
     if (vg && ch == 0) {                                    // value row: add up the column blocks' partial sums
         T b0 = (T)0;
-        for (int64_t b = 0; b < nblocks; ++b) b0 += C0[b * npad + row];
+        for (int64_t b = b_begin; b < b_end; ++b) b0 += C0[b * npad + row];
         T* y0 = y + row * (int64_t)(d + 1);
         T v = alpha0 * b0;
         if (accumulate) v += *y0;
@@ -220,11 +225,31 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
     }
 }
 
+// y[e] = alpha(e) * sum_z slab[z][e] + beta * y[e];  alpha(e) = alpha0 for the value entry of a value-gradient block
+// One thread per (row, entry of the block): grid = (rows / 256, bd); blockIdx.y == 0 is the value entry when vg.
+// (A flat index with `e % bd == 0` selecting the scale was miscompiled by hipcc 7.2 at -O3 — every entry took alpha0; the
+// kernel printed the right values as soon as a printf was added.  The 2-D form has no modulo to get wrong.)
+template <typename T>
+__global__ __launch_bounds__(256) void grad_wide_reduce_kernel(const T* __restrict__ slab, int32_t zs, int64_t total, int64_t n,
+                                                               T* __restrict__ y, T alpha, T beta, int32_t vg, int32_t bd, T alpha0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= n) return;
+    const int64_t e = i * bd + k;
+    T s = (T)0;
+    for (int z = 0; z < zs; ++z) s += slab[(int64_t)z * total + e];
+    const T sc = (vg != 0 && k == 0) ? alpha0 : alpha;
+    T v = sc * s;
+    if (beta != (T)0) v = cg_fma(beta, y[e], v);
+    y[e] = v;
+}
+
 struct GradWideArgs {
     const void* X; int64_t n; int32_t d; int32_t dpad;
     const void* P; void* C1; void* C2; int64_t npad; int64_t nblocks;
     void* y; double alpha, beta; int32_t accumulate;
     int32_t vg = 0; const void* A0P = nullptr; void* C0 = nullptr; double alpha0 = 0, vg_c = 0, vg_b = 0;
+    int32_t zs = 1; int64_t zstride = 0;   // column split of the apply kernel (y then points at the slice slab)
     const HostKernel* hk;
     hipStream_t stream;
 };
@@ -243,9 +268,9 @@ static int launch_grad_wide_T(const GradWideArgs& a) {
     if (a.vg) { if (pow) CG_COEF_LAUNCH(POWT, true); else CG_COEF_LAUNCH(false, true); }
     else { if (pow) CG_COEF_LAUNCH(POWT, false); else CG_COEF_LAUNCH(false, false); }
 #undef CG_COEF_LAUNCH
-    hipLaunchKernelGGL((grad_wide_apply_kernel<T, ISO>), dim3(rb, (unsigned)(a.dpad / WIDE_CH)), dim3(64), 0, a.stream, (const T*)a.X, a.n, a.d,
-                       a.dpad, (const V*)a.P, (const V*)a.C1, (const V*)a.C2, a.npad, a.nblocks, (T*)a.y, (T)a.alpha, (T)a.beta,
-                       a.accumulate, kp.gamma, a.vg, (const T*)a.C0, (T)a.alpha0);
+    hipLaunchKernelGGL((grad_wide_apply_kernel<T, ISO>), dim3(rb, (unsigned)(a.dpad / WIDE_CH), (unsigned)a.zs), dim3(64), 0, a.stream,
+                       (const T*)a.X, a.n, a.d, a.dpad, (const V*)a.P, (const V*)a.C1, (const V*)a.C2, a.npad, a.nblocks, (T*)a.y, (T)a.alpha,
+                       (T)a.beta, a.accumulate, kp.gamma, a.vg, (const T*)a.C0, (T)a.alpha0, a.zstride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_wide launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
