@@ -147,6 +147,7 @@ struct covgram_ctx {
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
+    int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;

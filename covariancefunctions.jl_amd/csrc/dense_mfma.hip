@@ -192,18 +192,20 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
 template <typename T>
 __global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float v = 0.0f;
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // grid-stride
         double s = 0;
         for (int c = 0; c < d; ++c) { const double xc = (double)X[i * (int64_t)d + c]; s += xc * xc; }
-        v = (float)s;
-        if (!(v >= 0.0f)) v = __builtin_inff();                  // NaN / overflow: never eligible
-        v *= 1.000001f;                                          // round up: the bound must not under-estimate
+        float f = (float)s;
+        if (!(f >= 0.0f)) f = __builtin_inff();                  // NaN / overflow: never eligible
+        v = fmaxf(v, f * 1.000001f);                             // round up: the bound must not under-estimate
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(outbits, __float_as_uint(v));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(outbits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));   // one per workgroup
 }
 
 int points_max_norm2(covgram_points* p) {
@@ -214,7 +216,7 @@ int points_max_norm2(covgram_points* p) {
     hipStream_t st = p->ctx->stream;
     hipError_t e = hipMemsetAsync(dbits, 0, sizeof(unsigned), st);
     if (e == hipSuccess) {
-        const unsigned grid = (unsigned)((p->n + 255) / 256);
+        const unsigned grid = (unsigned)std::min<int64_t>((p->n + 255) / 256, 2048);
         if (p->dtype == COVGRAM_F32) hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits);
         else hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits);
         e = hipGetLastError();

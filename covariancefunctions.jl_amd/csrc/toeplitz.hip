@@ -295,6 +295,162 @@ __global__ __launch_bounds__(256) void spectral_kernel(typename V2T<T>::type* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The three middle passes as ONE kernel (M' = 4^L <= 4096): forward row FFT, the spectral step, inverse row FFT.
+// A workgroup holds TWO rows of zbuf in LDS — k1 and its conjugate partner 1024 - k1 (rows 0 and 512 are self-paired and share
+// a workgroup) — so every conjugate pair the spectral step touches is resident:  load -> L radix-4 DIF stages (natural in,
+// digit-reversed out) -> untangle * spectrum * re-tangle on the digit-reversed positions (rev(M'-1-k') = M'-1-rev(k')) ->
+// L radix-4 DIT stages with conjugated twiddles (digit-reversed in, natural out) -> store.  No digit-reversal pass, one HBM
+// read and one write of zbuf instead of three of each (rocFFT batch, spectral_kernel, rocFFT batch).  Twiddles: a quarter
+// table W_M'^r, r < M'/4, in LDS; the other quadrants are multiplications by -i, -1, i.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ int rev4(int x) {
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { r = (r << 2) | (x & 3); x >>= 2; }
+    return r;
+}
+
+// W^idx from the quarter table (idx < 3 Q): forward W = exp(-2 pi i / M'), W^Q = -i
+template <typename V, bool INV>
+__device__ __forceinline__ V quarter_tw(const V* __restrict__ stw, int idx, int Q) {
+    const int quad = idx / Q, r = idx & (Q - 1);
+    V w = stw[r];
+    if (quad == 1) w = V{w.y, -w.x};
+    else if (quad == 2) w = V{-w.x, -w.y};
+    if (INV) w.y = -w.y;
+    return w;
+}
+
+template <typename T, int L>
+__global__ __launch_bounds__((1 << (2 * L)) / 4) void rowfft_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
+                                                                          const typename V2T<T>::type* __restrict__ S,
+                                                                          const typename V2T<T>::type* __restrict__ tA,
+                                                                          const typename V2T<T>::type* __restrict__ tB,
+                                                                          const typename V2T<T>::type* __restrict__ twr) {
+    using V = typename V2T<T>::type;
+    constexpr int Mp = 1 << (2 * L), Q = Mp / 4, NT = Q;
+    // LDS rows are padded by one element per 16 (slot(i) = i + i/16): with 16-byte elements a quarter-wave then always
+    // touches 16 distinct 16-byte bank groups — for the unit-stride stages (4 consecutive elements per lane) as well as for
+    // the long-stride ones; the span-4 stage additionally walks the groups, not the offsets, along the lanes.
+    constexpr int MpP = Mp + Mp / 16;
+    auto P = [](int i) { return i + (i >> 4); };
+    __shared__ V rowA[MpP];
+    __shared__ V rowB[MpP];
+    __shared__ V stw[Q];
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x;
+    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? COLFFT_N1 / 2 : COLFFT_N1 - wg;
+    V* __restrict__ gA = zbuf + (int64_t)kA * Mp;
+    V* __restrict__ gB = zbuf + (int64_t)kB * Mp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rowA[P(tid + i * NT)] = gA[tid + i * NT]; rowB[P(tid + i * NT)] = gB[tid + i * NT]; }
+    stw[tid] = twr[tid];
+    __syncthreads();
+
+    // ---- forward: radix-4 decimation in frequency ------------------------------------------------------------------------
+#pragma unroll 1
+    for (int s = 0; s < L; ++s) {
+        const int lg = 2 * (L - 1 - s);                  // log2 of the span Ls = M' / 4^(s+1)
+        const int Ls = 1 << lg;
+        const int j = (Ls == 4) ? (tid >> (2 * L - 4)) : (tid & (Ls - 1));
+        const int g = (Ls == 4) ? (tid & ((1 << (2 * L - 4)) - 1)) : (tid >> lg);
+        const int i0 = g * 4 * Ls + j;
+        const int e = j << (2 * s);                      // twiddle exponent j * 4^s (in units of W_M')
+        const V w1 = quarter_tw<V, false>(stw, e, Q), w2 = quarter_tw<V, false>(stw, 2 * e, Q), w3 = quarter_tw<V, false>(stw, 3 * e, Q);
+        const int p0 = P(i0), p1 = P(i0 + Ls), p2 = P(i0 + 2 * Ls), p3 = P(i0 + 3 * Ls);
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            V* x = rw ? rowB : rowA;
+            const V a = x[p0], b = x[p1], c = x[p2], d = x[p3];
+            const V t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+            x[p0] = cadd(t0, t2);
+            x[p1] = cmul(cadd(t1, cmulmi(t3)), w1);                 // (a - c) - i (b - d)
+            x[p2] = cmul(csub(t0, t2), w2);
+            x[p3] = cmul(cadd(t1, cmuli(t3)), w3);                  // (a - c) + i (b - d)
+        }
+        __syncthreads();
+    }
+
+    // ---- spectral step on conjugate pairs (same algebra as spectral_kernel; frequency k' lives at slot rev(k')) ----------
+    auto pair = [&](V& zs, V& zps, bool self, int k1, int kp, int64_t pos, int64_t ppos) {
+        const V Z = zs;
+        if (pos == 0) {                                  // k = 0 and the Nyquist bin share Z[0]
+            const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
+            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+            zs = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
+            return;
+        }
+        const V Zp = zps;
+        const V w = cmul(tA[k1], tB[kp]);
+        const V wc = cconj(w);
+        const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
+        const V wo = cmul(w, o);
+        const V X{(T)0.5 * (e.x + wo.y), (T)0.5 * (e.y - wo.x)};
+        const V ep = cconj(e), op = V{-o.x, o.y};
+        const V wop = cmul(wc, op);
+        const V Xp{(T)0.5 * (ep.x - wop.y), (T)0.5 * (ep.y + wop.x)};
+        const V Y = cmul(X, S[pos]), Yp = cmul(Xp, S[ppos]);
+        const V f = cadd(Y, cconj(Yp)), h = csub(Y, cconj(Yp));
+        const V wh = cmul(wc, h);
+        zs = V{(T)0.5 * (f.x - wh.y), (T)0.5 * (f.y + wh.x)};
+        if (!self) {
+            const V fp = cconj(f), hp = V{-h.x, h.y};
+            const V whp = cmul(w, hp);
+            zps = V{(T)0.5 * (fp.x + whp.y), (T)0.5 * (fp.y - whp.x)};
+        }
+    };
+    if (wg != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kp = tid + i * NT;
+            const int p = rev4<L>(kp);
+            pair(rowA[P(p)], rowB[P(Mp - 1 - p)], false, kA, kp, (int64_t)kA * Mp + kp, (int64_t)kB * Mp + (Mp - 1 - kp));
+        }
+    } else {
+        // row 0: (0, k') pairs with (0, (M' - k') mod M'); row 512: (512, k') with (512, M' - 1 - k'); the lower position owns the pair
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kp = tid + i * NT;
+            const int kq = (Mp - kp) & (Mp - 1);
+            if (kp <= kq) pair(rowA[P(rev4<L>(kp))], rowA[P(rev4<L>(kq))], kp == kq, 0, kp, (int64_t)kp, (int64_t)kq);
+            const int kr = Mp - 1 - kp;
+            if (kp < kr) {
+                const int p = rev4<L>(kp);
+                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, COLFFT_N1 / 2, kp, (int64_t)(COLFFT_N1 / 2) * Mp + kp, (int64_t)(COLFFT_N1 / 2) * Mp + kr);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- inverse: radix-4 decimation in time, conjugated twiddles --------------------------------------------------------
+#pragma unroll 1
+    for (int s = 0; s < L; ++s) {
+        const int lg = 2 * s;
+        const int Ls = 1 << lg;
+        const int j = (Ls == 4) ? (tid >> (2 * L - 4)) : (tid & (Ls - 1));
+        const int g = (Ls == 4) ? (tid & ((1 << (2 * L - 4)) - 1)) : (tid >> lg);
+        const int i0 = g * 4 * Ls + j;
+        const int e = j << (2 * (L - 1 - s));            // j * M' / (4 Ls)
+        const V w1 = quarter_tw<V, true>(stw, e, Q), w2 = quarter_tw<V, true>(stw, 2 * e, Q), w3 = quarter_tw<V, true>(stw, 3 * e, Q);
+        const int p0 = P(i0), p1 = P(i0 + Ls), p2 = P(i0 + 2 * Ls), p3 = P(i0 + 3 * Ls);
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            V* x = rw ? rowB : rowA;
+            const V a = x[p0], b = cmul(w1, x[p1]), c = cmul(w2, x[p2]), d = cmul(w3, x[p3]);
+            const V t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+            x[p0] = cadd(t0, t2);
+            x[p1] = cadd(t1, cmuli(t3));                            // (a - c) + i (b - d)
+            x[p2] = csub(t0, t2);
+            x[p3] = cadd(t1, cmulmi(t3));                           // (a - c) - i (b - d)
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gA[tid + i * NT] = rowA[P(tid + i * NT)]; gB[tid + i * NT] = rowB[P(tid + i * NT)]; }
+}
+
 }  // namespace covgram
 
 using namespace covgram;
@@ -333,7 +489,7 @@ template <typename T>
 static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
     const long double PI = 3.14159265358979323846264338327950288L;
     const int64_t nhi = M >> TWID_LB;
-    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp));
+    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp + Mp / 4));
     size_t o = 0;
     auto put = [&](long double ang) { h[o++] = (T)cosl(ang); h[o++] = (T)sinl(ang); };
     for (int t = 0; t < COLFFT_N1; ++t) put(-2 * PI * t / COLFFT_N1);                 // tw1024[t] = W_1024^t
@@ -341,9 +497,10 @@ static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
     for (int64_t q = 0; q < nhi; ++q) put(-2 * PI * q / (long double)nhi);             // thi[q]    = W_M^(2048 q)
     for (int k1 = 0; k1 < COLFFT_N1; ++k1) put(-PI * k1 / (long double)M);             // tA[k1]    = exp(-i pi k1 / M)
     for (int64_t kp = 0; kp < Mp; ++kp) put(-PI * kp / (long double)Mp);               // tB[k']    = exp(-i pi 1024 k' / M)
+    for (int64_t r = 0; r < Mp / 4; ++r) put(-2 * PI * r / (long double)Mp);           // twr[r]    = W_M'^r (quarter table)
 }
 
-struct FastTables { const void *tw, *tlo, *thi, *tA, *tB; };
+struct FastTables { const void *tw, *tlo, *thi, *tA, *tB, *twr; };
 static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     const size_t cs = 2 * dtype_size(Tz->dtype);
     const char* b = (const char*)Tz->tables;
@@ -353,7 +510,8 @@ static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     t.tlo = b; b += cs * (1 << TWID_LB);
     t.thi = b; b += cs * nhi;
     t.tA = b; b += cs * COLFFT_N1;
-    t.tB = b;
+    t.tB = b; b += cs * Tz->Mp;
+    t.twr = b;
     return t;
 }
 
@@ -377,6 +535,23 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
     constexpr int TW = colfft_tw<T>();
     const FastTables t = table_ptrs(Tz);
     hipStream_t st = Tz->ctx->stream;
+    int L = 0;
+    for (int l = 3; l <= 6; ++l) if (Tz->Mp == ((int64_t)1 << (2 * l))) L = l;
+    if (L && Tz->ctx->toeplitz_fused) {
+        // column FFT -> [row FFT, spectral step, inverse row FFT] in one kernel -> inverse column FFT: three passes over zbuf
+        hipLaunchKernelGGL((colfft_kernel<T, TW, false>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, a, Tz->m, (V*)Tz->zbuf, Tz->Mp,
+                           (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, (T*)nullptr, (int64_t)0, (T)0, (T)0);
+        const dim3 fg(COLFFT_N1 / 2);
+#define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
+                                        (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
+        switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
+#undef CG_FUSED
+        hipLaunchKernelGGL((colfft_kernel<T, TW, true>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, (const T*)nullptr, (int64_t)0,
+                           (V*)Tz->zbuf, Tz->Mp, (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, Tz->n, (T)alpha, (T)beta);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { set_error("toeplitz fused path launch failed: %s", hipGetErrorString(e2)); return COVGRAM_EHIP; }
+        return COVGRAM_OK;
+    }
     int rc = fast_forward<T>(Tz, a, Tz->m);
     if (rc) return rc;
     const int64_t pairs = (int64_t)(COLFFT_N1 / 2 + 1) * Tz->Mp;

@@ -659,3 +659,40 @@ def test_toeplitz_solve_pcg_vs_levinson(cg, oracle, n):
     T = cg.SymmetricToeplitz(torch.from_numpy(vc).cuda())
     x, info = cg.toeplitz_solve(T, bd, reltol=1e-12)
     assert info["converged"] and relerr(x.cpu().numpy(), oracle.levinson_toeplitz(vc, b)) <= 1e-8, info
+
+
+@pytest.mark.parametrize("dtype,n", [(torch.float64, 65536), (torch.float64, 250000), (torch.float64, 1000000), (torch.float64, 3000001),
+                                     (torch.float32, 250000), (torch.float32, 4000000)])
+def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
+    """M' = N / 2048 in {64, 256, 1024, 4096}: the row FFT, spectral step and inverse row FFT run as ONE kernel
+    (rowfft_fused_kernel) — against the numpy circulant-embedding oracle, explicit dense rows, and the rocFFT-batch path
+    (option toeplitz_fused = 0), symmetric and non-symmetric, alpha / beta."""
+    tol = 3e-5 if dtype == torch.float32 else 1e-10
+    rng = np.random.default_rng(n)
+    x = cg.srange(-1, 1, n, dtype)
+    a = rng.standard_normal(n).astype(npdt(dtype)); y0 = rng.standard_normal(n).astype(npdt(dtype))
+    ad = torch.from_numpy(a).cuda()
+    ko = oracle.Kernel(oracle.EXP)
+    G = cg.gramian(cg.Exp(), x)
+    vc, _ = oracle.toeplitz_vectors(ko, oracle.srange(-1, 1, n))
+    ref = oracle.toeplitz_mul(None, vc, None, a.astype(np.float64))
+    try:
+        out = {}
+        for fused in (1, 0):
+            cg.set_option("toeplitz_fused", fused)
+            yd = torch.from_numpy(y0.copy()).cuda()
+            cg.mul_(yd, G, ad, 0.3, -1.1)
+            out[fused] = yd.cpu().numpy()
+            assert relerr(out[fused], 0.3 * ref - 1.1 * y0) <= tol, (fused, n, relerr(out[fused], 0.3 * ref - 1.1 * y0))
+        assert relerr(out[1], out[0]) <= tol
+        cg.set_option("toeplitz_fused", 1)
+        b = (G @ ad).cpu().numpy()
+        rows = rng.choice(n, 8, replace=False)
+        dense_rows = np.array([np.dot(vc[np.abs(i - np.arange(n))], a.astype(np.float64)) for i in rows])
+        assert relerr(b[rows], dense_rows) <= tol
+        Tn = cg.gramian(cg.Exp(), x, x + 0.123)
+        rg = oracle.srange(-1, 1, n)
+        vc2, vr2 = oracle.toeplitz_vectors(ko, rg, (rg[0] + 0.123, rg[1], rg[2]))
+        assert relerr((Tn @ ad).cpu().numpy(), oracle.toeplitz_mul(None, vc2, vr2, a.astype(np.float64))) <= tol
+    finally:
+        cg.set_option("toeplitz_fused", 1)
