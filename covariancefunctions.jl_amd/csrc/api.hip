@@ -214,6 +214,16 @@ static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradi
             } else {
                 kp.mp_bound = 0.0;                   // eps^(1/0) = 0: never taken
             }
+            if (!for_gradient) {
+                // dense path: fold sqrt(2p+1) and log2(e) into the coordinate pre-scale, s' = (2p+1) log2(e)^2 s / l^2, so that
+                // sqrt(s') = r log2(e): H_p(r) = exp2(-sqrt(s')) sum_m (h_m / log2(e)^m) sqrt(s')^m, Taylor in s'
+                const double f2 = kp.mp_c * LOG2E * LOG2E;
+                kp.gamma = inv_l * sqrt(f2);
+                double li = 1.0, fi = 1.0;
+                for (int i = 0; i <= p; ++i) { kp.h0[i] *= li; kp.ty[i] *= fi; li /= LOG2E; fi /= f2; }
+                kp.mp_bound *= f2;
+                out->eq_folded = true;
+            }
             break;
         }
         default: break;

@@ -106,7 +106,7 @@ struct DenseBody {
         for (int c = 0; c < NR; ++c) aj[c] = p[D + c];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const V kv = PK::map(s[r], [&](T sv) { return phi_value<FAM, T, (FAM == COVGRAM_EQ), POW>(sv, kp); });
+            const V kv = PK::map(s[r], [&](T sv) { return phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), POW>(sv, kp); });
 #pragma unroll
             for (int c = 0; c < NR; ++c) acc[r][c] = PK::fma(aj[c], kv, acc[r][c]);
         }

@@ -91,8 +91,22 @@ template <typename T, bool F>
 struct Phi<COVGRAM_IMQ, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) { return cg_rsqrt(s + kp.param); }
 };
-template <typename T, bool F>
-struct Phi<COVGRAM_MATERNP, T, F> {
+// FOLDED (dense MVM kernels): the host pre-scales the coordinates by log2(e) sqrt(2p+1) / l, so sqrt(s) IS r log2(e);
+// exp(-r) = exp2(-sqrt(s)) (negation is a free source modifier) and the polynomial / Taylor tables are rescaled to that
+// argument (make_host_kernel): two multiplications fewer per pair.
+template <typename T>
+struct Phi<COVGRAM_MATERNP, T, true> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        T rr = cg_sqrt(s);
+        T e = cg_exp2(-rr);
+        T q, t;
+        if (kp.p <= 3) { q = horner3(kp.h0, rr); t = horner3(kp.ty, s); }
+        else { q = horner(kp.h0, kp.p, rr); t = horner(kp.ty, kp.p, s); }
+        return (s < kp.mp_bound) ? t : q * e;
+    }
+};
+template <typename T>
+struct Phi<COVGRAM_MATERNP, T, false> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         T r = cg_sqrt(kp.mp_c * s);
         T e = cg_exp(-r);

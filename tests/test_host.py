@@ -52,7 +52,7 @@ def test_kernel_parameter_tables_match_exact_rationals(cg):
     for p in range(0, 9):
         spec = cg.device_spec(cg.MaternP(p))
         for dtype, eps in ((cg._ffi.F32, np.finfo(np.float32).eps), (cg._ffi.F64, np.finfo(np.float64).eps)):
-            assert lib.covgram_debug_kernel_params(C.byref(spec), dtype, 0, out) == 0
+            assert lib.covgram_debug_kernel_params(C.byref(spec), dtype, 1, out) == 0     # unfolded tables (gradient / composite paths)
             v = list(out)
             assert v[5] == 2 * p + 1
             h0 = [float(x) for x in o.maternp_poly(p)]
@@ -67,6 +67,15 @@ def test_kernel_parameter_tables_match_exact_rationals(cg):
             if p >= 2:
                 assert np.isclose(v[8], d[1], rtol=1e-15)
                 assert np.allclose(v[27:27 + p - 1], [float(x) for x in o.maternp_poly(p - 2)], rtol=1e-15)
+            # dense path: sqrt(2p+1) log2(e) / l folded into the coordinate pre-scale, tables rescaled to that argument
+            assert lib.covgram_debug_kernel_params(C.byref(spec), dtype, 0, out) == 0
+            w = list(out)
+            L2E = math.log2(math.e); f2 = (2 * p + 1) * L2E * L2E
+            assert np.isclose(w[0], math.sqrt(f2), rtol=1e-15)
+            assert np.allclose(w[9:9 + p + 1], [h0[m] / L2E ** m for m in range(p + 1)], rtol=1e-14)
+            if p >= 1:
+                assert np.allclose(w[36:36 + p + 1], [ty[i] / f2 ** i for i in range(p + 1)], rtol=1e-13)
+                assert np.isclose(w[6], float(eps) ** (1.0 / p) * f2, rtol=1e-14)
     # EQ: dense path folds sqrt(log2(e)/2)/l into gamma, gradient path keeps gamma = 1/l
     spec = cg.device_spec(cg.Lengthscale(cg.EQ(), 0.5))
     lib.covgram_debug_kernel_params(C.byref(spec), cg._ffi.F32, 0, out)
