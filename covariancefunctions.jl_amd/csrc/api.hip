@@ -691,7 +691,11 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     rc = make_host_kernel(k, dtype, true, &hk);
     if (rc) return rc;
     // lane-owned rows up to d = 64 (fp32) / 48 (fp64) (grad_mvm.hpp); wider rows take the two-kernel panel path (grad_wide.hpp)
-    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
+    // composites take the panel path as well: its coefficient kernel evaluates their jets per block of column groups
+    // (factor-outer) where the lane-per-row kernel interprets them once per pair — C4-shaped EQ*RQ: 8.9 vs 16.1 ms
+    // (tools/gradcomp_bench.py); option grad_keep_r = 0 / 1 keeps them on the lane-per-row kernel
+    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2 ||
+                      (hk.tu_family >= COVGRAM_NFAMILY && ctx->grad_keep_r < 0 && d >= 8);
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(hk.tu_family);
     CG_CHECK_HIP(hipSetDevice(ctx->device));
