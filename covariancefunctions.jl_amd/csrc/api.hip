@@ -469,6 +469,7 @@ int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t co
                "slice [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)parent->n);
     covgram_points* p = new covgram_points(*parent);
     p->owns = false;
+    p->frag_cache = nullptr; p->frag_bytes = 0; p->frag_g = 0; p->frag_k2 = 0;   // a slice packs its own fragments
     p->n = count;
     p->dptr = (char*)parent->dptr + (size_t)first * parent->d * dtype_size(parent->dtype);
     parent->ctx->live_handles++;
@@ -478,6 +479,7 @@ int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t co
 
 int covgram_points_destroy(covgram_points* p) {
     if (!p) return COVGRAM_OK;
+    if (p->frag_cache) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->frag_cache); }
     if (p->owns && p->dptr) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->dptr); }
     p->ctx->live_handles--;
     delete p;
@@ -577,10 +579,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             int64_t jc; int js;
             (void)jc; (void)js;
             if (dtype == COVGRAM_F32)
-                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream,
                                    (const float*)nullptr, npad, NRpad, 0, (float*)y_c, n, ldy_d, nr, 0.0f, (float)beta);
             else
-                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream,
                                    (const double*)nullptr, npad, NRpad, 0, (double*)y_c, n, ldy_d, nr, 0.0, beta);
             continue;
         }
@@ -621,10 +623,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         if (tm) (void)hipEventRecord(tm->second, ctx->stream);
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
-                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream,
                                    (const float*)da.out, npad, NRpad, jsplit, (float*)y_c, n, ldy_d, nr, (float)alpha_eff, (float)beta);
             else
-                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream,
                                    (const double*)da.out, npad, NRpad, jsplit, (double*)y_c, n, ldy_d, nr, alpha_eff, beta);
         }
     }

@@ -166,6 +166,13 @@ struct covgram_points {
     int32_t dtype = 0;
     bool owns = false;
     double max_norm2 = 0;  // max_i |x_i|^2 (upper bound; slices inherit the parent's), computed once at creation
+    // matrix-core EQ path: the B fragments of this point set as the COLUMN side depend only on (points, gamma), not on the
+    // weights, so they are packed once and reused by every later MVM (the points are resident and immutable while the handle
+    // lives); only the 4-byte-per-column weights are rebuilt per MVM
+    mutable void* frag_cache = nullptr;
+    mutable size_t frag_bytes = 0;
+    mutable float frag_g = 0;
+    mutable int frag_k2 = 0;
 };
 
 namespace covgram {

@@ -189,6 +189,20 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
         for (int cr = 0; cr < NR; ++cr) W[(T * NR + cr) * 32 + l] = (j < m && c0 + cr < nrhs) ? A[j + (int64_t)(c0 + cr) * lda] : 0.0f;
 }
 
+// the per-MVM part of the pack when the fragments are cached: W[j] = a_j * exp2(-|g y_j|^2 / 2)
+__global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
+                                                          float* __restrict__ W, int64_t mpad, float g) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mpad) return;
+    float w = 0.0f;
+    if (j < m) {
+        float ny = 0.0f;
+        for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+        w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
+    }
+    W[j] = w;
+}
+
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
 template <typename T>
 __global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits) {
@@ -273,13 +287,25 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const int K2 = (D + 1) / 2;
     const int64_t ntile = (m + 31) / 32;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
-    void* P;
-    int rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + 32 * sizeof(float)), &P);
+    // fragments: cached in the column point set's handle (they do not depend on the weights); weights: per MVM
+    const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
+    void* Wp;
+    int rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
     if (rc) return rc;
-    uint4* PB = (uint4*)P;
-    float* W = (float*)(PB + ntile * K2 * 64);
-    const int64_t pe = ntile * K2 * 64;
-    hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, PB, W, K2, g);
+    float* W = (float*)Wp;
+    if (Y->frag_cache == nullptr || Y->frag_bytes != fbytes || Y->frag_g != g || Y->frag_k2 != K2) {
+        if (Y->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(Y->frag_cache); Y->frag_cache = nullptr; }
+        hipError_t me = hipMalloc(&Y->frag_cache, fbytes);
+        if (me != hipSuccess) { Y->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
+        Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
+        const int64_t pe = ntile * K2 * 64;
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
+                           (uint4*)Y->frag_cache, W, K2, g);
+    } else {
+        hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, W,
+                           ntile * 32, g);
+    }
+    const uint4* PB = (const uint4*)Y->frag_cache;
     // split the column tiles so that the grid holds ~CUs * 128 waves (as the lane-per-row kernel, profiles/r01_quickbench_wg64.txt)
     // row tiles per wave: two share every B fragment while the state fits (d <= 8); option "rows_per_lane" = 1 / 2 forces it
     const int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= 4 ? 2 : 1));
@@ -312,7 +338,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 #undef CG_MFMA_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     if (js > 1)
-        hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
+        hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
                            (int)js, y, n, n, 1, (float)alpha_eff, (float)beta);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
@@ -417,7 +443,7 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         if (rc) return rc;
         if (tm) (void)hipEventRecord(tm->second, ctx->stream);
         if (js > 1)
-            hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, ctx->stream, (const float*)out, npad,
+            hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream, (const float*)out, npad,
                                NR, (int)js, y_c, n, ldy, nr, (float)alpha_eff, (float)beta);
     }
     hipError_t e = hipGetLastError();
