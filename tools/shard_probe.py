@@ -17,3 +17,15 @@ e0.record()
 for _ in range(K): G.mul_(y, a)
 e1.record(); e1.synchronize()
 print(f"rows={rows}: {e0.elapsed_time(e1) / K * 1e3:.1f} us per MVM (ideal 1/8 of 1660 us = 207 us)")
+res = {}
+for rep in range(6):
+    for tw in (0, 4096, 8192, 12288):
+        cg.set_option("target_wgs", tw)
+        for _ in range(3): G.mul_(y, a)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(100): G.mul_(y, a)
+        e1.record(); e1.synchronize()
+        res.setdefault(tw, []).append(e0.elapsed_time(e1) / 100 * 1e3)
+for tw, v in res.items():
+    print(f"  target_wgs={tw}: median {np.median(v):.1f} us  min {np.min(v):.1f} us")
