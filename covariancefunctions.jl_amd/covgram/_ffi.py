@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
 
 # enums (include/covgram.h)
-EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT = range(9)
+EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN = range(10)
 CONSTANT, COMPOSITE = 100, 101
 COMPOSITE_MAX_TERMS, COMPOSITE_MAX_FACTORS = 4, 6
 ISOTROPIC, DOTPRODUCT = 1, 2

@@ -225,7 +225,7 @@ class MaternP(IsotropicKernel):
 
 
 class Matern(IsotropicKernel):
-    """src/stationary.jl:87-114 (Bessel form) — GenericInput for the device: no compiled profile."""
+    """src/stationary.jl:87-114 (Bessel form, real ν > 0); on the device Temme's series / Steed's continued fraction."""
 
     def __init__(self, nu):
         if not nu > 0:
@@ -438,6 +438,7 @@ def isdot(k): return isinstance(k, (Dot, ExponentialDot)) or (isinstance(k, (Pro
 _BASE = {
     ExponentiatedQuadratic: _ffi.EQ, Exponential: _ffi.EXP, RationalQuadratic: _ffi.RQ, GammaExponential: _ffi.GAMMAEXP,
     Cauchy: _ffi.CAUCHY, InverseMultiQuadratic: _ffi.IMQ, MaternP: _ffi.MATERNP, Dot: _ffi.DOT, ExponentialDot: _ffi.EXPDOT,
+    Matern: _ffi.MATERN,
 }
 
 
@@ -475,7 +476,8 @@ def _simple_spec(k) -> Optional[_ffi.covgram_kernel]:
     spec.trait = _ffi.DOTPRODUCT if fam in (_ffi.DOT, _ffi.EXPDOT) else _ffi.ISOTROPIC
     spec.p = getattr(k, "p", 0) if fam == _ffi.MATERNP else 0
     spec.power = power
-    spec.param = {_ffi.RQ: getattr(k, "alpha", 0.0), _ffi.GAMMAEXP: getattr(k, "gamma", 0.0), _ffi.IMQ: getattr(k, "c", 0.0)}.get(fam, 0.0)
+    spec.param = {_ffi.RQ: getattr(k, "alpha", 0.0), _ffi.GAMMAEXP: getattr(k, "gamma", 0.0), _ffi.IMQ: getattr(k, "c", 0.0),
+                  _ffi.MATERN: getattr(k, "nu", 0.0)}.get(fam, 0.0)
     spec.lengthscale = ls
     spec.scale = scale
     if spec.trait == _ffi.DOTPRODUCT and ls != 1.0:

@@ -44,28 +44,28 @@ int pad_dim(int d) {
     int launch_dense_wide_family_##n(const DenseArgs&, int dtype); \
     int launch_grad_family_##n(const GradArgs&, int dtype);        \
     int launch_grad_wide_family_##n(const GradWideArgs&, int dtype);
-CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(9) CG_DECL(10)
+CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(9) CG_DECL(10) CG_DECL(11)
 #undef CG_DECL
 
 dense_launch_fn dense_launcher(int family) {
     static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_family_0, launch_dense_family_1, launch_dense_family_2, launch_dense_family_3, launch_dense_family_4,
         launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8, launch_dense_family_9,
-        launch_dense_family_10};
+        launch_dense_family_10, launch_dense_family_11};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 dense_launch_fn dense_wide_launcher(int family) {
     static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_wide_family_0, launch_dense_wide_family_1, launch_dense_wide_family_2, launch_dense_wide_family_3,
         launch_dense_wide_family_4, launch_dense_wide_family_5, launch_dense_wide_family_6, launch_dense_wide_family_7,
-        launch_dense_wide_family_8, launch_dense_wide_family_9, launch_dense_wide_family_10};
+        launch_dense_wide_family_8, launch_dense_wide_family_9, launch_dense_wide_family_10, launch_dense_wide_family_11};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 grad_launch_fn grad_launcher(int family) {
     static const grad_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_family_0, launch_grad_family_1, launch_grad_family_2, launch_grad_family_3, launch_grad_family_4,
         launch_grad_family_5, launch_grad_family_6, launch_grad_family_7, launch_grad_family_8, launch_grad_family_9,
-        launch_grad_family_10};
+        launch_grad_family_10, launch_grad_family_11};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 
@@ -226,6 +226,40 @@ static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradi
             }
             break;
         }
+        case COVGRAM_MATERN: {
+            // Matern(nu), real nu > 0 (src/stationary.jl:87-114): phi = C r^nu K_nu(r), r = sqrt(2 nu s), C = 2^(1-nu)/Gamma(nu);
+            // below taylor_bound the reference's polynomial (:100-110).  K_a by Temme's series (x < 2) / Steed's continued fraction
+            // (x >= 2) at order mu = a - round(a) and upward recurrence; the mu-only constants are computed here, per order:
+            // h0 <- order nu (value), h1 <- |nu - 1| (phi'), h2 <- |nu - 2| (phi'').
+            const double nu = k->param;
+            CG_REQUIRE(nu > 0, COVGRAM_EINVAL, "DomainError: nu = %g is negative", nu);
+            CG_REQUIRE(nu <= 64, COVGRAM_EUNSUPPORTED, "Matern: nu = %g exceeds 64", nu);
+            kp.param = nu;
+            kp.mp_c = 2.0 * nu;
+            const double eps = (dtype == COVGRAM_F64) ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+            kp.mp_bound = (nu > 2) ? sqrt(eps) : ((nu > 1) ? eps : 0.0);
+            kp.ty[0] = 1.0;
+            kp.ty[1] = (nu > 1) ? nu / (2 * (1 - nu)) : 0.0;
+            kp.ty[2] = (nu > 2) ? nu * nu / (8 * (2 - 3 * nu + nu * nu)) : 0.0;
+            kp.c0 = exp2(1.0 - nu) / tgamma(nu);                      // C
+            auto order = [&](double a, double* h) {                   // h[0..6] = nl, mu, gam1, gam2, 1/Gamma(1+mu), 1/Gamma(1-mu), pi mu / sin(pi mu)
+                const double nl = floor(a + 0.5);
+                const long double mu = (long double)a - nl;
+                const long double gp = 1.0L / tgammal(1.0L + mu), gm = 1.0L / tgammal(1.0L - mu);
+                long double g1;
+                if (fabsl(mu) < 0.01L) {                              // (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu) from the series of 1/Gamma
+                    const long double m2 = mu * mu;
+                    g1 = -(0.57721566490153286061L + m2 * (-0.042002635034095235529L + m2 * (-0.042197734555544336748L + m2 * 0.0072189432466630995424L)));
+                } else {
+                    g1 = (gm - gp) / (2 * mu);
+                }
+                const long double pimu = 3.14159265358979323846264338327950288L * mu;
+                h[0] = nl; h[1] = (double)mu; h[2] = (double)g1; h[3] = (double)((gm + gp) / 2); h[4] = (double)gp; h[5] = (double)gm;
+                h[6] = (fabsl(pimu) < 1e-18L) ? 1.0 : (double)(pimu / sinl(pimu));
+            };
+            order(nu, kp.h0); order(fabs(nu - 1), kp.h1); order(fabs(nu - 2), kp.h2);
+            break;
+        }
         default: break;
     }
     kp.gamma2 = kp.gamma * kp.gamma;
@@ -255,7 +289,7 @@ grad_wide_launch_fn grad_wide_launcher(int family) {
     static const grad_wide_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_wide_family_0, launch_grad_wide_family_1, launch_grad_wide_family_2, launch_grad_wide_family_3,
         launch_grad_wide_family_4, launch_grad_wide_family_5, launch_grad_wide_family_6, launch_grad_wide_family_7,
-        launch_grad_wide_family_8, launch_grad_wide_family_9, launch_grad_wide_family_10};
+        launch_grad_wide_family_8, launch_grad_wide_family_9, launch_grad_wide_family_10, launch_grad_wide_family_11};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 

@@ -121,6 +121,89 @@ struct Phi<COVGRAM_MATERNP, T, false> {
         return (s < kp.mp_bound) ? t : q * e;
     }
 };
+// ---- Matern with real nu (src/stationary.jl:87-114): modified Bessel function of the second kind -----------------------
+// K_a(x), a >= 0, x > 0.  hc[0..6] = round(a), mu = a - round(a), and the mu-only constants of Temme's method
+// (gam1, gam2, 1/Gamma(1+mu), 1/Gamma(1-mu), pi mu / sin(pi mu)), prepared by the host (api.hip).  x < 2: Temme's series
+// for K_mu and K_mu+1; x >= 2: Steed's continued fraction (CF2); then the upward recurrence K_{b+1} = K_{b-1} + (2b/x) K_b,
+// which is the stable direction for K.  The iteration counts depend on the lane's x; the loops stop at eps(T).
+template <typename T>
+__device__ __forceinline__ T cg_log(T x) { return cg_log2(x) * (T)0.69314718055994530942; }
+
+template <typename T>
+__device__ T besselk(T x, const T* __restrict__ hc) {
+    const T EPS = (sizeof(T) == 8) ? (T)2.2e-16 : (T)1.2e-7;
+    const int nl = (int)hc[0];
+    const T mu = hc[1], gam1 = hc[2], gam2 = hc[3], gampl = hc[4], gammi = hc[5], fact = hc[6];
+    const T mu2 = mu * mu, xi = (T)1 / x, xi2 = (T)2 * xi;
+    T rkmu, rk1;
+    if (x < (T)2) {
+        const T b = (T)0.5 * x;
+        T d = -cg_log(b);
+        T e = mu * d;
+        const T ee = cg_exp(e), ie = (T)1 / ee;
+        const T ch = (T)0.5 * (ee + ie);
+        const T fact2 = (e > -EPS && e < EPS) ? (T)1 : (T)0.5 * (ee - ie) / e;          // sinh(e) / e
+        T ff = fact * (gam1 * ch + gam2 * fact2 * d);
+        T sum = ff;
+        T p = (T)0.5 * ee / gampl, q = (T)0.5 * ie / gammi, c = (T)1;
+        d = b * b;
+        T sum1 = p;
+        for (int i = 1; i < 500; ++i) {
+            const T fi = (T)i;
+            ff = (fi * ff + p + q) / (fi * fi - mu2);
+            c *= d / fi;
+            p /= (fi - mu);
+            q /= (fi + mu);
+            const T del = c * ff;
+            sum += del;
+            sum1 += c * (p - fi * ff);
+            if (!(del > sum * EPS || -del > sum * EPS)) break;                            // |del| <= |sum| eps (sum > 0)
+        }
+        rkmu = sum;
+        rk1 = sum1 * xi2;
+    } else {
+        T b = (T)2 * ((T)1 + x), d = (T)1 / b, h = d, delh = d, q1 = (T)0, q2 = (T)1;
+        const T a1 = (T)0.25 - mu2;
+        T q = a1, c = a1, a = -a1;
+        T s = (T)1 + q * delh;
+        for (int i = 2; i < 500; ++i) {
+            a -= (T)(2 * (i - 1));
+            c = -a * c / (T)i;
+            const T qnew = (q1 - b * q2) / a;
+            q1 = q2; q2 = qnew;
+            q += c * qnew;
+            b += (T)2;
+            d = (T)1 / (b + a * d);
+            delh = (b * d - (T)1) * delh;
+            h += delh;
+            const T dels = q * delh;
+            s += dels;
+            const T rel = dels / s;
+            if (!(rel > EPS || -rel > EPS)) break;
+        }
+        h = a1 * h;
+        rkmu = cg_sqrt((T)1.57079632679489661923 * xi) * cg_exp(-x) / s;
+        rk1 = rkmu * (mu + x + (T)0.5 - h) * xi;
+    }
+    for (int i = 1; i <= nl; ++i) {
+        const T t = (mu + (T)i) * xi2 * rk1 + rkmu;
+        rkmu = rk1; rk1 = t;
+    }
+    return rkmu;
+}
+
+// kp.param = nu, kp.mp_c = 2 nu, kp.c0 = 2^(1-nu)/Gamma(nu), kp.mp_bound = taylor_bound, kp.ty = its polynomial,
+// kp.h0 / h1 / h2 = the Temme constants for the orders nu, |nu-1|, |nu-2|
+template <typename T, bool F>
+struct Phi<COVGRAM_MATERN, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        if (s < kp.mp_bound) return cg_fma(cg_fma(kp.ty[2], s, kp.ty[1]), s, (T)1);      // src/stationary.jl:100-110
+        if (!(s > (T)0)) return (T)1;                                                     // k(x, x) = 1 (also for nu <= 1)
+        const T r = cg_sqrt(kp.mp_c * s);
+        return kp.c0 * cg_pow(r, kp.param) * besselk<T>(r, kp.h0);
+    }
+};
+
 template <typename T, bool F>
 struct Phi<COVGRAM_DOT, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return s; }
@@ -144,6 +227,7 @@ __device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
         case COVGRAM_MATERNP: v = Phi<COVGRAM_MATERNP, T, false>::eval(s, kp); break;
         case COVGRAM_DOT: v = s; break;
         case COVGRAM_EXPDOT: v = Phi<COVGRAM_EXPDOT, T, false>::eval(s, kp); break;
+        case COVGRAM_MATERN: v = Phi<COVGRAM_MATERN, T, false>::eval(s, kp); break;
         default: v = (T)1; break;                         // COVGRAM_CONSTANT: the factor is its scale
     }
     if (kp.power != 1) v = ipow(v, kp.power);
@@ -203,6 +287,7 @@ __device__ __forceinline__ void expr_accumulate_block(const typename Pk<T>::V (&
                 CG_EXPR_CASE(COVGRAM_CAUCHY)
                 CG_EXPR_CASE(COVGRAM_IMQ)
                 CG_EXPR_CASE(COVGRAM_MATERNP)
+                CG_EXPR_CASE(COVGRAM_MATERN)
                 CG_EXPR_CASE(COVGRAM_EXPDOT)
                 default:                                           // COVGRAM_DOT
                     CG_EXPR_CASE(COVGRAM_DOT)
@@ -323,6 +408,26 @@ struct DPhi<COVGRAM_MATERNP, T> {
         }
     }
 };
+// d/dr [r^a K_a(r)] = -r^a K_{a-1}(r) and dr/ds = nu / r  =>  phi' = -C nu r^(nu-1) K_{|nu-1|}(r),  phi'' = C nu^2 r^(nu-2) K_{|nu-2|}(r)
+// (K_{-a} = K_a); below taylor_bound the derivatives of the reference's polynomial, as ForwardDiff sees it.
+template <typename T>
+struct DPhi<COVGRAM_MATERN, T> {
+    static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
+        const T nu = kp.param;
+        if (s < kp.mp_bound) {
+            v = cg_fma(cg_fma(kp.ty[2], s, kp.ty[1]), s, (T)1);
+            d1 = cg_fma((T)2 * kp.ty[2], s, kp.ty[1]);
+            d2 = (T)2 * kp.ty[2];
+            return;
+        }
+        const T r = cg_sqrt(kp.mp_c * s);
+        const T lr = cg_log2(r);
+        const T C = kp.c0;
+        v = C * cg_exp2(nu * lr) * besselk<T>(r, kp.h0);
+        d1 = -C * nu * cg_exp2((nu - (T)1) * lr) * besselk<T>(r, kp.h1);
+        d2 = C * nu * nu * cg_exp2((nu - (T)2) * lr) * besselk<T>(r, kp.h2);
+    }
+};
 template <typename T>
 struct DPhi<COVGRAM_DOT, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
@@ -360,6 +465,7 @@ __device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T
         case COVGRAM_MATERNP: DPhi<COVGRAM_MATERNP, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_DOT: DPhi<COVGRAM_DOT, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_EXPDOT: DPhi<COVGRAM_EXPDOT, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_MATERN: DPhi<COVGRAM_MATERN, T>::eval(s, kp, v, d1, d2); break;
         default: v = (T)1; d1 = (T)0; d2 = (T)0; break;   // COVGRAM_CONSTANT
     }
     if (kp.power != 1) power_jet(kp.power, v, d1, d2);
@@ -425,6 +531,7 @@ __device__ __forceinline__ void expr_jet_block(const typename Pk<T>::V (&s)[BG],
                 CG_JET_CASE(COVGRAM_CAUCHY)
                 CG_JET_CASE(COVGRAM_IMQ)
                 CG_JET_CASE(COVGRAM_MATERNP)
+                CG_JET_CASE(COVGRAM_MATERN)
                 CG_JET_CASE(COVGRAM_EXPDOT)
                 default:
                     CG_JET_CASE(COVGRAM_DOT)

@@ -66,7 +66,9 @@ typedef enum covgram_family {
     COVGRAM_MATERNP = 6,  /* Matern nu = p + 1/2, 0 <= p <= 8  src/stationary.jl:117-158 */
     COVGRAM_DOT = 7,      /* s                                 src/mercer.jl:6-9         */
     COVGRAM_EXPDOT = 8,   /* exp(s)                            src/mercer.jl:19-22       */
-    COVGRAM_NFAMILY = 9,
+    COVGRAM_MATERN = 9,   /* Matern, real nu > 0: 2^(1-nu)/Gamma(nu) r^nu K_nu(r), r = sqrt(2 nu s); Taylor guard near 0
+                             (param = nu)                                        src/stationary.jl:87-114  */
+    COVGRAM_NFAMILY = 10,
     /* only inside / as the head of a covgram_kernel_composite: */
     COVGRAM_CONSTANT = 100, /* factor: the constant `scale`            src/stationary.jl:27-34   */
     COVGRAM_COMPOSITE = 101 /* head of a covgram_kernel_composite      src/algebra.jl:5-63       */
@@ -86,7 +88,7 @@ typedef struct covgram_kernel {
     int32_t trait;      /* covgram_trait; must agree with the family (checked) */
     int32_t p;          /* MaternP order */
     int32_t power;      /* Power(k, p) exponent, >= 1 (src/algebra.jl:50-63); 1 = none */
-    double param;       /* RQ alpha | gammaExp gamma | IMQ c */
+    double param;       /* RQ alpha | gammaExp gamma | IMQ c | Matern nu */
     double lengthscale; /* Lengthscale(k, l): s <- s/l^2, isotropic only (src/transformation.jl:6-19); 1 = none */
     double scale;       /* Constant(c) * k (src/algebra.jl:23-25); 1 = none */
 } covgram_kernel;

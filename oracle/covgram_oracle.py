@@ -26,8 +26,8 @@ import numpy as np
 # ----------------------------------------------------------------------------------------
 # kernel description (mirrors include/covgram.h :: covgram_kernel)
 # ----------------------------------------------------------------------------------------
-EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT = range(9)
-FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT"]
+EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN = range(10)
+FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT", "MATERN"]
 ISOTROPIC, DOTPRODUCT = 1, 2
 CONSTANT = 100   # a factor of a Composite that is just its `scale` (stationary.jl:27-34)
 
@@ -38,7 +38,7 @@ class Kernel:
     family: int
     p: int = 0            # MaternP order (stationary.jl:117-121)
     power: int = 1        # Power exponent (algebra.jl:50-63); 1 = none
-    param: float = 0.0    # RQ alpha (stationary.jl:45-53) | gammaExp gamma (:63-71) | IMQ c (:231-235)
+    param: float = 0.0    # RQ alpha (stationary.jl:45-53) | gammaExp gamma (:63-71) | IMQ c (:231-235) | Matern nu (:87-114)
     lengthscale: float = 1.0  # Lengthscale(k, l): s <- s / l^2 (transformation.jl:6-19)
     scale: float = 1.0    # Constant(c) * k (algebra.jl:23-25, stationary.jl:15-32)
 
@@ -139,6 +139,28 @@ def _maternp(s, p: int, dtype):
     return y
 
 
+def _matern_taylor(nu: float, dtype):
+    """stationary.jl:99-110: taylor_bound and the polynomial the reference returns below it."""
+    eps = _eps(dtype)
+    bound = math.sqrt(eps) if nu > 2 else (eps if nu > 1 else 0.0)
+    t1 = nu / (2 * (1 - nu)) if nu > 1 else 0.0
+    t2 = nu ** 2 / (8 * (2 - 3 * nu + nu ** 2)) if nu > 2 else 0.0
+    return bound, t1, t2
+
+
+def _matern(s, nu: float, dtype):
+    """stationary.jl:97-114: 2^(1-nu)/gamma(nu) * r^nu besselk(nu, r), r = sqrt(2 nu r²) (adbesselkxv = r^nu K_nu(r), whose
+    limit at r = 0 is 2^(nu-1) gamma(nu), i.e. k = 1), with the Taylor polynomial below taylor_bound."""
+    from scipy.special import gamma as sgamma, kv
+    s = np.asarray(s, dtype=np.float64)
+    bound, t1, t2 = _matern_taylor(nu, dtype)
+    r = np.sqrt(2 * nu * s)
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        y = 2 ** (1 - nu) / sgamma(nu) * r ** nu * kv(nu, r)
+    y = np.where(r == 0, 1.0, y)
+    return np.where(s < bound, 1 + t1 * s + t2 * s * s, y)
+
+
 def profile(k, s, dtype=np.float64):
     """phi(s) for every family in scope.  `dtype` only selects eps(T) for the MaternP guard."""
     s = np.asarray(s, dtype=np.float64)
@@ -169,6 +191,8 @@ def profile(k, s, dtype=np.float64):
         v = 1.0 / np.sqrt(s + k.param ** 2)          # stationary.jl:235
     elif f == MATERNP:
         v = _maternp(s, k.p, dtype)                  # stationary.jl:132-158
+    elif f == MATERN:
+        v = _matern(s, k.param, dtype)               # stationary.jl:97-114
     elif f == DOT:
         v = s                                        # mercer.jl:9
     elif f == EXPDOT:
@@ -257,6 +281,19 @@ def profile_derivatives(k: Kernel, s, dtype=np.float64):
                         t2 = t2 + ci * i * (i - 1) * s ** (i - 2)
                 d1 = np.where(s < bound, t1, d1)
                 d2 = np.where(s < bound, t2, d2)
+        elif f == MATERN:
+            # d/dr[r^a K_a(r)] = -r^a K_{a-1}(r), dr/ds = nu/r: what ForwardDiff computes through adbesselkxv; the polynomial branch
+            # differentiated termwise
+            from scipy.special import gamma as sgamma, kv
+            nu = k.param
+            bound, t1, t2 = _matern_taylor(nu, dtype)
+            C = 2 ** (1 - nu) / sgamma(nu)
+            r = np.sqrt(2 * nu * s)
+            v = _matern(s, nu, dtype)
+            d1 = -C * nu * r ** (nu - 1) * kv(nu - 1, r)
+            d2 = C * nu ** 2 * r ** (nu - 2) * kv(nu - 2, r)
+            d1 = np.where(s < bound, t1 + 2 * t2 * s, d1)
+            d2 = np.where(s < bound, 2 * t2, d2)
         elif f == DOT:
             v = s; d1 = np.ones_like(s); d2 = np.zeros_like(s)
         elif f == EXPDOT:

@@ -67,6 +67,10 @@ def mp_phi(k, s):
         r = mp.sqrt((2 * p + 1) * s)   # naive closed form, src/stationary.jl:162-169
         v = sum(mp.mpf(math.factorial(p + i)) / (math.factorial(p - i) * math.factorial(i)) * (2 * r) ** (p - i) for i in range(p + 1))
         v = v * mp.exp(-r) / (mp.mpf(math.factorial(2 * p)) / math.factorial(p))
+    elif f == o.MATERN:   # src/stationary.jl:111-112 (no Taylor branch here: the inputs stay far above taylor_bound)
+        nu = mp.mpf(k.param)
+        r = mp.sqrt(2 * nu * s)
+        v = mp.mpf(1) if r == 0 else 2 ** (1 - nu) / mp.gamma(nu) * r ** nu * mp.besselk(nu, r)
     elif f == o.DOT: v = s
     else: v = mp.exp(s)
     return mp.mpf(k.scale) * v ** k.power
@@ -161,6 +165,9 @@ COMPOSITES = {
     "dot_sum": o.Composite(((o.Kernel(o.DOT, power=2),), (o.Kernel(o.EXPDOT, scale=0.3),)), o.DOTPRODUCT, 1.0),
 }
 VALGRAD_KERNELS = ["EQ", "RQ1", "MaternP2", "Dot3", "ExpDot", "EQ_l07"]
+# Matern with real nu (src/stationary.jl:87-114): Bessel-function profile, checked here against mpmath's besselk
+MATERN_KERNELS = {"Matern0.8": o.Kernel(o.MATERN, param=0.8), "Matern1.3": o.Kernel(o.MATERN, param=1.3, lengthscale=0.6),
+                  "Matern2.7": o.Kernel(o.MATERN, param=2.7, scale=1.5), "Matern2.5": o.Kernel(o.MATERN, param=2.5)}
 
 
 def rel(a, b):
@@ -265,7 +272,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "kronecker.npz"), **kr)
 
     # ---- (5) composite kernels and ValueGradientKernel (mirrors test/gradient.jl:87-125, test/gradient_algebra.jl:13-47) ----
-    comp = {"names": np.array(list(COMPOSITES)), "valgrad_names": np.array(VALGRAD_KERNELS)}
+    comp = {"names": np.array(list(COMPOSITES)), "valgrad_names": np.array(VALGRAD_KERNELS), "matern_names": np.array(list(MATERN_KERNELS))}
+    for nm, km in MATERN_KERNELS.items():
+        comp[f"matern_{nm}_fields"] = kernel_fields(km)
     for d in (1, 3, 8):
         for (n, m) in ((4, 6), (65, 33)):
             rng = np.random.default_rng(0xC0F * 5000 + 100 * d + n)
@@ -278,7 +287,7 @@ def main():
             for key, val in (("X", X), ("Y", Y), ("a", a), ("y0", y0), ("ag", ag), ("yg0", yg0), ("av", av), ("yv0", yv0),
                              ("ab", np.array([alpha, beta]))):
                 comp[f"{tag}_{key}"] = val
-            kernels = dict(COMPOSITES); kernels.update({nm: KERNELS[nm] for nm in VALGRAD_KERNELS})
+            kernels = dict(COMPOSITES); kernels.update({nm: KERNELS[nm] for nm in VALGRAD_KERNELS}); kernels.update(MATERN_KERNELS)
             for name, k in kernels.items():
                 b = o.mul(y0, k, X, Y, a, alpha, beta)
                 bg = o.grad_mul(yg0, k, X, Y, ag, alpha, beta)
@@ -288,7 +297,7 @@ def main():
                                       (bv, mp_valgrad_mul(k, X, Y, av, yv0, alpha, beta))):
                         e = rel(got, want); worst = max(worst, e)
                         assert e < 1e-12, (name, tag, e)
-                if name in COMPOSITES:
+                if name in COMPOSITES or name in MATERN_KERNELS:
                     comp[f"{tag}_{name}_b"], comp[f"{tag}_{name}_bg"] = b, bg
                 comp[f"{tag}_{name}_bv"] = bv
     np.savez_compressed(os.path.join(OUT, "composite.npz"), **comp)

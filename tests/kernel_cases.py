@@ -21,6 +21,12 @@ def cases(cg):
         ("Dot()", cg.Dot(), o.Kernel(o.DOT)),
         ("ExponentialDot", cg.ExponentialDot(), o.Kernel(o.EXPDOT)),
         ("EQ^2", cg.EQ() ** 2, o.Kernel(o.EQ, power=2)),
+        # Matern with real nu (Bessel-function profile, src/stationary.jl:87-114): below 1, between 1 and 2, above 2, half-integer
+        ("Matern(0.8)", cg.Matern(0.8), o.Kernel(o.MATERN, param=0.8)),
+        ("Lengthscale(Matern(1.3),0.6)", cg.Lengthscale(cg.Matern(1.3), 0.6), o.Kernel(o.MATERN, param=1.3, lengthscale=0.6)),
+        ("1.5*Matern(2.7)", 1.5 * cg.Matern(2.7), o.Kernel(o.MATERN, param=2.7, scale=1.5)),
+        ("Matern(2.5)", cg.Matern(2.5), o.Kernel(o.MATERN, param=2.5)),
+        ("Matern(7.25)", cg.Matern(7.25), o.Kernel(o.MATERN, param=7.25)),
     ]
 
 
@@ -41,12 +47,13 @@ def composite_cases(cg):
 
 def valgrad_cases(cg):
     keep = {"EQ", "RQ(1.0)", "MaternP(2)", "Dot()^3", "ExponentialDot", "Lengthscale(EQ,0.7)", "Cauchy", "EQ^2",
-            "2.5*Lengthscale(MaternP(2),1.3)"}
+            "2.5*Lengthscale(MaternP(2),1.3)", "1.5*Matern(2.7)"}
     return [c for c in cases(cg) if c[0] in keep] + composite_cases(cg)
 
 
 # kernels whose phi', phi'' are finite at s = 0 (gradient Gramian well defined on the diagonal)
 def grad_cases(cg):
     keep = {"EQ", "RQ(1.0)", "RQ(0.37)", "Cauchy", "IMQ(0.8)", "MaternP(2)", "MaternP(3)", "Lengthscale(EQ,0.7)",
-            "2.5*Lengthscale(MaternP(2),1.3)", "Dot()^3", "Dot()", "ExponentialDot", "EQ^2"}
+            "2.5*Lengthscale(MaternP(2),1.3)", "Dot()^3", "Dot()", "ExponentialDot", "EQ^2", "1.5*Matern(2.7)", "Matern(2.5)",
+            "Matern(7.25)"}
     return [c for c in cases(cg) if c[0] in keep]

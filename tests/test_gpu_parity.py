@@ -696,3 +696,31 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
         assert relerr((Tn @ ad).cpu().numpy(), oracle.toeplitz_mul(None, vc2, vr2, a.astype(np.float64))) <= tol
     finally:
         cg.set_option("toeplitz_fused", 1)
+
+
+def test_matern_real_nu_golden(cg, oracle):
+    """Matern(nu) with the device Bessel function (Temme series / Steed continued fraction) against the mpmath-checked fixtures:
+    dense, gradient and value-gradient MVMs; Matern(p + 1/2) equals MaternP(p); Matrix(G) diagonal is exactly 1."""
+    g = np.load(f"{GOLD}/composite.npz")
+    for d in (1, 3, 8):
+        for (n, m) in ((4, 6), (65, 33)):
+            tag = f"d{d}_n{n}_m{m}"
+            X, Y, a, y0, ag, yg0, av, yv0 = (g[f"{tag}_{s}"] for s in ("X", "Y", "a", "y0", "ag", "yg0", "av", "yv0"))
+            alpha, beta = g[f"{tag}_ab"]
+            Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+            for name in g["matern_names"]:
+                fam, p, power, param, ls, sc = g[f"matern_{name}_fields"]
+                k = sc * cg.Lengthscale(cg.Matern(param), ls) if ls != 1.0 else sc * cg.Matern(param)
+                for K, vec, y_init, key in ((cg.gramian(k, Xd, Yd), a, y0, "b"), (cg.gramian(cg.GradientKernel(k), Xd, Yd), ag, yg0, "bg"),
+                                            (cg.gramian(cg.ValueGradientKernel(k), Xd, Yd), av, yv0, "bv")):
+                    yd = torch.from_numpy(y_init.copy()).cuda()
+                    cg.mul_(yd, K, torch.from_numpy(vec).cuda(), alpha, beta)
+                    assert relerr(yd.cpu().numpy(), g[f"{tag}_{name}_{key}"]) <= 1e-12, (name, tag, key, relerr(yd.cpu().numpy(), g[f"{tag}_{name}_{key}"]))
+    rng = np.random.default_rng(8)
+    X = torch.from_numpy(rng.standard_normal((200, 3))).cuda(); a = torch.from_numpy(rng.standard_normal(200)).cuda()
+    for p in (0, 1, 2, 3):
+        assert relerr((cg.gramian(cg.Matern(p + 0.5), X) @ a).cpu().numpy(), (cg.gramian(cg.MaternP(p), X) @ a).cpu().numpy()) <= 1e-12
+    M = cg.gramian(cg.Matern(0.8), X).to_dense()
+    assert torch.all(torch.diagonal(M) == 1.0) and bool(torch.isfinite(M).all())
+    with pytest.raises(cg.DomainError):
+        cg.Matern(-1.0)

@@ -118,7 +118,9 @@ def test_kernel_lowering_and_folding(cg):
     assert s.power == 3 and s.scale == 8.0
     s = cg.device_spec(cg.Lengthscale(cg.Lengthscale(cg.EQ(), 2.0), 3.0))
     assert s.lengthscale == 6.0
-    assert cg.device_spec(cg.Matern(2.7)) is None
+    s = cg.device_spec(2.0 * cg.Lengthscale(cg.Matern(2.7), 0.4))
+    assert (s.family, s.trait, s.param, s.lengthscale, s.scale) == (cg._ffi.MATERN, cg._ffi.ISOTROPIC, 2.7, 0.4, 2.0)
+    assert cg.device_spec(cg.FiniteBasis([lambda t: t])) is None
     assert cg.device_spec(cg.RQ(0.3)).param == 0.3 and cg.device_spec(cg.InverseMultiQuadratic(1.5)).param == 1.5
     with pytest.raises(cg.DomainError):
         cg.RQ(-1.0)
@@ -151,7 +153,9 @@ def test_composite_lowering(cg):
     assert isinstance(cg.input_trait(cg.EQ() * cg.RQ(1.0)), cg.IsotropicInput)
     # outside the device set
     assert cg.device_spec(cg.EQ() + cg.Dot()) is None and isinstance(cg.input_trait(cg.EQ() + cg.Dot()), cg.GenericInput)
-    assert cg.device_spec(cg.EQ() + cg.Matern(2.7)) is None
+    c = cg.device_spec(cg.EQ() + cg.Matern(2.7))
+    assert c.nterms == 2 and c.factors[1].family == f.MATERN and c.factors[1].param == 2.7
+    assert cg.device_spec(cg.EQ() + cg.FiniteBasis([lambda t: t])) is None          # no device profile at all
     five = cg.EQ() + cg.RQ(1.0) + cg.Cauchy() + cg.Exp() + cg.MaternP(1)
     assert cg.device_spec(five) is None                                # more than COVGRAM_COMPOSITE_MAX_TERMS
     seven = cg.EQ() * cg.RQ(1.0) * cg.Cauchy() * cg.Exp() * cg.MaternP(1) * cg.MaternP(2) * cg.MaternP(3)

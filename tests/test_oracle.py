@@ -159,7 +159,11 @@ def test_golden_composite_and_value_gradient():
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
     import make_golden as mg
     g = np.load(f"{GOLD}/composite.npz")
-    kernels = dict(mg.COMPOSITES); kernels.update({nm: mg.KERNELS[nm] for nm in mg.VALGRAD_KERNELS})
+    kernels = dict(mg.COMPOSITES); kernels.update({nm: mg.KERNELS[nm] for nm in mg.VALGRAD_KERNELS}); kernels.update(mg.MATERN_KERNELS)
+    # Matern(p + 1/2) with the Bessel function == MaternP(p) with the closed form (src/stationary.jl:85, 117-131)
+    ss = np.array([0.0, 1e-9, 1e-3, 0.5, 3.0, 20.0, 400.0])
+    for p in (0, 1, 2, 3, 5):
+        assert np.allclose(o.profile(o.Kernel(o.MATERN, param=p + 0.5), ss), o.profile(o.Kernel(o.MATERNP, p=p), ss), rtol=1e-13, atol=1e-300)
     for d in (1, 3, 8):
         for (n, m) in ((4, 6), (65, 33)):
             tag = f"d{d}_n{n}_m{m}"
@@ -167,7 +171,7 @@ def test_golden_composite_and_value_gradient():
             alpha, beta = g[f"{tag}_ab"]
             for name, k in kernels.items():
                 assert rel(o.valgrad_mul(yv0, k, X, Y, av, alpha, beta), g[f"{tag}_{name}_bv"]) < 1e-14
-                if name in mg.COMPOSITES:
+                if name in mg.COMPOSITES or name in mg.MATERN_KERNELS:
                     assert rel(o.mul(y0, k, X, Y, a, alpha, beta), g[f"{tag}_{name}_b"]) < 1e-14
                     assert rel(o.grad_mul(yg0, k, X, Y, ag, alpha, beta), g[f"{tag}_{name}_bg"]) < 1e-14
                 if n == 4:
@@ -195,6 +199,8 @@ def test_golden_composite_and_value_gradient():
     # symmetric case: the value-gradient Gramian is symmetric (test/gradient.jl:100-104)
     Xs = rng.standard_normal((5, 2))
     for k in kernels.values():
+        if getattr(k, "family", None) == o.MATERN and k.param <= 2:
+            continue                                        # phi'' (nu <= 2) / phi' (nu <= 1) are singular at r = 0, like Exp
         M = o.valgrad_matrix(k, Xs, Xs)
         assert np.abs(M - M.T).max() < 1e-12 * max(1.0, np.abs(M).max())
 
