@@ -15,7 +15,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
 # enums (include/covgram.h)
 EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN = range(10)
 CONSTANT, COMPOSITE = 100, 101
-COMPOSITE_MAX_TERMS, COMPOSITE_MAX_FACTORS = 4, 6
+COMPOSITE_MAX_TERMS, COMPOSITE_MAX_FACTORS = 8, 8
 ISOTROPIC, DOTPRODUCT = 1, 2
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1

@@ -554,6 +554,63 @@ class LazyMatrixProduct(LazyOperator):
         return self.U @ self.V.t()
 
 
+class ScaledOperator(LazyOperator):
+    """Diagonal(dx) · K · Diagonal(dy), lazy — gramian(::VerticalRescaling) (src/transformation.jl:165-171 builds exactly this
+    LazyMatrixProduct(Dx, K, Dy)).  The two diagonal scalings are O(n) vector ops around K's own MVM."""
+
+    def __init__(self, dx: torch.Tensor, K: LazyOperator, dy: torch.Tensor):
+        self.dx, self.K, self.dy = dx, K, dy
+        self.shape, self.dtype, self.device = K.shape, K.dtype, K.device
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
+        sa = self.dy * a if a.dim() == 1 else self.dy[:, None] * a
+        t = self.K @ sa
+        t = self.dx * t if t.dim() == 1 else self.dx[:, None] * t
+        return y.copy_(alpha * t) if beta == 0 else y.mul_(beta).add_(t, alpha=alpha)
+
+    def to_dense(self):
+        return self.dx[:, None] * self.K.to_dense() * self.dy[None, :]
+
+
+class LinearMapBlockGramian(LazyOperator):
+    """Gradient Gramian of k(Ux, Uy): block (i, j) = Uᵀ B_ij(Ux, Uy) U (chain rule), applied as  b_i = Uᵀ Σ_j B_ij (U a_j):
+    two small (d′ × d) maps around the device block MVM on the transformed points.  U: (d′, d) matrix or a length-d diagonal."""
+
+    def __init__(self, U: torch.Tensor, inner: "BlockGramian", d: int):
+        self.U, self.inner, self.d = U, inner, d
+        n, m = inner.inner.shape
+        self.shape = (n * d, m * d)
+        self.dtype, self.device = inner.dtype, inner.device
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        n, m = self.inner.inner.shape
+        A = _vec_arg(a, self.shape[1], self.dtype, self.device, "a").reshape(m, self.d)
+        UA = (A * self.U if self.U.dim() == 1 else A @ self.U.t()).contiguous()
+        t = (self.inner @ UA.reshape(-1)).reshape(n, -1)
+        b = (t * self.U if self.U.dim() == 1 else t @ self.U).reshape(-1)
+        return y.copy_(alpha * b) if beta == 0 else y.mul_(beta).add_(b, alpha=alpha)
+
+
+class CosineBlockGramian(LazyOperator):
+    """Gradient Gramian of the Cosine kernel (src/gradient.jl:129-136): block (i, j) = −k₂ c cᵀ with k₂ = −4π² cos(2π c·(x_i − y_j)),
+    i.e. (rank-2 scalar Gramian) ⊗ c cᵀ:  b_i = 4π² c Σ_j cos(u_i − v_j) (c·a_j)."""
+
+    def __init__(self, c: torch.Tensor, scalar: "LazyMatrixProduct"):
+        self.c, self.scalar = c, scalar
+        d = c.shape[0]
+        self.d = d
+        self.shape = (scalar.shape[0] * d, scalar.shape[1] * d)
+        self.dtype, self.device = scalar.dtype, scalar.device
+
+    def mul_(self, y, a, alpha=1.0, beta=0.0):
+        n, m = self.scalar.shape
+        A = _vec_arg(a, self.shape[1], self.dtype, self.device, "a").reshape(m, self.d)
+        t = self.scalar @ (A @ self.c).contiguous()
+        b = ((4 * math.pi ** 2) * t[:, None] * self.c[None, :]).reshape(-1)
+        return y.copy_(alpha * b) if beta == 0 else y.mul_(beta).add_(b, alpha=alpha)
+
+
 class LazyMatrixSum(LazyOperator):
     """D + G kept lazy (src/gramian.jl:55-60, src/lazy_linear_algebra.jl:91-133): mul! accumulates the
     terms with β = 1 after the first."""
@@ -610,6 +667,38 @@ def _first_column(k, x: torch.Tensor, y0: torch.Tensor) -> torch.Tensor:
     return Gramian(k, x, y0.reshape(1, -1)).to_dense()[:, 0].contiguous()
 
 
+def _transform_points(k, p: torch.Tensor) -> torch.Tensor:
+    """u(x) for every point (one O(n d d′) pass on the device): ScaledInputKernel / ARD, Warped, Periodic."""
+    if isinstance(k, K.ScaledInputKernel):
+        U = torch.as_tensor(k.U, dtype=p.dtype, device=p.device)
+        return (p * U if U.dim() == 1 else p @ U.t()).contiguous()
+    if isinstance(k, K.Warped):
+        if callable(k.u):
+            return torch.as_tensor(k.u(p), dtype=p.dtype, device=p.device).reshape(p.shape[0], -1).contiguous()
+        U = torch.as_tensor(k.u, dtype=p.dtype, device=p.device)
+        return (p @ U.t()).contiguous()
+    if isinstance(k, K.Periodic):
+        if p.shape[1] != 1:
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, "Periodic: input has to be one-dimensional (src/transformation.jl:53)")
+        ang = (2 * math.pi) * p[:, 0]
+        return torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).contiguous()
+    raise TypeError(type(k))
+
+
+def _cosine_lowrank(k, px: torch.Tensor, py: torch.Tensor, same: bool):
+    c = torch.as_tensor(k.c, dtype=px.dtype, device=px.device)
+    if c.numel() == 1 and px.shape[1] != 1:
+        c = c.expand(px.shape[1])
+    if c.shape[0] != px.shape[1]:
+        raise _ffi.DimensionMismatch(_ffi.EINVAL, f"Cosine: length(c) = {c.shape[0]} ≠ d = {px.shape[1]}")
+    u = (2 * math.pi) * (px @ c)
+    U = torch.stack([torch.cos(u), torch.sin(u)], dim=1)
+    if same:
+        return LazyMatrixProduct(U, U)
+    v = (2 * math.pi) * (py @ c)
+    return LazyMatrixProduct(U, torch.stack([torch.cos(v), torch.sin(v)], dim=1))
+
+
 def gramian(k, x=None, y=None, trait: Optional[K.InputTrait] = None):
     """gramian(k, x[, y][, trait]) — picks the representation exactly as the reference does."""
     if x is None:
@@ -638,6 +727,34 @@ def gramian(k, x=None, y=None, trait: Optional[K.InputTrait] = None):
             V = U if same else basis(py)
             return LazyMatrixProduct(U, V)
         raise _ffi.UnsupportedKernel(_ffi.EUNSUPPORTED, "FiniteBasis with fewer points than basis functions is a GenericInput Gramian (src/mercer.jl:68)")
+
+    # ---- input / output transformations: the points are transformed ONCE, the hot path runs on the result -------------------
+    if isinstance(k, K.VerticalRescaling):                     # src/transformation.jl:165-171
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        fx = torch.as_tensor(k.f(px), dtype=px.dtype, device=px.device).reshape(-1)
+        fy = fx if same else torch.as_tensor(k.f(py), dtype=px.dtype, device=px.device).reshape(-1)
+        return ScaledOperator(fx, gramian(k.k, px, None if same else py), fy)
+    if isinstance(k, (K.ScaledInputKernel, K.Warped, K.Periodic)):   # src/transformation.jl:82-90, 114-118, 54-65
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        tx = _transform_points(k, px)
+        return gramian(k.k, tx, None if same else _transform_points(k, py))
+    if isinstance(k, K.CosineKernel):                           # rank 2: cos(u_i − v_j) = cos u_i cos v_j + sin u_i sin v_j
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        return _cosine_lowrank(k, px, py, same)
+    if isinstance(k, K.GradientKernel) and isinstance(k.k, K.ScaledInputKernel):
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        U = torch.as_tensor(k.k.U, dtype=px.dtype, device=px.device)
+        tx = _transform_points(k.k, px)
+        inner = BlockGramian(K.GradientKernel(k.k.k), tx, None if same else _transform_points(k.k, py))
+        return LinearMapBlockGramian(U, inner, px.shape[1])
+    if isinstance(k, K.GradientKernel) and isinstance(k.k, K.CosineKernel):
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        return CosineBlockGramian(torch.as_tensor(k.k.c, dtype=px.dtype, device=px.device), _cosine_lowrank(k.k, px, py, same))
 
     if isinstance(k, (K.GradientKernel, K.ValueGradientKernel)):   # src/gramian.jl:120-123
         return BlockGramian(k, x, None if same else y)

@@ -263,6 +263,101 @@ class ExponentialDot(DotProductKernel):
         return math.exp(s)                                   # src/mercer.jl:22
 
 
+def Line(sigma: float = 0.0):
+    """Line(σ) = Dot() + σ (src/mercer.jl:12)."""
+    return Dot() + sigma
+
+
+def Polynomial(d: int, sigma: float = 0.0):
+    """Polynomial(d, σ) = Line(σ)^d (src/mercer.jl:13-14); lowers to a composite of Dot powers on the device."""
+    return Line(sigma) ** int(d)
+
+
+Poly = Polynomial
+
+
+class CosineKernel(StationaryKernel):
+    """k(x, y) = cos(2π c·(x − y)) (src/stationary.jl:197-211), input_trait = StationaryLinearFunctionalInput.
+    cos(u_i − v_j) = cos u_i cos v_j + sin u_i sin v_j: its Gramian has rank 2 (the reference's own "IDEA: trig-identity ->
+    low-rank gramian", :204) and is represented as such here."""
+
+    def __init__(self, c):
+        self.c = np.atleast_1d(np.asarray(c, dtype=np.float64))
+
+    def __call__(self, *args):
+        if len(args) == 2:
+            x = np.atleast_1d(np.asarray(args[0], dtype=np.float64)); y = np.atleast_1d(np.asarray(args[1], dtype=np.float64))
+            return math.cos(2 * math.pi * float(np.dot(self.c, x - y)))
+        return math.cos(2 * math.pi * float(args[0]))
+
+
+Cosine = Cos = CosineKernel
+
+
+class Periodic(StationaryKernel):
+    """Periodic(k)(τ) = k((2 sin(πτ))²) for 1-D inputs (src/transformation.jl:54-65): the isotropic kernel k on the circle
+    embedding e(x) = (cos 2πx, sin 2πx), since |e(x) − e(y)|² = 4 sin²(π(x − y))."""
+
+    def __init__(self, k):
+        if not isinstance(k, IsotropicKernel):
+            raise TypeError("Periodic(k::IsotropicKernel)")
+        self.k = k
+
+    def __call__(self, *args):
+        tau = float(args[0]) - float(args[1]) if len(args) == 2 else float(args[0])
+        return self.k.profile((2 * math.sin(math.pi * tau)) ** 2)
+
+
+class ScaledInputKernel(AbstractKernel):
+    """ScaledInputKernel(k, U)(x, y) = k(U x, U y) (src/transformation.jl:71-79); `gramian` pre-multiplies the points once
+    (:82-90).  ARD(k, l) (:42-46) is the diagonal case U = Diagonal(1 ./ l)."""
+
+    def __init__(self, k, U):
+        self.k = k
+        self.U = np.asarray(U, dtype=np.float64)
+        self.diagonal = self.U.ndim == 1
+
+    def __call__(self, x, y):
+        x = np.atleast_1d(np.asarray(x, dtype=np.float64)); y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+        return self.k(self.U * x, self.U * y) if self.diagonal else self.k(self.U @ x, self.U @ y)
+
+
+def ARD(k, l):
+    """Automatic relevance determination (src/transformation.jl:42-46): k on inputs scaled by 1 ./ l; scalar l = Lengthscale."""
+    if np.ndim(l) == 0:
+        return Lengthscale(k, l)
+    l = np.asarray(l, dtype=np.float64)
+    if not np.all(l > 0):
+        raise DomainError(f"l = {l} is non-positive")
+    return ScaledInputKernel(k, 1.0 / l)
+
+
+class Warped(AbstractKernel):
+    """Warped(k, u)(x, y) = k(u(x), u(y)) (src/transformation.jl:98-110); u is a matrix or a callable that maps an (n, d) tensor of
+    points to an (n, d') tensor (vectorised over points); `gramian` warps the points once (:114-118)."""
+
+    def __init__(self, k, u):
+        self.k = k
+        self.u = u
+
+    def __call__(self, x, y):
+        u = (lambda z: np.asarray(self.u) @ z) if not callable(self.u) else (lambda z: np.asarray(self.u(np.atleast_2d(z)))[0])
+        return self.k(u(np.atleast_1d(np.asarray(x, dtype=np.float64))), u(np.atleast_1d(np.asarray(y, dtype=np.float64))))
+
+
+class VerticalRescaling(AbstractKernel):
+    """VerticalRescaling(k, f)(x, y) = f(x) k(x, y) f(y) (src/transformation.jl:156-171): Diagonal · gramian(k) · Diagonal; f is
+    vectorised over an (n, d) tensor of points and returns n values."""
+
+    def __init__(self, k, f):
+        self.k, self.f = k, f
+
+    def __call__(self, x, y):
+        fx = float(np.asarray(self.f(np.atleast_2d(np.asarray(x, dtype=np.float64)))).reshape(-1)[0])
+        fy = float(np.asarray(self.f(np.atleast_2d(np.asarray(y, dtype=np.float64)))).reshape(-1)[0])
+        return fx * self.k(x, y) * fy
+
+
 class FiniteBasis(MercerKernel):
     """src/mercer.jl:41-70: k(x,y) = Σ_b b(x) b(y); basis functions are vectorised callables."""
 
@@ -419,6 +514,8 @@ def input_trait(k) -> InputTrait:
         return k.input_trait
     if isinstance(k, (Dot, ExponentialDot)):
         return DotProductInput()
+    if isinstance(k, CosineKernel):
+        return StationaryLinearFunctionalInput()             # src/stationary.jl:206
     if isinstance(k, IsotropicKernel):
         return IsotropicInput()
     if isinstance(k, StationaryKernel):
@@ -533,6 +630,17 @@ def device_spec(k):
     terms = _expand(k)
     if not terms:
         return None
+    # within a term, identical profiles multiply into one factor with a higher Power: phi^a phi^b = phi^(a+b)
+    def _pow_merge(fs):
+        out = {}
+        for f in fs:
+            key = (f.family, f.p, f.param, f.lengthscale)
+            if key in out:
+                out[key].power += f.power
+            else:
+                g = _ffi.covgram_kernel(); _copy_spec(g, f); out[key] = g
+        return list(out.values())
+    terms = [(c, _pow_merge(fs)) for c, fs in terms]
     # merge like terms (pure constants included), drop zero terms
     merged = {}
     for c, fs in terms:

@@ -100,8 +100,8 @@ typedef struct covgram_kernel {
  * own scale, lengthscale and power (or family COVGRAM_CONSTANT: just `scale`).  Every entry point that takes a
  * `const covgram_kernel*` accepts `&composite.head` (head.family == COVGRAM_COMPOSITE, head.trait = the common trait,
  * head.power == 1, head.lengthscale == 1). */
-#define COVGRAM_COMPOSITE_MAX_TERMS 4
-#define COVGRAM_COMPOSITE_MAX_FACTORS 6
+#define COVGRAM_COMPOSITE_MAX_TERMS 8
+#define COVGRAM_COMPOSITE_MAX_FACTORS 8
 typedef struct covgram_kernel_composite {
     covgram_kernel head;
     int32_t nterms;

@@ -683,3 +683,49 @@ def pivoted_cholesky(A, tol=0.0, max_rank=None):
         d[piv[:k + 1]] = 0.0
         rank = k + 1
     return L[:, :rank], piv, rank
+
+
+# ----------------------------------------------------------------------------------------
+# Input / output transformations (src/transformation.jl) and the Cosine kernel (src/stationary.jl:197-211), by definition
+# ----------------------------------------------------------------------------------------
+def scaled_input_points(U, X):
+    """(S::ScaledInputKernel)(x, y) = S.k(S.U*x, S.U*y) (transformation.jl:79); ARD(k, l) is U = Diagonal(1 ./ l) (:42-45).
+    U: (d', d) matrix or a length-d diagonal."""
+    U = np.asarray(U, dtype=np.float64); X = as_points(X).astype(np.float64)
+    return X * U if U.ndim == 1 else X @ U.T
+
+
+def periodic_matrix(k: Kernel, x, y=None, dtype=np.float64):
+    """Periodic(k)(τ) = k((2 sin(π τ))²) for one-dimensional inputs (transformation.jl:61-65)."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1); y = x if y is None else np.asarray(y, dtype=np.float64).reshape(-1)
+    tau = x[:, None] - y[None, :]
+    return profile(k, (2 * np.sin(np.pi * tau)) ** 2, dtype)
+
+
+def cosine_matrix(c, X, Y=None):
+    """Cosine(c)(x, y) = cos(2π c·(x − y)) (stationary.jl:207-211)."""
+    X = as_points(X).astype(np.float64); Y = X if Y is None else as_points(Y).astype(np.float64)
+    c = np.asarray(c, dtype=np.float64).reshape(-1)
+    return np.cos(2 * np.pi * ((X @ c)[:, None] - (Y @ c)[None, :]))
+
+
+def cosine_grad_matrix(c, X, Y=None):
+    """Gradient Gramian of Cosine: block = −k₂ c c' (gradient.jl:129-136), k₂ = d²/dz² cos(2π z) = −4π² cos(2π c·r)."""
+    X = as_points(X).astype(np.float64); Y = X if Y is None else as_points(Y).astype(np.float64)
+    c = np.asarray(c, dtype=np.float64).reshape(-1)
+    return np.kron(4 * np.pi ** 2 * cosine_matrix(c, X, Y), np.outer(c, c))
+
+
+def linear_map_grad_matrix(k: Kernel, U, X, Y=None, dtype=np.float64):
+    """∂x ∂y' k(Ux, Uy) = U' B(Ux, Uy) U (chain rule through transformation.jl:79): dense (n d) × (m d) matrix."""
+    U = np.asarray(U, dtype=np.float64)
+    Um = np.diag(U) if U.ndim == 1 else U
+    X = as_points(X).astype(np.float64); Y = X if Y is None else as_points(Y).astype(np.float64)
+    TX, TY = scaled_input_points(U, X), scaled_input_points(U, Y)
+    n, m, d, dp = X.shape[0], Y.shape[0], X.shape[1], Um.shape[0]
+    inner = grad_matrix(k, TX, TY, dtype)
+    M = np.zeros((n * d, m * d))
+    for i in range(n):
+        for j in range(m):
+            M[i * d:(i + 1) * d, j * d:(j + 1) * d] = Um.T @ inner[i * dp:(i + 1) * dp, j * dp:(j + 1) * dp] @ Um
+    return M

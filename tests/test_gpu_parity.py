@@ -724,3 +724,53 @@ def test_matern_real_nu_golden(cg, oracle):
     assert torch.all(torch.diagonal(M) == 1.0) and bool(torch.isfinite(M).all())
     with pytest.raises(cg.DomainError):
         cg.Matern(-1.0)
+
+
+def test_transformed_kernels(cg, oracle):
+    """ARD / ScaledInputKernel / Warped / Periodic / VerticalRescaling / Cosine / Polynomial (src/transformation.jl,
+    src/stationary.jl:197-211, src/mercer.jl:12-14): the points (or the output) are transformed once on the host side and the
+    hot path does the rest — against the definitions restated in the oracle; test/stationary.jl:132-175, test/transformation.jl:12-45."""
+    rng = np.random.default_rng(17)
+    n, m, d = 70, 45, 3
+    X = rng.standard_normal((n, d)); Y = rng.standard_normal((m, d))
+    a = rng.standard_normal(m); ag = rng.standard_normal(m * d)
+    Xd, Yd, ad, agd = (torch.from_numpy(v).cuda() for v in (X, Y, a, ag))
+    ko = oracle.Kernel(oracle.MATERNP, p=2)
+    # ARD == scaled inputs; ScaledInputKernel with a rectangular U; Warped with a callable
+    l = np.array([0.5, 1.3, 2.0])
+    G = cg.gramian(cg.ARD(cg.MaternP(2), l), Xd, Yd)
+    assert relerr((G @ ad).cpu().numpy(), oracle.matrix(ko, oracle.scaled_input_points(1 / l, X), oracle.scaled_input_points(1 / l, Y)) @ a) <= 1e-12
+    assert isinstance(cg.ARD(cg.EQ(), 2.0), cg.Lengthscale)                                       # scalar l: plain Lengthscale
+    U = rng.standard_normal((5, d))
+    G = cg.gramian(cg.ScaledInputKernel(cg.RQ(1.0), U), Xd, Yd)
+    assert relerr((G @ ad).cpu().numpy(), oracle.matrix(oracle.Kernel(oracle.RQ, param=1.0), oracle.scaled_input_points(U, X), oracle.scaled_input_points(U, Y)) @ a) <= 1e-12
+    G = cg.gramian(cg.Warped(cg.EQ(), lambda p: torch.tanh(p)), Xd, Yd)
+    assert relerr((G @ ad).cpu().numpy(), oracle.matrix(oracle.Kernel(oracle.EQ), np.tanh(X), np.tanh(Y)) @ a) <= 1e-12
+    # gradient Gramians through the linear maps (chain rule U' B U)
+    K = cg.gramian(cg.GradientKernel(cg.ARD(cg.MaternP(2), l)), Xd, Yd)
+    assert relerr((K @ agd).cpu().numpy(), oracle.linear_map_grad_matrix(ko, 1 / l, X, Y) @ ag) <= 1e-12
+    K = cg.gramian(cg.GradientKernel(cg.ScaledInputKernel(cg.EQ(), U)), Xd, Yd)
+    assert relerr((K @ agd).cpu().numpy(), oracle.linear_map_grad_matrix(oracle.Kernel(oracle.EQ), U, X, Y) @ ag) <= 1e-12
+    # Periodic on 1-D inputs, incl. a regular grid (stays a plain Gramian on the embedded points)
+    x1 = rng.standard_normal(60); y1 = rng.standard_normal(33); a1 = rng.standard_normal(33)
+    P = cg.gramian(cg.Periodic(cg.EQ()), torch.from_numpy(x1).cuda(), torch.from_numpy(y1).cuda())
+    assert relerr((P @ torch.from_numpy(a1).cuda()).cpu().numpy(), oracle.periodic_matrix(oracle.Kernel(oracle.EQ), x1, y1) @ a1) <= 1e-12
+    assert abs(cg.Periodic(cg.EQ())(0.3, 1.3) - 1.0) < 1e-12                                       # 1-periodic
+    # VerticalRescaling = Diagonal * G * Diagonal
+    f = lambda p: 1.0 / (1.0 + (p * p).sum(dim=1) if torch.is_tensor(p) else 1.0 / (1.0 + (np.asarray(p) ** 2).sum(axis=1)))
+    fnp = lambda p: 1.0 / (1.0 + (p ** 2).sum(axis=1))
+    V = cg.gramian(cg.VerticalRescaling(cg.MaternP(2), lambda p: 1.0 / (1.0 + (p * p).sum(1))), Xd, Yd)
+    assert isinstance(V, cg.ScaledOperator)
+    ref = fnp(X)[:, None] * oracle.matrix(ko, X, Y) * fnp(Y)[None, :]
+    assert relerr((V @ ad).cpu().numpy(), ref @ a) <= 1e-12 and relerr(V.to_dense().cpu().numpy(), ref) <= 1e-12
+    # Cosine: rank-2 Gramian, and its gradient Gramian (rank-2) x (c c')
+    c = rng.standard_normal(d) * 0.3
+    C = cg.gramian(cg.Cosine(c), Xd, Yd)
+    assert isinstance(C, cg.LazyMatrixProduct) and C.U.shape[1] == 2
+    assert relerr((C @ ad).cpu().numpy(), oracle.cosine_matrix(c, X, Y) @ a) <= 1e-12
+    KC = cg.gramian(cg.GradientKernel(cg.Cosine(c)), Xd, Yd)
+    assert relerr((KC @ agd).cpu().numpy(), oracle.cosine_grad_matrix(c, X, Y) @ ag) <= 1e-12
+    assert isinstance(cg.input_trait(cg.Cosine(c)), cg.StationaryLinearFunctionalInput)
+    # Polynomial(d, sigma) = (Dot() + sigma)^d as one composite
+    Pk = cg.gramian(cg.Polynomial(4, 0.5), Xd, Yd)
+    assert relerr((Pk @ ad).cpu().numpy(), ((X @ Y.T + 0.5) ** 4) @ a) <= 1e-12

@@ -146,8 +146,9 @@ def test_composite_lowering(cg):
     assert c.factors[2].lengthscale == 0.5
     # Power of a composite multiplies out; constants merge into one CONSTANT term
     c = cg.device_spec((cg.EQ() + 1.0) ** 2)
-    assert c.nterms == 3 and sorted(c.factors[i].family for i in range(4)) == [f.EQ, f.EQ, f.EQ, f.CONSTANT]
-    assert list(c.nfactors)[:3] == [2, 1, 1] and [c.factors[i].scale for i in range(4)] == [1.0, 1.0, 2.0, 1.0]   # k² + 2k + 1
+    assert c.nterms == 3 and [c.factors[i].family for i in range(3)] == [f.EQ, f.EQ, f.CONSTANT]
+    assert list(c.nfactors)[:3] == [1, 1, 1]                                                        # k² + 2k + 1 ...
+    assert [(c.factors[i].power, c.factors[i].scale) for i in range(3)] == [(2, 1.0), (1, 2.0), (1, 1.0)]   # ... with k·k merged into Power 2
     c = cg.device_spec(cg.Dot() ** 2 + 0.3 * cg.ExponentialDot())
     assert c.head.trait == f.DOTPRODUCT and c.factors[0].power == 2 and c.factors[1].scale == 0.3
     assert isinstance(cg.input_trait(cg.EQ() * cg.RQ(1.0)), cg.IsotropicInput)
@@ -157,9 +158,13 @@ def test_composite_lowering(cg):
     assert c.nterms == 2 and c.factors[1].family == f.MATERN and c.factors[1].param == 2.7
     assert cg.device_spec(cg.EQ() + cg.FiniteBasis([lambda t: t])) is None          # no device profile at all
     five = cg.EQ() + cg.RQ(1.0) + cg.Cauchy() + cg.Exp() + cg.MaternP(1)
-    assert cg.device_spec(five) is None                                # more than COVGRAM_COMPOSITE_MAX_TERMS
-    seven = cg.EQ() * cg.RQ(1.0) * cg.Cauchy() * cg.Exp() * cg.MaternP(1) * cg.MaternP(2) * cg.MaternP(3)
-    assert cg.device_spec(seven) is None                               # more than COVGRAM_COMPOSITE_MAX_FACTORS
+    assert cg.device_spec(five).nterms == 5
+    nine = five + cg.MaternP(2) + cg.MaternP(3) + cg.RQ(2.0) + cg.GammaExp(1.0)
+    assert cg.device_spec(nine) is None                                # more than COVGRAM_COMPOSITE_MAX_TERMS (8)
+    prod9 = cg.EQ() * cg.RQ(1.0) * cg.Cauchy() * cg.Exp() * cg.MaternP(1) * cg.MaternP(2) * cg.MaternP(3) * cg.RQ(2.0) * cg.GammaExp(1.0)
+    assert cg.device_spec(prod9) is None                               # more than COVGRAM_COMPOSITE_MAX_FACTORS (8)
+    p4 = cg.device_spec(cg.Polynomial(4, 0.5))                         # (Dot + 0.5)^4 = Dot^4 + 2 Dot^3 + 1.5 Dot^2 + 0.5 Dot + 0.0625
+    assert p4.nterms == 5 and [(p4.factors[i].power, p4.factors[i].scale) for i in range(5)] == [(4, 1.0), (3, 2.0), (2, 1.5), (1, 0.5), (1, 0.0625)]
     # host evaluation of the algebra agrees with the oracle's composite
     import kernel_cases
     rng = np.random.default_rng(11)
