@@ -29,7 +29,10 @@ class ShardedGramian:
     `local_factory(k, x_rows, y)` builds the local operator; by default the device `gramian`.  (The CPU
     multi-process tests inject a factory so that the sharding + collective logic runs under gloo.)"""
 
-    def __init__(self, k, x, y=None, group=None, local_factory: Optional[Callable] = None):
+    def __init__(self, k, x, y=None, group=None, local_factory: Optional[Callable] = None, block: Optional[int] = None):
+        """block: entries per point of the flat vectors — 1 for scalar kernels, d for GradientKernel, d + 1 for
+        ValueGradientKernel Gramians (inferred from the kernel when not given): rank g then owns the rows
+        [lo_g * block, hi_g * block) of the flat output and the all-gather moves ceil(n/P) * block entries per rank."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -45,7 +48,12 @@ class ShardedGramian:
             self.local = local_factory(k, x_rows, y_full)
         else:
             self.local = None
-        self.shape = (self.n, self.m)
+        if block is None:
+            from . import kernels as _K
+            d = x.shape[1] if x.dim() > 1 else 1
+            block = d if isinstance(k, _K.GradientKernel) else (d + 1 if isinstance(k, _K.ValueGradientKernel) else 1)
+        self.block = int(block)
+        self.shape = (self.n * self.block, self.m * self.block)
         # exercise the collective even on one rank (used to validate the RCCL path on single-GPU boxes)
         self.force_collective = bool(int(__import__("os").environ.get("COVGRAM_FORCE_COLLECTIVE", "0"))) and dist.is_initialized()
 
@@ -53,8 +61,8 @@ class ShardedGramian:
         key = (tuple(a.shape[1:]), a.dtype, a.device)
         if getattr(self, "_buf_key", None) != key:
             tail = tuple(a.shape[1:])
-            self._shard = torch.zeros((self.per,) + tail, dtype=a.dtype, device=a.device)
-            self._full = torch.empty((self.per * self.world,) + tail, dtype=a.dtype, device=a.device)
+            self._shard = torch.zeros((self.per * self.block,) + tail, dtype=a.dtype, device=a.device)
+            self._full = torch.empty((self.per * self.world * self.block,) + tail, dtype=a.dtype, device=a.device)
             self._buf_key = key
         return self._shard, self._full
 
@@ -68,10 +76,10 @@ class ShardedGramian:
     def matmul(self, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """b = G a, complete on every rank.  a: (m,) or (m, p), replicated.  Buffers are allocated once and reused
         (Krylov callers multiply with the same shapes every iteration)."""
-        rows = self.hi - self.lo
+        rows = (self.hi - self.lo) * self.block
         if self.world == 1 and not self.force_collective:
             if out is None:
-                out = torch.empty((self.n,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+                out = torch.empty((self.n * self.block,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
             if self.local is not None:
                 self._local_into(out, a)
             return out
@@ -83,7 +91,7 @@ class ShardedGramian:
         dist.all_gather_into_tensor(target, shard, group=self.group)       # the ONLY collective of the MVM
         if target is out:
             return out
-        b = full[: self.n]
+        b = full[: self.n * self.block]
         if out is not None:
             out.copy_(b)
             return out

@@ -39,11 +39,36 @@ def _worker(rank, world, port, n, m, d, nrhs, q):
     dist.destroy_process_group()
 
 
-def _run(n, m, d, nrhs, world=2):
+def _grad_worker(rank, world, port, n, m, d, nrhs, q):
+    """Row-sharded GradientKernel Gramian: flat point-major block vectors, rank g owns the blocks of its rows."""
+    sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import covgram as cg
+    import covgram_oracle as o
+    rng = np.random.default_rng(321)
+    X = torch.from_numpy(rng.standard_normal((n, d))); Y = torch.from_numpy(rng.standard_normal((m, d)))
+    a = torch.from_numpy(rng.standard_normal(m * d))
+    ko = o.Kernel(o.EQ)
+
+    def factory(k, x_rows, y_full):
+        return lambda vec: torch.from_numpy(o.grad_mul(None, ko, x_rows.numpy(), y_full.numpy(), vec.numpy()))
+
+    G = cg.ShardedGramian(cg.GradientKernel(cg.EQ()), X, Y, local_factory=factory)
+    b = G @ a
+    ref = o.grad_mul(None, ko, X.numpy(), Y.numpy(), a.numpy())
+    err = float(np.linalg.norm(b.numpy() - ref) / np.linalg.norm(ref))
+    q.put((rank, G.lo, G.hi, tuple(b.shape), err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n, m, d, nrhs, world=2, worker=None):
+    worker = worker or _worker
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, d, nrhs, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n, m, d, nrhs, q)) for r in range(world)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
@@ -64,3 +89,10 @@ def test_row_sharded_mvm_world2_matrix_and_ragged():
     assert [r[1:3] for r in res] == [(0, 2), (2, 3)]
     for r in res:
         assert r[3] == (3, 3) and r[4] < 1e-14
+
+
+def test_row_sharded_gradient_gramian_world2():
+    res = _run(n=11, m=7, d=3, nrhs=1, worker=_grad_worker)      # ragged: shards of 6 and 5 points = 18 and 15 entries
+    assert [r[1:3] for r in res] == [(0, 6), (6, 11)]
+    for r in res:
+        assert r[3] == (33,) and r[4] < 1e-13

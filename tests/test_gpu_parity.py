@@ -774,3 +774,18 @@ def test_transformed_kernels(cg, oracle):
     # Polynomial(d, sigma) = (Dot() + sigma)^d as one composite
     Pk = cg.gramian(cg.Polynomial(4, 0.5), Xd, Yd)
     assert relerr((Pk @ ad).cpu().numpy(), ((X @ Y.T + 0.5) ** 4) @ a) <= 1e-12
+
+
+def test_sharded_gramian_single_rank_dense_and_gradient(cg, oracle):
+    """ShardedGramian without a process group (world = 1): same numbers as the local operators; block Gramians included."""
+    rng = np.random.default_rng(41)
+    X = rng.standard_normal((90, 4)); a = rng.standard_normal(90); ag = rng.standard_normal(90 * 4); av = rng.standard_normal(90 * 5)
+    Xd = torch.from_numpy(X).cuda()
+    S = cg.ShardedGramian(cg.MaternP(2), Xd)
+    assert relerr((S @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.MATERNP, p=2), X, X, a)) <= 1e-12
+    Sg = cg.ShardedGramian(cg.GradientKernel(cg.EQ()), Xd)
+    assert Sg.block == 4 and Sg.shape == (360, 360)
+    assert relerr((Sg @ torch.from_numpy(ag).cuda()).cpu().numpy(), oracle.grad_mul(None, oracle.Kernel(oracle.EQ), X, X, ag)) <= 1e-12
+    Sv = cg.ShardedGramian(cg.ValueGradientKernel(cg.EQ()), Xd)
+    assert Sv.block == 5
+    assert relerr((Sv @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.valgrad_mul(None, oracle.Kernel(oracle.EQ), X, X, av)) <= 1e-12
