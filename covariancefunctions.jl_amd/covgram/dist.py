@@ -98,3 +98,19 @@ class ShardedGramian:
         return b.clone()
 
     __matmul__ = matmul
+
+    def mul_(self, y: torch.Tensor, a: torch.Tensor, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+        """mul!(y, G, a, α, β) with b complete on every rank: lets the Krylov callers (covgram.cg) run unchanged on a
+        row-sharded Gramian — vectors are replicated, so their dot products need no further collective."""
+        if alpha == 1.0 and beta == 0.0:
+            return self.matmul(a, out=y)
+        t = self.matmul(a)
+        return y.copy_(alpha * t) if beta == 0 else y.mul_(beta).add_(t, alpha=alpha)
+
+    @property
+    def dtype(self):
+        return self.local.dtype if hasattr(self.local, "dtype") else torch.float64
+
+    @property
+    def device(self):
+        return self.local.device if hasattr(self.local, "device") else torch.device("cpu")

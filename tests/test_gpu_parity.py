@@ -789,3 +789,15 @@ def test_sharded_gramian_single_rank_dense_and_gradient(cg, oracle):
     Sv = cg.ShardedGramian(cg.ValueGradientKernel(cg.EQ()), Xd)
     assert Sv.block == 5
     assert relerr((Sv @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.valgrad_mul(None, oracle.Kernel(oracle.EQ), X, X, av)) <= 1e-12
+
+
+def test_cg_on_sharded_gramian(cg, oracle):
+    """(G + σ²I) \\ b by CG with the row-sharded operator as the MVM (world = 1 here; the only collective of an iteration is
+    the all-gather inside the MVM)."""
+    rng = np.random.default_rng(43)
+    X = rng.standard_normal((300, 2)); b = rng.standard_normal(300)
+    S = cg.ShardedGramian(cg.MaternP(1), torch.from_numpy(X).cuda())
+    A = cg.LazyMatrixSum(S, 0.1 * torch.ones(300, dtype=torch.float64, device="cuda"))
+    x, info = cg.cg(A, torch.from_numpy(b).cuda(), reltol=1e-10)
+    M = oracle.matrix(oracle.Kernel(oracle.MATERNP, p=1), X) + 0.1 * np.eye(300)
+    assert info["converged"] and relerr(x.cpu().numpy(), np.linalg.solve(M, b)) <= 1e-8
