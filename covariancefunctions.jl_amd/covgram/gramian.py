@@ -619,7 +619,7 @@ class LazyMatrixSum(LazyOperator):
         self.args = []
         for a in args:
             self.args.extend(a.args if isinstance(a, LazyMatrixSum) else [a])
-        lazy = [a for a in self.args if hasattr(a, "mul_")][0]
+        lazy = [a for a in self.args if (hasattr(a, "mul_") and not torch.is_tensor(a))][0]
         self.shape, self.dtype, self.device = lazy.shape, lazy.dtype, lazy.device
 
     def mul_(self, y, a, alpha=1.0, beta=0.0):
@@ -627,7 +627,7 @@ class LazyMatrixSum(LazyOperator):
         first = True
         for A in self.args:
             b = beta if first else 1.0
-            if hasattr(A, "mul_"):
+            if (hasattr(A, "mul_") and not torch.is_tensor(A)):
                 A.mul_(y, a, alpha, b)
             else:   # Diagonal given as a 1-D tensor, or a dense matrix
                 A = torch.as_tensor(A, dtype=self.dtype, device=self.device)
