@@ -568,6 +568,11 @@ def _simple_spec(k) -> Optional[_ffi.covgram_kernel]:
     fam = _BASE.get(type(k))
     if fam is None:
         return None
+    if fam == _ffi.MATERN and float(k.nu - 0.5).is_integer() and 0 <= int(k.nu - 0.5) <= _ffi.MATERNP_MAX_P:
+        # half-integer ν: the same function has the closed form of MaternP(ν − 1/2) (the reference's own "IDEA: use rational types
+        # to dispatch to MaternP evaluation", src/stationary.jl:85) — ~50x cheaper per pair than the Bessel-function path
+        k = MaternP(int(k.nu - 0.5))
+        fam = _ffi.MATERNP
     spec = _ffi.covgram_kernel()
     spec.family = fam
     spec.trait = _ffi.DOTPRODUCT if fam in (_ffi.DOT, _ffi.EXPDOT) else _ffi.ISOTROPIC

@@ -120,6 +120,8 @@ def test_kernel_lowering_and_folding(cg):
     assert s.lengthscale == 6.0
     s = cg.device_spec(2.0 * cg.Lengthscale(cg.Matern(2.7), 0.4))
     assert (s.family, s.trait, s.param, s.lengthscale, s.scale) == (cg._ffi.MATERN, cg._ffi.ISOTROPIC, 2.7, 0.4, 2.0)
+    s = cg.device_spec(cg.Matern(2.5))                                 # half-integer ν -> the closed form
+    assert (s.family, s.p) == (cg._ffi.MATERNP, 2) and cg.device_spec(cg.Matern(2.51)).family == cg._ffi.MATERN
     assert cg.device_spec(cg.FiniteBasis([lambda t: t])) is None
     assert cg.device_spec(cg.RQ(0.3)).param == 0.3 and cg.device_spec(cg.InverseMultiQuadratic(1.5)).param == 1.5
     with pytest.raises(cg.DomainError):
