@@ -111,6 +111,15 @@ def main():
          roofline={"bound": "hbm", "achieved_GBps": bytes_alg / (med * 1e-3) * 1e-9, "peak_GBps": HBM_PEAK * 1e-9,
                    "frac": bytes_alg / (med * 1e-3) / HBM_PEAK, "algorithmic_bytes": bytes_alg})
     del T, a, y
+    # C5, fp32 variant (BASELINE.json configs[4]: "also f32 variant")
+    T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n5, torch.float32))
+    a32 = torch.from_numpy(ah.astype(np.float32)).cuda(); y32 = torch.empty_like(a32)
+    med, mn = timeit(lambda: T.mul_(y32, a32))
+    emit(config="C5-f32", what="the same Toeplitz MVM in fp32", ms_median=med, ms_min=mn, mvm_per_s=1e3 / med,
+         rel_err_vs_numpy_fft=rel(y32.cpu().numpy(), ref),
+         roofline={"bound": "hbm", "achieved_GBps": 0.5 * bytes_alg / (med * 1e-3) * 1e-9, "peak_GBps": HBM_PEAK * 1e-9,
+                   "frac": 0.5 * bytes_alg / (med * 1e-3) / HBM_PEAK, "algorithmic_bytes": 0.5 * bytes_alg})
+    del T, a32, y32
     # Kronecker: the README case (README.md:205-210): Exp^{(x)3} on a 128^3 grid, dense 128x128 factors, fp64
     ax = torch.linspace(0, 1, 128, dtype=torch.float64, device="cuda")
     Gk = cg.gramian(cg.separable("*", cg.Exp(), cg.Exp(), cg.Exp()), cg.LazyGrid(ax, 3))
