@@ -828,8 +828,8 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
                                (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
-        // (C4: 2.47 ms at CUs*8, 2.09 ms at CUs*32, profiles/r01_gradbench_sweep_v2.txt)
-        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 32);
+        // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
+        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 64);
         GradArgs ga;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
