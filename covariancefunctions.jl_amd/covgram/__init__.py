@@ -14,13 +14,13 @@ from ._ffi import CovgramError, DimensionMismatch, UnsupportedKernel, NoDevice
 from .kernels import (AbstractKernel, MercerKernel, StationaryKernel, IsotropicKernel, MultiKernel, Constant,
                       ExponentiatedQuadratic, EQ, RationalQuadratic, RQ, Exponential, Exp, GammaExponential, GammaExp,
                       Cauchy, InverseMultiQuadratic, MaternP, Matern, Dot, ExponentialDot, FiniteBasis, Product, Sum, Power,
-                      Lengthscale, ARD, ScaledInputKernel, Warped, Periodic, VerticalRescaling, CosineKernel, Cosine, Cos, Line, Polynomial, Poly,
+                      Lengthscale, ARD, ScaledInputKernel, Warped, Periodic, VerticalRescaling, CosineKernel, Cosine, Cos, Line, Polynomial, Poly, NeuralNetwork, NN, AsinDot,
                       SeparableProduct, separable, SeparableKernel, Separable, GradientKernel, ValueGradientKernel, InputTrait,
                       GenericInput, IsotropicInput, DotProductInput, StationaryInput, StationaryLinearFunctionalInput,
                       PeriodicInput, input_trait, register_input_trait, ismercer, isstationary, isisotropic, isdot,
                       device_spec, DomainError)
 from .gramian import (Gramian, BlockGramian, SymmetricToeplitz, Toeplitz, Circulant, KroneckerProduct, kronecker,
-                      SeparableGramian, LazyMatrixProduct, LazyMatrixSum, ScaledOperator, LinearMapBlockGramian, CosineBlockGramian, Fill, LazyOperator, LazyGrid, StepRangeLen,
+                      SeparableGramian, LazyMatrixProduct, LazyMatrixSum, ScaledOperator, LinearMapBlockGramian, CosineBlockGramian, PointJacobianBlockGramian, Fill, LazyOperator, LazyGrid, StepRangeLen,
                       srange, gramian, mul_, get_ctx, set_option, get_info, kernel_time)
 from .dist import ShardedGramian, shard_bounds
 from .solve import cg, solve, toeplitz_solve

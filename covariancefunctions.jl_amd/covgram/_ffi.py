@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
 
 # enums (include/covgram.h)
-EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN = range(10)
+EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN, ASINDOT = range(11)
 CONSTANT, COMPOSITE = 100, 101
 COMPOSITE_MAX_TERMS, COMPOSITE_MAX_FACTORS = 8, 8
 ISOTROPIC, DOTPRODUCT = 1, 2

@@ -554,6 +554,15 @@ class LazyMatrixProduct(LazyOperator):
         return self.U @ self.V.t()
 
 
+def _by_columns(op, y, a, alpha, beta):
+    """Matrix right-hand side for operators whose mul_ is written for vectors: one column at a time."""
+    for c in range(a.shape[1]):
+        yc = y[:, c].contiguous()
+        op.mul_(yc, a[:, c].contiguous(), alpha, beta)
+        y[:, c] = yc
+    return y
+
+
 class ScaledOperator(LazyOperator):
     """Diagonal(dx) · K · Diagonal(dy), lazy — gramian(::VerticalRescaling) (src/transformation.jl:165-171 builds exactly this
     LazyMatrixProduct(Dx, K, Dy)).  The two diagonal scalings are O(n) vector ops around K's own MVM."""
@@ -584,6 +593,8 @@ class LinearMapBlockGramian(LazyOperator):
         self.dtype, self.device = inner.dtype, inner.device
 
     def mul_(self, y, a, alpha=1.0, beta=0.0):
+        if torch.is_tensor(a) and a.dim() == 2:
+            return _by_columns(self, y, a, alpha, beta)
         n, m = self.inner.inner.shape
         A = _vec_arg(a, self.shape[1], self.dtype, self.device, "a").reshape(m, self.d)
         UA = (A * self.U if self.U.dim() == 1 else A @ self.U.t()).contiguous()
@@ -604,11 +615,39 @@ class CosineBlockGramian(LazyOperator):
         self.dtype, self.device = scalar.dtype, scalar.device
 
     def mul_(self, y, a, alpha=1.0, beta=0.0):
+        if torch.is_tensor(a) and a.dim() == 2:
+            return _by_columns(self, y, a, alpha, beta)
         n, m = self.scalar.shape
         A = _vec_arg(a, self.shape[1], self.dtype, self.device, "a").reshape(m, self.d)
         t = self.scalar @ (A @ self.c).contiguous()
         b = ((4 * math.pi ** 2) * t[:, None] * self.c[None, :]).reshape(-1)
         return y.copy_(alpha * b) if beta == 0 else y.mul_(beta).add_(b, alpha=alpha)
+
+
+class PointJacobianBlockGramian(LazyOperator):
+    """Gradient Gramian of k(u(x), u(y)) for a pointwise warp u: block (i, j) = J_iᵀ B̂_ij J_j.  Here u is the NeuralNetwork
+    normalisation x ↦ x̂ = [x, √σ] / ρ, ρ = sqrt(1 + |x|² + σ):  J a = [a; 0]/ρ − x̂ (x·a)/ρ²,  Jᵀ v = v[:d]/ρ − x (x̂·v)/ρ²."""
+
+    def __init__(self, x: torch.Tensor, y: torch.Tensor, xh: torch.Tensor, yh: torch.Tensor, rx: torch.Tensor, ry: torch.Tensor,
+                 inner: "BlockGramian"):
+        self.x, self.y, self.xh, self.yh, self.rx, self.ry, self.inner = x, y, xh, yh, rx, ry, inner
+        n, m, d = x.shape[0], y.shape[0], x.shape[1]
+        self.d = d
+        self.shape = (n * d, m * d)
+        self.dtype, self.device = inner.dtype, inner.device
+
+    def mul_(self, yv, a, alpha=1.0, beta=0.0):
+        if torch.is_tensor(a) and a.dim() == 2:
+            return _by_columns(self, yv, a, alpha, beta)
+        n, m, d = self.x.shape[0], self.y.shape[0], self.d
+        A = _vec_arg(a, self.shape[1], self.dtype, self.device, "a").reshape(m, d)
+        ya = (self.y * A).sum(dim=1)
+        JA = torch.cat([A, torch.zeros(m, 1, dtype=self.dtype, device=self.device)], dim=1) / self.ry[:, None] \
+            - self.yh * (ya / self.ry ** 2)[:, None]
+        V = (self.inner @ JA.reshape(-1).contiguous()).reshape(n, d + 1)
+        xv = (self.xh * V).sum(dim=1)
+        b = (V[:, :d] / self.rx[:, None] - self.x * (xv / self.rx ** 2)[:, None]).reshape(-1)
+        return yv.copy_(alpha * b) if beta == 0 else yv.mul_(beta).add_(b, alpha=alpha)
 
 
 class LazyMatrixSum(LazyOperator):
@@ -740,6 +779,19 @@ def gramian(k, x=None, y=None, trait: Optional[K.InputTrait] = None):
         py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
         tx = _transform_points(k, px)
         return gramian(k.k, tx, None if same else _transform_points(k, py))
+    if isinstance(k, K.NeuralNetwork) or (isinstance(k, K.GradientKernel) and isinstance(k.k, K.NeuralNetwork)):
+        nn = k if isinstance(k, K.NeuralNetwork) else k.k          # src/mercer.jl:82-85 on normalised augmented inputs
+        px = _as_points(x)
+        py = px if same else _as_points(y, device=px.device, dtype=px.dtype)
+        def warp(p):
+            rho = torch.sqrt(1 + (p * p).sum(dim=1) + nn.sigma)
+            z = torch.cat([p, torch.full((p.shape[0], 1), math.sqrt(nn.sigma), dtype=p.dtype, device=p.device)], dim=1)
+            return (z / rho[:, None]).contiguous(), rho
+        xh, rx = warp(px)
+        yh, ry = (xh, rx) if same else warp(py)
+        if isinstance(k, K.NeuralNetwork):
+            return Gramian(K.AsinDot(), xh, None if same else yh)
+        return PointJacobianBlockGramian(px, py, xh, yh, rx, ry, BlockGramian(K.GradientKernel(K.AsinDot()), xh, None if same else yh))
     if isinstance(k, K.CosineKernel):                           # rank 2: cos(u_i − v_j) = cos u_i cos v_j + sin u_i sin v_j
         px = _as_points(x)
         py = px if same else _as_points(y, device=px.device, dtype=px.dtype)

@@ -358,6 +358,33 @@ class VerticalRescaling(AbstractKernel):
         return fx * self.k(x, y) * fy
 
 
+class AsinDot(DotProductKernel):
+    """φ(s) = (2/π) asin(s): what the NeuralNetwork kernel is on its normalised augmented inputs (device family ASINDOT)."""
+
+    def profile(self, s):
+        return 2 / math.pi * math.asin(s)
+
+
+class NeuralNetwork(MercerKernel):
+    """NN(σ)(x, y) = 2/π asin(l(x,y) / sqrt((1 + l(x,x)) (1 + l(y,y)))), l = Line(σ) = x·y + σ (src/mercer.jl:73-85).
+    With x̂ = [x, √σ] / sqrt(1 + |x|² + σ) this is AsinDot on (x̂, ŷ): `gramian` warps the points once and the dot-product
+    hot path does the rest; the gradient Gramian follows by the chain rule through the warp (per-point Jacobians, O(d) each),
+    which for σ = 0 is exactly the reference's Woodbury block (src/gradient.jl:187-210)."""
+
+    def __init__(self, sigma: float = 0.0):
+        if sigma < 0:
+            raise DomainError(f"σ = {sigma} is negative")
+        self.sigma = float(sigma)
+
+    def __call__(self, x, y):
+        x = np.atleast_1d(np.asarray(x, dtype=np.float64)); y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+        l = lambda u, v: float(np.dot(u, v)) + self.sigma
+        return 2 / math.pi * math.asin(l(x, y) / math.sqrt((1 + l(x, x)) * (1 + l(y, y))))
+
+
+NN = NeuralNetwork
+
+
 class FiniteBasis(MercerKernel):
     """src/mercer.jl:41-70: k(x,y) = Σ_b b(x) b(y); basis functions are vectorised callables."""
 
@@ -512,7 +539,7 @@ def input_trait(k) -> InputTrait:
             return tr
     if isinstance(k, (Product, Sum, Power, GradientKernel, ValueGradientKernel)):
         return k.input_trait
-    if isinstance(k, (Dot, ExponentialDot)):
+    if isinstance(k, (Dot, ExponentialDot, AsinDot)):
         return DotProductInput()
     if isinstance(k, CosineKernel):
         return StationaryLinearFunctionalInput()             # src/stationary.jl:206
@@ -535,7 +562,7 @@ def isdot(k): return isinstance(k, (Dot, ExponentialDot)) or (isinstance(k, (Pro
 _BASE = {
     ExponentiatedQuadratic: _ffi.EQ, Exponential: _ffi.EXP, RationalQuadratic: _ffi.RQ, GammaExponential: _ffi.GAMMAEXP,
     Cauchy: _ffi.CAUCHY, InverseMultiQuadratic: _ffi.IMQ, MaternP: _ffi.MATERNP, Dot: _ffi.DOT, ExponentialDot: _ffi.EXPDOT,
-    Matern: _ffi.MATERN,
+    Matern: _ffi.MATERN, AsinDot: _ffi.ASINDOT,
 }
 
 
@@ -575,7 +602,7 @@ def _simple_spec(k) -> Optional[_ffi.covgram_kernel]:
         fam = _ffi.MATERNP
     spec = _ffi.covgram_kernel()
     spec.family = fam
-    spec.trait = _ffi.DOTPRODUCT if fam in (_ffi.DOT, _ffi.EXPDOT) else _ffi.ISOTROPIC
+    spec.trait = _ffi.DOTPRODUCT if fam in (_ffi.DOT, _ffi.EXPDOT, _ffi.ASINDOT) else _ffi.ISOTROPIC
     spec.p = getattr(k, "p", 0) if fam == _ffi.MATERNP else 0
     spec.power = power
     spec.param = {_ffi.RQ: getattr(k, "alpha", 0.0), _ffi.GAMMAEXP: getattr(k, "gamma", 0.0), _ffi.IMQ: getattr(k, "c", 0.0),

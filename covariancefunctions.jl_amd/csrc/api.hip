@@ -44,28 +44,28 @@ int pad_dim(int d) {
     int launch_dense_wide_family_##n(const DenseArgs&, int dtype); \
     int launch_grad_family_##n(const GradArgs&, int dtype);        \
     int launch_grad_wide_family_##n(const GradWideArgs&, int dtype);
-CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(9) CG_DECL(10) CG_DECL(11)
+CG_DECL(0) CG_DECL(1) CG_DECL(2) CG_DECL(3) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(9) CG_DECL(10) CG_DECL(11) CG_DECL(12)
 #undef CG_DECL
 
 dense_launch_fn dense_launcher(int family) {
     static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_family_0, launch_dense_family_1, launch_dense_family_2, launch_dense_family_3, launch_dense_family_4,
         launch_dense_family_5, launch_dense_family_6, launch_dense_family_7, launch_dense_family_8, launch_dense_family_9,
-        launch_dense_family_10, launch_dense_family_11};
+        launch_dense_family_10, launch_dense_family_11, launch_dense_family_12};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 dense_launch_fn dense_wide_launcher(int family) {
     static const dense_launch_fn t[NUM_TU_FAMILIES] = {
         launch_dense_wide_family_0, launch_dense_wide_family_1, launch_dense_wide_family_2, launch_dense_wide_family_3,
         launch_dense_wide_family_4, launch_dense_wide_family_5, launch_dense_wide_family_6, launch_dense_wide_family_7,
-        launch_dense_wide_family_8, launch_dense_wide_family_9, launch_dense_wide_family_10, launch_dense_wide_family_11};
+        launch_dense_wide_family_8, launch_dense_wide_family_9, launch_dense_wide_family_10, launch_dense_wide_family_11, launch_dense_wide_family_12};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 grad_launch_fn grad_launcher(int family) {
     static const grad_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_family_0, launch_grad_family_1, launch_grad_family_2, launch_grad_family_3, launch_grad_family_4,
         launch_grad_family_5, launch_grad_family_6, launch_grad_family_7, launch_grad_family_8, launch_grad_family_9,
-        launch_grad_family_10, launch_grad_family_11};
+        launch_grad_family_10, launch_grad_family_11, launch_grad_family_12};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 
@@ -153,7 +153,7 @@ int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, Host
 
 static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out) {
     CG_REQUIRE(k->family >= 0 && k->family < COVGRAM_NFAMILY, COVGRAM_EUNSUPPORTED, "unknown kernel family %d", k->family);
-    const bool dotfam = (k->family == COVGRAM_DOT || k->family == COVGRAM_EXPDOT);
+    const bool dotfam = (k->family == COVGRAM_DOT || k->family == COVGRAM_EXPDOT || k->family == COVGRAM_ASINDOT);
     const int trait = dotfam ? COVGRAM_DOTPRODUCT : COVGRAM_ISOTROPIC;
     CG_REQUIRE(k->trait == trait, COVGRAM_EINVAL, "kernel trait %d does not match family %d (input_trait would be %d)",
                k->trait, k->family, trait);
@@ -289,7 +289,7 @@ grad_wide_launch_fn grad_wide_launcher(int family) {
     static const grad_wide_launch_fn t[NUM_TU_FAMILIES] = {
         launch_grad_wide_family_0, launch_grad_wide_family_1, launch_grad_wide_family_2, launch_grad_wide_family_3,
         launch_grad_wide_family_4, launch_grad_wide_family_5, launch_grad_wide_family_6, launch_grad_wide_family_7,
-        launch_grad_wide_family_8, launch_grad_wide_family_9, launch_grad_wide_family_10, launch_grad_wide_family_11};
+        launch_grad_wide_family_8, launch_grad_wide_family_9, launch_grad_wide_family_10, launch_grad_wide_family_11, launch_grad_wide_family_12};
     return (family >= 0 && family < NUM_TU_FAMILIES) ? t[family] : nullptr;
 }
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const T* __restrict__ X, in
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t jb = (int64_t)blockIdx.y * 16;
     if (i >= n) return;
-    const bool iso = (family != COVGRAM_DOT && family != COVGRAM_EXPDOT);
+    const bool iso = (family != COVGRAM_DOT && family != COVGRAM_EXPDOT && family != COVGRAM_ASINDOT);
     const T* xi = X + i * (int64_t)d;
     for (int64_t j = jb; j < jb + 16 && j < m; ++j) {
         const T* yj = Y + j * (int64_t)d;

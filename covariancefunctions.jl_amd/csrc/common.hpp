@@ -84,7 +84,7 @@ template <int FAM, typename T> struct ParamsOf { using type = KParams<T>; };
 template <typename T> struct ParamsOf<FAM_EXPR_ISO, T> { using type = ExprParams<T>; };
 template <typename T> struct ParamsOf<FAM_EXPR_DOT, T> { using type = ExprParams<T>; };
 template <int FAM> constexpr bool fam_is_expr = (FAM == FAM_EXPR_ISO || FAM == FAM_EXPR_DOT);
-template <int FAM> constexpr bool fam_is_iso = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT && FAM != FAM_EXPR_DOT);
+template <int FAM> constexpr bool fam_is_iso = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT && FAM != COVGRAM_ASINDOT && FAM != FAM_EXPR_DOT);
 
 struct HostKernel {
     covgram_kernel k;     // simple kernel, or the head of a composite

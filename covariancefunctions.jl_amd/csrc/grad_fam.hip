@@ -4,7 +4,7 @@
 #include "grad_wide.hpp"
 
 #ifndef COVGRAM_FAM
-#error "compile with -DCOVGRAM_FAM=<0..11>"
+#error "compile with -DCOVGRAM_FAM=<0..12>"
 #endif
 
 namespace covgram {

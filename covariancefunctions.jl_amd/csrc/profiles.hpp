@@ -212,6 +212,11 @@ template <typename T, bool F>
 struct Phi<COVGRAM_EXPDOT, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(s); }
 };
+// NeuralNetwork kernel on normalised augmented inputs (src/mercer.jl:82-85): (2/pi) asin(x^.y^)
+template <typename T, bool F>
+struct Phi<COVGRAM_ASINDOT, T, F> {
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return (T)0.63661977236758134308 * asin(s); }
+};
 
 // ---- runtime-family evaluation (dense instantiation, composite factors): a wave-uniform switch ------------------
 template <typename T>
@@ -228,6 +233,7 @@ __device__ __forceinline__ T phi_any(int family, T s, const KParams<T>& kp) {
         case COVGRAM_DOT: v = s; break;
         case COVGRAM_EXPDOT: v = Phi<COVGRAM_EXPDOT, T, false>::eval(s, kp); break;
         case COVGRAM_MATERN: v = Phi<COVGRAM_MATERN, T, false>::eval(s, kp); break;
+        case COVGRAM_ASINDOT: v = Phi<COVGRAM_ASINDOT, T, false>::eval(s, kp); break;
         default: v = (T)1; break;                         // COVGRAM_CONSTANT: the factor is its scale
     }
     if (kp.power != 1) v = ipow(v, kp.power);
@@ -288,6 +294,7 @@ __device__ __forceinline__ void expr_accumulate_block(const typename Pk<T>::V (&
                 CG_EXPR_CASE(COVGRAM_IMQ)
                 CG_EXPR_CASE(COVGRAM_MATERNP)
                 CG_EXPR_CASE(COVGRAM_MATERN)
+                CG_EXPR_CASE(COVGRAM_ASINDOT)
                 CG_EXPR_CASE(COVGRAM_EXPDOT)
                 default:                                           // COVGRAM_DOT
                     CG_EXPR_CASE(COVGRAM_DOT)
@@ -435,6 +442,14 @@ struct DPhi<COVGRAM_DOT, T> {
     }
 };
 template <typename T>
+struct DPhi<COVGRAM_ASINDOT, T> {   // f1, f2 of src/gradient.jl:192-194
+    static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
+        const T c = (T)0.63661977236758134308;
+        const T q = cg_rsqrt((T)1 - s * s);
+        v = c * asin(s); d1 = c * q; d2 = c * s * q * q * q;
+    }
+};
+template <typename T>
 struct DPhi<COVGRAM_EXPDOT, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
         v = cg_exp(s); d1 = v; d2 = v;
@@ -466,6 +481,7 @@ __device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T
         case COVGRAM_DOT: DPhi<COVGRAM_DOT, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_EXPDOT: DPhi<COVGRAM_EXPDOT, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_MATERN: DPhi<COVGRAM_MATERN, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_ASINDOT: DPhi<COVGRAM_ASINDOT, T>::eval(s, kp, v, d1, d2); break;
         default: v = (T)1; d1 = (T)0; d2 = (T)0; break;   // COVGRAM_CONSTANT
     }
     if (kp.power != 1) power_jet(kp.power, v, d1, d2);
@@ -532,6 +548,7 @@ __device__ __forceinline__ void expr_jet_block(const typename Pk<T>::V (&s)[BG],
                 CG_JET_CASE(COVGRAM_IMQ)
                 CG_JET_CASE(COVGRAM_MATERNP)
                 CG_JET_CASE(COVGRAM_MATERN)
+                CG_JET_CASE(COVGRAM_ASINDOT)
                 CG_JET_CASE(COVGRAM_EXPDOT)
                 default:
                     CG_JET_CASE(COVGRAM_DOT)

@@ -68,7 +68,9 @@ typedef enum covgram_family {
     COVGRAM_EXPDOT = 8,   /* exp(s)                            src/mercer.jl:19-22       */
     COVGRAM_MATERN = 9,   /* Matern, real nu > 0: 2^(1-nu)/Gamma(nu) r^nu K_nu(r), r = sqrt(2 nu s); Taylor guard near 0
                              (param = nu)                                        src/stationary.jl:87-114  */
-    COVGRAM_NFAMILY = 10,
+    COVGRAM_ASINDOT = 10, /* (2/pi) asin(s): the NeuralNetwork kernel on its normalised augmented inputs x^ = [x, sqrt(sigma)] /
+                             sqrt(1 + |x|^2 + sigma), for which x^.y^ is the argument of asin   src/mercer.jl:73-85 */
+    COVGRAM_NFAMILY = 11,
     /* only inside / as the head of a covgram_kernel_composite: */
     COVGRAM_CONSTANT = 100, /* factor: the constant `scale`            src/stationary.jl:27-34   */
     COVGRAM_COMPOSITE = 101 /* head of a covgram_kernel_composite      src/algebra.jl:5-63       */

@@ -26,8 +26,8 @@ import numpy as np
 # ----------------------------------------------------------------------------------------
 # kernel description (mirrors include/covgram.h :: covgram_kernel)
 # ----------------------------------------------------------------------------------------
-EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN = range(10)
-FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT", "MATERN"]
+EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN, ASINDOT = range(11)
+FAMILY_NAMES = ["EQ", "EXP", "RQ", "GAMMAEXP", "CAUCHY", "IMQ", "MATERNP", "DOT", "EXPDOT", "MATERN", "ASINDOT"]
 ISOTROPIC, DOTPRODUCT = 1, 2
 CONSTANT = 100   # a factor of a Composite that is just its `scale` (stationary.jl:27-34)
 
@@ -46,7 +46,7 @@ class Kernel:
     def trait(self) -> int:
         # properties.jl:39-43: IsotropicKernel -> IsotropicInput, Dot/ExponentialDot -> DotProductInput,
         # Power inherits the trait of its base kernel.
-        return DOTPRODUCT if self.family in (DOT, EXPDOT) else ISOTROPIC
+        return DOTPRODUCT if self.family in (DOT, EXPDOT, ASINDOT) else ISOTROPIC
 
 
 @dataclass(frozen=True)
@@ -197,6 +197,8 @@ def profile(k, s, dtype=np.float64):
         v = s                                        # mercer.jl:9
     elif f == EXPDOT:
         v = np.exp(s)                                # mercer.jl:22
+    elif f == ASINDOT:
+        v = 2 / np.pi * np.arcsin(s)                 # mercer.jl:84 on normalised inputs
     else:
         raise ValueError(f"unknown family {f}")
     if k.power != 1:
@@ -298,6 +300,8 @@ def profile_derivatives(k: Kernel, s, dtype=np.float64):
             v = s; d1 = np.ones_like(s); d2 = np.zeros_like(s)
         elif f == EXPDOT:
             v = np.exp(s); d1 = v; d2 = v
+        elif f == ASINDOT:                               # f0, f1, f2 of gradient.jl:192-194
+            v = 2 / np.pi * np.arcsin(s); d1 = 2 / np.pi / np.sqrt(1 - s * s); d2 = 2 / np.pi * s / np.sqrt(1 - s * s) ** 3
         else:
             raise ValueError(f"unknown family {f}")
         d1 = d1 * inner
@@ -728,4 +732,39 @@ def linear_map_grad_matrix(k: Kernel, U, X, Y=None, dtype=np.float64):
     for i in range(n):
         for j in range(m):
             M[i * d:(i + 1) * d, j * d:(j + 1) * d] = Um.T @ inner[i * dp:(i + 1) * dp, j * dp:(j + 1) * dp] @ Um
+    return M
+
+
+# ----------------------------------------------------------------------------------------
+# NeuralNetwork kernel (src/mercer.jl:73-85) and its gradient block (src/gradient.jl:187-210), restated literally
+# ----------------------------------------------------------------------------------------
+def nn_matrix(sigma, X, Y=None):
+    """k(x, y) = 2/π asin(l(x,y) / sqrt((1 + l(x,x)) (1 + l(y,y)))), l(x, y) = x·y + σ."""
+    X = as_points(X).astype(np.float64); Y = X if Y is None else as_points(Y).astype(np.float64)
+    lxy = X @ Y.T + sigma
+    lxx = (X * X).sum(1) + sigma; lyy = (Y * Y).sum(1) + sigma
+    return 2 / np.pi * np.arcsin(lxy / np.sqrt((1 + lxx)[:, None] * (1 + lyy)[None, :]))
+
+
+def nn_grad_block(x, y):
+    """∂x ∂y' of the NN kernel with σ = 0 as the reference assembles it: k1 I + [x y] C [x y]' (gradient.jl:187-210)."""
+    x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    Nx, Ny = x @ x + 1, y @ y + 1
+    dxy, Nxy = x @ y, Nx * Ny
+    dd = dxy / np.sqrt(Nxy)
+    k1 = 2 / np.pi / np.sqrt(1 - dd * dd) / np.sqrt(Nxy)
+    k2 = 2 / np.pi / np.sqrt(1 - dd * dd) ** 3 * dd / Nxy
+    k12 = k1 + k2 * dxy
+    C = np.array([[-k12 / Nx, k12 * dxy / Nxy], [k2, -k12 / Ny]])
+    U = np.stack([x, y], axis=1)
+    return k1 * np.eye(x.shape[0]) + U @ C @ U.T
+
+
+def nn_grad_matrix(X, Y=None):
+    X = as_points(X).astype(np.float64); Y = X if Y is None else as_points(Y).astype(np.float64)
+    n, d = X.shape; m = Y.shape[0]
+    M = np.zeros((n * d, m * d))
+    for i in range(n):
+        for j in range(m):
+            M[i * d:(i + 1) * d, j * d:(j + 1) * d] = nn_grad_block(X[i], Y[j])
     return M

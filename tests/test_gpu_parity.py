@@ -801,3 +801,27 @@ def test_cg_on_sharded_gramian(cg, oracle):
     x, info = cg.cg(A, torch.from_numpy(b).cuda(), reltol=1e-10)
     M = oracle.matrix(oracle.Kernel(oracle.MATERNP, p=1), X) + 0.1 * np.eye(300)
     assert info["converged"] and relerr(x.cpu().numpy(), np.linalg.solve(M, b)) <= 1e-8
+
+
+def test_neural_network_kernel(cg, oracle):
+    """NN(σ) (src/mercer.jl:73-85): AsinDot on normalised augmented points; gradient Gramian by the chain rule through the
+    normalisation == the reference's Woodbury block for σ = 0 (src/gradient.jl:187-210); test/gradient.jl:21 lists NN()."""
+    rng = np.random.default_rng(23)
+    n, m, d = 60, 41, 4
+    X = rng.standard_normal((n, d)); Y = rng.standard_normal((m, d)); a = rng.standard_normal(m); ag = rng.standard_normal(m * d)
+    Xd, Yd, ad, agd = (torch.from_numpy(v).cuda() for v in (X, Y, a, ag))
+    for sigma in (0.0, 0.7):
+        G = cg.gramian(cg.NN(sigma), Xd, Yd)
+        M = oracle.nn_matrix(sigma, X, Y)
+        assert relerr((G @ ad).cpu().numpy(), M @ a) <= 1e-12 and relerr(G.to_dense().cpu().numpy(), M) <= 1e-12
+        assert abs(cg.NN(sigma)(X[0], Y[0]) - M[0, 0]) <= 1e-14
+    Gs = cg.gramian(cg.NN(), Xd)                                                      # symmetric, diagonal < 1
+    assert relerr((Gs @ torch.from_numpy(rng.standard_normal(n)).cuda()).shape[0], n) == 0
+    K = cg.gramian(cg.GradientKernel(cg.NN()), Xd, Yd)
+    assert relerr((K @ agd).cpu().numpy(), oracle.nn_grad_matrix(X, Y) @ ag) <= 1e-12
+    Ks = cg.gramian(cg.GradientKernel(cg.NN()), Xd)
+    Ms = oracle.nn_grad_matrix(X)
+    assert np.abs(Ms - Ms.T).max() < 1e-13 and relerr(Ks.to_dense().cpu().numpy(), Ms) <= 1e-12
+    Xf = X.astype(np.float32)
+    Gf = cg.gramian(cg.NN(), torch.from_numpy(Xf).cuda())
+    assert relerr((Gf @ torch.from_numpy(a[:1].repeat(n).astype(np.float32)).cuda()).cpu().numpy(), oracle.nn_matrix(0.0, Xf) @ a[:1].repeat(n)) <= 1e-5
