@@ -324,7 +324,7 @@ __device__ __forceinline__ V quarter_tw(const V* __restrict__ stw, int idx, int 
 }
 
 template <typename T, int L>
-__global__ __launch_bounds__((1 << (2 * L)) / 4) void rowfft_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
+__global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void rowfft_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
                                                                           const typename V2T<T>::type* __restrict__ S,
                                                                           const typename V2T<T>::type* __restrict__ tA,
                                                                           const typename V2T<T>::type* __restrict__ tB,
