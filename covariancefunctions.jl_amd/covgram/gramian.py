@@ -173,20 +173,38 @@ def _as_points(x, device=None, dtype=None) -> torch.Tensor:
 
 
 class _Points:
-    """Device-resident point set + its covgram_points handle (borrowing the tensor's memory)."""
+    """Device-resident point set + its covgram_points handle (borrowing the tensor's memory).
+
+    The C ABI's contract for borrowed memory is "unchanged while the handle lives" (the library caches the point set's max norm
+    and, on the matrix-core path, its packed fragments).  A lazy Gramian in the reference, however, follows in-place changes of
+    its points, so this wrapper watches torch's in-place version counter and re-creates the handle when the tensor was written
+    to since the handle was made."""
 
     def __init__(self, t: torch.Tensor):
         self.t = t
         self.ctx = get_ctx(t.device)
-        self.handle = _ffi._P()
-        _ffi.check(_ffi.lib().covgram_points_create(self.ctx.handle, C.byref(self.handle), _ffi._P(t.data_ptr()), t.shape[0],
+        self._h = _ffi._P()
+        self._create()
+
+    def _create(self):
+        t = self.t
+        _ffi.check(_ffi.lib().covgram_points_create(self.ctx.handle, C.byref(self._h), _ffi._P(t.data_ptr()), t.shape[0],
                                                     t.shape[1], _dtype_code(t.dtype), _ffi.DEVICE))
+        self._ver = t._version
+
+    @property
+    def handle(self):
+        if self.t._version != self._ver:                      # points were modified in place: norms / fragments are stale
+            _ffi.lib().covgram_points_destroy(self._h)
+            self._h = _ffi._P()
+            self._create()
+        return self._h
 
     def __del__(self):
         try:
-            if self.handle:
-                _ffi.lib().covgram_points_destroy(self.handle)
-                self.handle = None
+            if self._h:
+                _ffi.lib().covgram_points_destroy(self._h)
+                self._h = None
         except Exception:
             pass
 

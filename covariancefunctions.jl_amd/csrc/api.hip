@@ -597,6 +597,8 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const int64_t rowblocks = (n + rows_per_wg - 1) / rows_per_wg;
     const int64_t npad = rowblocks * rows_per_wg;
 
+    // isotropic kernels work relative to the column side's centre (common.hpp: covgram_points::center)
+    const void* Cn = (hk.k.trait == COVGRAM_ISOTROPIC) ? Y->center : nullptr;
     bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
     if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
@@ -631,21 +633,22 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             const int64_t tot = mp * (int64_t)(D + NRpad);
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(dense_wide_pack_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const float*)Y->dptr, m, Y->d, D, (const float*)a_c, lda_d, nr, 0, (float*)P, NRpad, PKN, 32, (float)hk.kp.gamma);
+                                   (const float*)Y->dptr, m, Y->d, D, (const float*)a_c, lda_d, nr, 0, (float*)P, NRpad, PKN, 32, (float)hk.kp.gamma, (const float*)Cn);
             else
                 hipLaunchKernelGGL(dense_wide_pack_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const double*)Y->dptr, m, Y->d, D, (const double*)a_c, lda_d, nr, 0, (double*)P, NRpad, PKN, 32, hk.kp.gamma);
+                                   (const double*)Y->dptr, m, Y->d, D, (const double*)a_c, lda_d, nr, 0, (double*)P, NRpad, PKN, 32, hk.kp.gamma, (const double*)Cn);
         } else if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma);
+                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma, (const float*)Cn);
         else
             hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma);
+                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma, (const double*)Cn);
         int64_t jchunk; int jsplit;
         // chunks are multiples of 64 columns (whole packed pairs); small problems split finer than the 512-column
         // inner accumulation block so that they still expose thousands of waves
         choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
         DenseArgs da;
+        da.C = Cn;
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
         da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;
         da.variant = (int)ctx->dense_variant; da.lds_pad = (int)ctx->lds_pad; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
@@ -748,6 +751,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         a_dev = sa; y_dev = sy;
     }
     const bool iso = (k->trait == COVGRAM_ISOTROPIC);
+    const void* Cn = iso ? Y->center : nullptr;
     const double alpha0 = alpha * hk.kp.scale;              // value row of the value-gradient blocks
     // isotropic: b = -2 gamma^2 (psi' a + 2 psi'' r'(r'.a));  dot product: b = k1 a + k2 y (x.a)
     const double alpha_eff = alpha * hk.kp.scale * (iso ? -2.0 * hk.kp.gamma2 : 1.0);
@@ -789,11 +793,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
             const int64_t pe = pc * (int64_t)D;
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(grad_wide_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const float*)Y->dptr, m, d, D, (const float*)a_dev, col0, pc, (float*)P, PKN, (float)hk.kp.gamma, vg, (float*)A0P);
+                                   (const float*)Y->dptr, m, d, D, (const float*)a_dev, col0, pc, (float*)P, PKN, (float)hk.kp.gamma, vg, (float*)A0P, (const float*)Cn);
             else
                 hipLaunchKernelGGL(grad_wide_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma, vg, (double*)A0P);
+                                   (const double*)Y->dptr, m, d, D, (const double*)a_dev, col0, pc, (double*)P, PKN, hk.kp.gamma, vg, (double*)A0P, (const double*)Cn);
             GradWideArgs wa;
+            wa.Cn = Cn;
             wa.vg = vg; wa.A0P = A0P; wa.C0 = C0; wa.alpha0 = zs > 1 ? 1.0 : alpha0;
             wa.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma; wa.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
             wa.X = X->dptr; wa.n = n; wa.d = d; wa.dpad = D; wa.P = P; wa.C1 = C; wa.C2 = (char*)C + (size_t)pc * npad64 * ts;
@@ -822,15 +827,16 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         const int64_t pe = (m + 1) * (int64_t)D;
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma, vg, (float*)A0);
+                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma, vg, (float*)A0, (const float*)Cn);
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0);
+                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
         choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 64);
         GradArgs ga;
+        ga.C = Cn;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         ga.vg = vg; ga.A0 = A0; ga.alpha0 = alpha0;

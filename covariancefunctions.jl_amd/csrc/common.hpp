@@ -166,6 +166,13 @@ struct covgram_points {
     int32_t dtype = 0;
     bool owns = false;
     double max_norm2 = 0;  // max_i |x_i|^2 (upper bound; slices inherit the parent's), computed once at creation
+    // Common centre of isotropic kernels: the first point of the ROOT point set (slices inherit it), read by the kernels from
+    // device memory (center) and by the host gates from the copy taken at creation (center_host).  Isotropic kernels
+    // evaluate ((x - c) - (y - c)) gamma with c = the COLUMN side's centre, so the pre-scaled coordinates round relative to
+    // the cloud's extent and results do not depend on where the cloud sits (translation invariance of r = |x - y|).
+    const void* center = nullptr;
+    std::vector<double> center_host;
+    double max_cnorm2 = 0; // max_i |x_i - c|^2 (upper bound), same reduction as max_norm2
     // matrix-core EQ path: the B fragments of this point set as the COLUMN side depend only on (points, gamma), not on the
     // weights, so they are packed once and reused by every later MVM (the points are resident and immutable while the handle
     // lives); only the 4-byte-per-column weights are rebuilt per MVM
@@ -191,6 +198,7 @@ struct DenseArgs {
     int32_t nrhs; int32_t Dpad; int32_t NRpad;
     int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
     int32_t lds_pad = 0;                   // dynamic LDS bytes requested only to cap waves per CU (occupancy experiments)
+    const void* C = nullptr;               // common centre (d scalars on the device) subtracted from both sides by isotropic kernels
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;
@@ -205,6 +213,7 @@ struct GradArgs {
     void* out; int64_t npad;               // partials [jsplit][npad][D] or final
     int32_t Dpad; int64_t jchunk; int32_t jsplit;
     int32_t keep_r;                        // -1 auto, 0 recompute r in sweep 2, 1 keep r in VGPRs
+    const void* C = nullptr;               // common centre of isotropic kernels (dense_mvm.hpp)
     int32_t vg = 0;                        // 1: ValueGradientKernel blocks of d+1 (out slab rows D+1)
     const void* A0 = nullptr;              // vg: value weights of the columns, m+1 entries
     double alpha0 = 0, vg_c = 0, vg_b = 0; // vg: scale of the value row, c2 and b0 coupling coefficients

@@ -37,7 +37,8 @@ namespace covgram {
 //   PB[(T * K2 + mm) * 64 + l] = that fragment (zero outside the point set / dimension)
 //   W[32 T + r]                = a_j * exp2(-|g y_j|^2 / 2)                     (0 for padding columns)
 __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
-                                                        uint4* __restrict__ PB, float* __restrict__ W, int32_t K2, float g) {
+                                                        uint4* __restrict__ PB, float* __restrict__ W, int32_t K2, float g,
+                                                        const float* __restrict__ Cn) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     const int64_t T = q / K2;
     const int64_t j = 32 * T + (l & 31);
     const int c = 2 * mm + (l >> 5);
-    const float yt = (j < m && c < d) ? g * Y[j * (int64_t)d + c] : 0.0f;
+    const float yt = (j < m && c < d) ? g * (Y[j * (int64_t)d + c] - Cn[c]) : 0.0f;
     unsigned y1, y2, y3;
     split3(yt, y1, y2, y3);
     PB[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
         float w = 0.0f;
         if (j < m) {
             float ny = 0.0f;
-            for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+            for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
             w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
         }
         W[j] = w;
@@ -66,7 +67,7 @@ template <int K2, int RT>
 __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
-                                                           float alpha, float beta, int32_t final_store) {
+                                                           float alpha, float beta, int32_t final_store, const float* __restrict__ Cn) {
     const int l = threadIdx.x, t = l & 31, h = l >> 5;
     const int64_t i0 = (int64_t)blockIdx.x * (32 * RT);
     // A fragments: lane (t, h) holds the split of x~[row][c = 2 mm + h]; the row norm from the same fp32 values
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restri
 #pragma unroll
         for (int mm = 0; mm < K2; ++mm) {
             const int c = 2 * mm + h;
-            const float xt = (c < d) ? g * xr[c] : 0.0f;
+            const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
             part = __builtin_fmaf(xt, xt, part);
             unsigned x1, x2, x3;
             split3(xt, x1, x2, x3);
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restri
 // slots [1, 1, 1, n1, n2, n3, 0, 0] with n = |g y|^2;  beyond: zeros.   W[(T * NR + c) * 32 + r] = A[j + c lda].
 __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
                                                             int64_t lda, int32_t nrhs, int32_t c0, uint4* __restrict__ PB,
-                                                            float* __restrict__ W, int32_t K2, int32_t NR, float g, int32_t iso) {
+                                                            float* __restrict__ W, int32_t K2, int32_t NR, float g, int32_t iso,
+                                                            const float* __restrict__ Cn) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -172,13 +174,13 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
     uint4 frag = make_uint4(0, 0, 0, 0);
     if (j < m) {
         if (c < d) {
-            const float yt = (iso ? -2.0f : 1.0f) * (g * Y[j * (int64_t)d + c]);
+            const float yt = iso ? -2.0f * (g * (Y[j * (int64_t)d + c] - Cn[c])) : g * Y[j * (int64_t)d + c];
             unsigned y1, y2, y3;
             split3(yt, y1, y2, y3);
             frag = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
         } else if (iso && c == d) {
             float ny = 0.0f;
-            for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+            for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
             unsigned n1, n2, n3;
             split3(ny, n1, n2, n3);
             frag = make_uint4(BF16_ONE | (BF16_ONE << 16), BF16_ONE | (n1 << 16), n2 | (n3 << 16), 0);
@@ -191,13 +193,13 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
 
 // the per-MVM part of the pack when the fragments are cached: W[j] = a_j * exp2(-|g y_j|^2 / 2)
 __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
-                                                          float* __restrict__ W, int64_t mpad, float g) {
+                                                          float* __restrict__ W, int64_t mpad, float g, const float* __restrict__ Cn) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= mpad) return;
     float w = 0.0f;
     if (j < m) {
         float ny = 0.0f;
-        for (int cc = 0; cc < d; ++cc) { const float yc = g * Y[j * (int64_t)d + cc]; ny = __builtin_fmaf(yc, yc, ny); }
+        for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
         w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
     }
     W[j] = w;
@@ -206,44 +208,68 @@ __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restric
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
 template <typename T>
 __global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits) {
-    float v = 0.0f;
+    // outbits[0]: max |x_i|^2 (dot-product kernels), outbits[1]: max |x_i - x_0|^2 (isotropic kernels, centre = first point)
+    float v = 0.0f, vc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // grid-stride
-        double s = 0;
-        for (int c = 0; c < d; ++c) { const double xc = (double)X[i * (int64_t)d + c]; s += xc * xc; }
-        float f = (float)s;
+        double s = 0, sc = 0;
+        for (int c = 0; c < d; ++c) {
+            const double xc = (double)X[i * (int64_t)d + c], xd = xc - (double)X[c];
+            s += xc * xc; sc += xd * xd;
+        }
+        float f = (float)s, fc = (float)sc;
         if (!(f >= 0.0f)) f = __builtin_inff();                  // NaN / overflow: never eligible
+        if (!(fc >= 0.0f)) fc = __builtin_inff();
         v = fmaxf(v, f * 1.000001f);                             // round up: the bound must not under-estimate
+        vc = fmaxf(vc, fc * 1.000001f);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    __shared__ float wmax[4];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    for (int o = 32; o > 0; o >>= 1) { v = fmaxf(v, __shfl_xor(v, o)); vc = fmaxf(vc, __shfl_xor(vc, o)); }
+    __shared__ float wmax[4], wcmax[4];
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = v; wcmax[threadIdx.x >> 6] = vc; }
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(outbits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));   // one per workgroup
+    if (threadIdx.x == 0) {                                      // one pair of atomics per workgroup
+        atomicMax(outbits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+        atomicMax(outbits + 1, __float_as_uint(fmaxf(fmaxf(wcmax[0], wcmax[1]), fmaxf(wcmax[2], wcmax[3]))));
+    }
 }
 
 int points_max_norm2(covgram_points* p) {
-    p->max_norm2 = 0.0;
+    p->max_norm2 = 0.0; p->max_cnorm2 = 0.0;
+    p->center = nullptr; p->center_host.assign((size_t)p->d, 0.0);
     if (p->n == 0) return COVGRAM_OK;
+    p->center = p->dptr;                                         // first point of the set
     unsigned* dbits = nullptr;
-    CG_CHECK_HIP(hipMalloc(&dbits, sizeof(unsigned)));
+    CG_CHECK_HIP(hipMalloc(&dbits, 2 * sizeof(unsigned)));
     hipStream_t st = p->ctx->stream;
-    hipError_t e = hipMemsetAsync(dbits, 0, sizeof(unsigned), st);
+    hipError_t e = hipMemsetAsync(dbits, 0, 2 * sizeof(unsigned), st);
     if (e == hipSuccess) {
         const unsigned grid = (unsigned)std::min<int64_t>((p->n + 255) / 256, 2048);
         if (p->dtype == COVGRAM_F32) hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits);
         else hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits);
         e = hipGetLastError();
     }
-    unsigned bits = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bits, dbits, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    unsigned bits[2] = {0, 0};
+    std::vector<char> c0((size_t)p->d * dtype_size(p->dtype));
+    if (e == hipSuccess) e = hipMemcpyAsync(bits, dbits, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c0.data(), p->dptr, c0.size(), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(dbits);
     if (e != hipSuccess) { set_error("max-norm reduction failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
-    float f;
-    memcpy(&f, &bits, sizeof(f));
-    p->max_norm2 = (double)f;
+    float f[2];
+    memcpy(f, bits, sizeof(f));
+    p->max_norm2 = (double)f[0];
+    p->max_cnorm2 = (double)f[1];
+    for (int c = 0; c < p->d; ++c)
+        p->center_host[c] = p->dtype == COVGRAM_F32 ? (double)((const float*)c0.data())[c] : ((const double*)c0.data())[c];
     return COVGRAM_OK;
+}
+
+// bound on max_i |x_i - c_Y| from the per-handle quantities: |x - c_Y| <= |x - c_X| + |c_X - c_Y|
+static double centred_radius(const covgram_points* X, const covgram_points* Y) {
+    double s = 0;
+    for (int c = 0; c < X->d; ++c) { const double t = X->center_host[c] - Y->center_host[c]; s += t * t; }
+    if (!(s >= 0)) return INFINITY;
+    return sqrt(X->max_cnorm2) + sqrt(s) * 1.000001;
 }
 
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
@@ -252,7 +278,7 @@ bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgra
     if (X->d > 32 || Y->n == 0) return false;                   // beyond d = 32 the fragments leave one wave per SIMD
     if (ctx->dense_variant == 2) return true;
     const double g2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale);   // |x~|^2 = g2 |x|^2
-    return g2 * sqrt(X->max_norm2) * sqrt(Y->max_norm2) <= MFMA_GATE;
+    return g2 * centred_radius(X, Y) * sqrt(Y->max_cnorm2) <= MFMA_GATE;
 }
 
 // resident single-wave workgroups per CU of the kernel instance (register-limited), for the grid sizing below
@@ -271,11 +297,11 @@ static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : 
 
 template <int K2>
 static void launch_mfma(int rt, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
-                        float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store) {
+                        float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
     if (rt == 2)
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
 }
 
 // y <- alpha * scale * G a + beta * y for ONE right-hand side (device pointers)
@@ -287,6 +313,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const int K2 = (D + 1) / 2;
     const int64_t ntile = (m + 31) / 32;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
+    const float* Cn = (const float*)Y->center;                    // both sides are taken relative to the column side's centre
     // fragments: cached in the column point set's handle (they do not depend on the weights); weights: per MVM
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
     void* Wp;
@@ -300,10 +327,10 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
         Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
-                           (uint4*)Y->frag_cache, W, K2, g);
+                           (uint4*)Y->frag_cache, W, K2, g, Cn);
     } else {
         hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, W,
-                           ntile * 32, g);
+                           ntile * 32, g, Cn);
     }
     const uint4* PB = (const uint4*)Y->frag_cache;
     // split the column tiles so that the grid holds ~CUs * 128 waves (as the lane-per-row kernel, profiles/r01_quickbench_wg64.txt)
@@ -330,7 +357,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const int fs = js == 1 ? 1 : 0;
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs); break;
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
@@ -379,7 +406,8 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
     if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
     if (ctx->dense_variant == 2) return true;
-    const double P = sqrt(X->max_norm2) * sqrt(Y->max_norm2) / (hk.k.lengthscale * hk.k.lengthscale);
+    const double P = (iso ? centred_radius(X, Y) * sqrt(Y->max_cnorm2) : sqrt(X->max_norm2) * sqrt(Y->max_norm2)) /
+                     (hk.k.lengthscale * hk.k.lengthscale);
     if (!(P < 1e30)) return false;
     if (!iso) return true;                                                     // x.y itself: no cancellation to gate
     // relative sensitivity of the profile to an absolute error in s (natural units): |phi'/phi| at its maximum
@@ -419,11 +447,11 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         float* W = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a_c,
-                           lda, nr, 0, PB, W, K2, NR, (float)hk.kp.gamma, iso ? 1 : 0);
+                           lda, nr, 0, PB, W, K2, NR, (float)hk.kp.gamma, iso ? 1 : 0, (const float*)Y->center);
         MfmaArgs ma;
         ma.K2 = K2; ma.NR = NR;
         ma.RT = (NR == 1 && K2 <= 4 && ctx->rows_per_lane != 1) ? 2 : 1;
-        ma.hk = &hk; ma.stream = ctx->stream;
+        ma.hk = &hk; ma.stream = ctx->stream; ma.Cn = (const float*)Y->center;
         const int nb = launch(ma, true);
         const int64_t rowtiles = (n + 32 * ma.RT - 1) / (32 * ma.RT);
         const int64_t npad = rowtiles * 32 * ma.RT;

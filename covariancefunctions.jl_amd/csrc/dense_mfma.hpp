@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
                                                             int64_t tchunk, float alpha, float beta, int32_t final_store,
-                                                            const KParams<float> kp) {
+                                                            const float* __restrict__ Cn, const KParams<float> kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     const int l = threadIdx.x, t = l & 31, h = l >> 5;
     const int64_t i0 = (int64_t)blockIdx.x * (32 * RT);
@@ -56,14 +56,14 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
         const float* __restrict__ xr = X + row * (int64_t)d;
         float nx = 0.0f;
         if constexpr (ISO)
-            for (int cc = 0; cc < d; ++cc) { const float xc = g * xr[cc]; nx = __builtin_fmaf(xc, xc, nx); }
+            for (int cc = 0; cc < d; ++cc) { const float xc = g * (xr[cc] - Cn[cc]); nx = __builtin_fmaf(xc, xc, nx); }
 #pragma unroll
         for (int mm = 0; mm < K2; ++mm) {
             const int c = 2 * mm + h;
             uint4 f = make_uint4(0, 0, 0, 0);
             if (c < d) {
                 unsigned x1, x2, x3;
-                split3(g * xr[c], x1, x2, x3);
+                split3(ISO ? g * (xr[c] - Cn[c]) : g * xr[c], x1, x2, x3);
                 f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
             } else if (ISO && c == d) {
                 unsigned n1, n2, n3;
@@ -159,6 +159,7 @@ struct MfmaArgs {
     const HostKernel* hk;
     hipStream_t stream;
     dim3 grid;
+    const float* Cn = nullptr;   // common centre of isotropic kernels (dense_mvm.hpp)
 };
 
 // returns the resident blocks per CU of the instance when `query` is set (no launch), COVGRAM_OK / error otherwise
@@ -174,7 +175,7 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
         return cached;
     }
     hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out, a.npad,
-                       a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, cast_params<float>(a.hk->kp));
+                       a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, cast_params<float>(a.hk->kp));
     return COVGRAM_OK;
 }
 

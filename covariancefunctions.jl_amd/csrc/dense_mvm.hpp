@@ -117,7 +117,10 @@ template <typename T, int FAM, int D, int NR, int R, bool POW>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     const T* __restrict__ X, int64_t n, int32_t d, const typename Pk<T>::V* __restrict__ P, int64_t m,
     T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs, int64_t jchunk, T alpha, T beta,
-    int32_t final_store, const typename ParamsOf<FAM, T>::type kp) {
+    int32_t final_store, const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp) {
+    // Cn: the common centre c (d scalars, the column point set's reference point) that isotropic kernels subtract from BOTH
+    // sides before the pre-scale: (x - c) gamma - (y - c) gamma keeps the rounding of the scaled coordinates relative to the
+    // cloud's extent, not to its distance from the origin (the reference subtracts first and scales after, src/util.jl:40-47).
     constexpr bool ISO = fam_is_iso<FAM>;
     using Body = DenseBody<T, FAM, D, NR, R, POW, ISO>;
     using PK = Pk<T>;
@@ -143,10 +146,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
         const T* xr = X + row * (int64_t)d;
         if (d == D) {   // common case: no padding, straight loads
 #pragma unroll
-            for (int l = 0; l < D; ++l) x[r][l] = xr[l] * kp.gamma;
+            for (int l = 0; l < D; ++l) x[r][l] = (ISO ? xr[l] - Cn[l] : xr[l]) * kp.gamma;
         } else {
 #pragma unroll
-            for (int l = 0; l < D; ++l) x[r][l] = (l < d) ? xr[l] * kp.gamma : (T)0;
+            for (int l = 0; l < D; ++l) x[r][l] = (l < d) ? (ISO ? xr[l] - Cn[l] : xr[l]) * kp.gamma : (T)0;
         }
     }
 
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void dense_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
                                                          int64_t lda, int32_t nrhs, int32_t c0, T* __restrict__ P, int32_t D,
-                                                         int32_t NR, int32_t PKN, T gamma) {
+                                                         int32_t NR, int32_t PKN, T gamma, const T* __restrict__ Cn) {
     const int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // padded column index
     const int64_t mp = ((m + PKN - 1) / PKN) * PKN;
     if (jj >= mp) return;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const T* __restrict__ Y
     const int64_t g = jj / PKN;
     const int h = (int)(jj - g * PKN);
     T* p = P + g * (int64_t)(D + NR) * PKN + h;
-    for (int l = 0; l < D; ++l) p[(int64_t)l * PKN] = (l < d) ? Y[j * (int64_t)d + l] * gamma : (T)0;
+    for (int l = 0; l < D; ++l) p[(int64_t)l * PKN] = (l < d) ? (Y[j * (int64_t)d + l] - (Cn ? Cn[l] : (T)0)) * gamma : (T)0;
     for (int c = 0; c < NR; ++c) p[(int64_t)(D + c) * PKN] = (!pad && c0 + c < nrhs) ? A[j + (int64_t)(c0 + c) * lda] : (T)0;
 }
 
@@ -258,7 +261,7 @@ static int launch_dense_one(const DenseArgs& a) {
     const int final_store = (a.jsplit == 1) ? 1 : 0;
     hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW>), grid, dim3(DENSE_THREADS), (size_t)a.lds_pad, a.stream, (const T*)a.X, a.n,
                        a.d, (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha,
-                       (T)a.beta, final_store, kp);
+                       (T)a.beta, final_store, (const T*)a.C, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -26,7 +26,8 @@ template <typename T> constexpr int wide_jg() { return 32; }   // column groups 
 template <typename T>
 __global__ __launch_bounds__(256) void dense_wide_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, int32_t dpad,
                                                               const T* __restrict__ A, int64_t lda, int32_t nrhs, int32_t c0,
-                                                              T* __restrict__ P, int32_t NR, int32_t PKN, int32_t JG, T gamma) {
+                                                              T* __restrict__ P, int32_t NR, int32_t PKN, int32_t JG, T gamma,
+                                                              const T* __restrict__ Cn) {
     const int64_t cols_per_blk = (int64_t)JG * PKN;
     const int64_t nblk = (m + cols_per_blk - 1) / cols_per_blk;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (padded column, coordinate-or-weight slot)
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void dense_wide_pack_kernel(const T* __restric
     T* base = P + blk * (int64_t)JG * slots * PKN;
     if (sl < dpad) {
         const int ch = sl / WIDE_CH, ll = sl - ch * WIDE_CH;
-        base[((int64_t)(ch * JG + g) * WIDE_CH + ll) * PKN + h] = (sl < d) ? Y[j * (int64_t)d + sl] * gamma : (T)0;
+        base[((int64_t)(ch * JG + g) * WIDE_CH + ll) * PKN + h] = (sl < d) ? (Y[j * (int64_t)d + sl] - (Cn ? Cn[sl] : (T)0)) * gamma : (T)0;
     } else {
         const int c = sl - dpad;
         base[((int64_t)dpad * JG + (int64_t)g * NR + c) * PKN + h] = (!pad && c0 + c < nrhs) ? A[j + (int64_t)(c0 + c) * lda] : (T)0;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wide_kernel(const T* __re
                                                                    const typename Pk<T>::V* __restrict__ P, int64_t m,
                                                                    T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
                                                                    int64_t jchunk, T alpha, T beta, int32_t final_store,
-                                                                   const typename ParamsOf<FAM, T>::type kp) {
+                                                                   const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -85,10 +86,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wide_kernel(const T* __re
             const int l0 = ch * WIDE_CH;
             if (l0 + WIDE_CH <= d) {
 #pragma unroll
-                for (int l = 0; l < WIDE_CH; ++l) x[l] = xr[l0 + l] * kp.gamma;
+                for (int l = 0; l < WIDE_CH; ++l) x[l] = (ISO ? xr[l0 + l] - Cn[l0 + l] : xr[l0 + l]) * kp.gamma;
             } else {
 #pragma unroll
-                for (int l = 0; l < WIDE_CH; ++l) x[l] = (l0 + l < d) ? xr[l0 + l] * kp.gamma : (T)0;
+                for (int l = 0; l < WIDE_CH; ++l) x[l] = (l0 + l < d) ? (ISO ? xr[l0 + l] - Cn[l0 + l] : xr[l0 + l]) * kp.gamma : (T)0;
             }
             const V* __restrict__ pc = pb + (int64_t)ch * (JG * WIDE_CH);
 #pragma unroll
@@ -153,7 +154,7 @@ static int launch_dense_wide_NR(const DenseArgs& a) {
 #define CG_WIDE_LAUNCH(POWV)                                                                                                        \
     hipLaunchKernelGGL((dense_wide_kernel<T, FAM, NR, POWV>), grid, dim3(DENSE_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, a.Dpad, \
                        (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha, (T)a.beta,        \
-                       final_store, kp)
+                       final_store, (const T*)a.C, kp)
     if constexpr (fam_is_expr<FAM>) CG_WIDE_LAUNCH(false);
     else { if (pow) CG_WIDE_LAUNCH(true); else CG_WIDE_LAUNCH(false); }
 #undef CG_WIDE_LAUNCH

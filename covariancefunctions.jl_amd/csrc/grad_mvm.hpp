@@ -56,7 +56,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
                                                                 int64_t jchunk, T alpha, T beta, int32_t final_store,
                                                                 const T* __restrict__ A0, T alpha0, T vg_c, T vg_b,
-                                                                const typename ParamsOf<FAM, T>::type kp) {
+                                                                const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     constexpr int DC = (64 / (int)sizeof(T) < D) ? 64 / (int)sizeof(T) : D;   // dims per chunk (one 64-byte s_load per operand)
     constexpr int NC = (D + DC - 1) / DC;
@@ -75,10 +75,10 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
         const T* xr = X + row * (int64_t)d;
         if (d == D) {   // common case: no padding, straight vector loads
 #pragma unroll
-            for (int l = 0; l < D; ++l) x[l] = xr[l] * kp.gamma;
+            for (int l = 0; l < D; ++l) x[l] = (ISO ? xr[l] - Cn[l] : xr[l]) * kp.gamma;      // common centre: dense_mvm.hpp
         } else {
 #pragma unroll
-            for (int l = 0; l < D; ++l) x[l] = (l < d) ? xr[l] * kp.gamma : (T)0;
+            for (int l = 0; l < D; ++l) x[l] = (l < d) ? (ISO ? xr[l] - Cn[l] : xr[l]) * kp.gamma : (T)0;
         }
 #pragma unroll
         for (int l = 0; l < D; ++l) b[l] = (T)0;
@@ -237,14 +237,15 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
 // vg = 1: A holds blocks of d+1 (value weight first); the value weights go to A0[0..m] (A0[m] = 0, prefetch only).
 template <typename T>
 __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
-                                                        T* __restrict__ P, int32_t D, T gamma, int32_t vg, T* __restrict__ A0) {
+                                                        T* __restrict__ P, int32_t D, T gamma, int32_t vg, T* __restrict__ A0,
+                                                        const T* __restrict__ Cn) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (m + 1) * (int64_t)D) return;
     const int64_t j = e / D;
     const int l = (int)(e - j * D);
     T* p = P + j * (int64_t)(2 * D);
     const bool real = (j < m) && (l < d);
-    p[l] = real ? Y[j * (int64_t)d + l] * gamma : (T)0;
+    p[l] = real ? (Y[j * (int64_t)d + l] - (Cn ? Cn[l] : (T)0)) * gamma : (T)0;
     p[D + l] = real ? A[j * (int64_t)(d + vg) + vg + l] : (T)0;
     if (vg && l == 0) A0[j] = (j < m) ? A[j * (int64_t)(d + 1)] : (T)0;
 }
@@ -268,7 +269,7 @@ static int launch_grad_one(const GradArgs& a) {
 #define CG_GRAD_LAUNCH(KEEPV, POWV, VGV)                                                                                                \
     hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,  \
                        (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,             \
-                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, kp)
+                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp)
     bool done = false;
     if (a.vg) {   // the value-gradient variant always recomputes r (one instantiation per D)
         if (pow) CG_GRAD_LAUNCH(false, POWT, true); else CG_GRAD_LAUNCH(false, false, true);

@@ -23,7 +23,8 @@ constexpr int GJG = 16;   // column groups per block (fp32: 32 columns, fp64: 16
 template <typename T>
 __global__ __launch_bounds__(256) void grad_wide_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, int32_t dpad,
                                                              const T* __restrict__ A, int64_t col0, int64_t pcols,
-                                                             T* __restrict__ P, int32_t PKN, T gamma, int32_t vg, T* __restrict__ A0P) {
+                                                             T* __restrict__ P, int32_t PKN, T gamma, int32_t vg, T* __restrict__ A0P,
+                                                             const T* __restrict__ Cn) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (panel column, coordinate)
     if (e >= pcols * (int64_t)dpad) return;
     const int64_t jp = e / dpad;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void grad_wide_pack_kernel(const T* __restrict
     const int nch = dpad / WIDE_CH;
     T* base = P + blk * (int64_t)nch * 2 * GJG * WIDE_CH * PKN;
     const bool real = sl < d;
-    base[(((int64_t)(ch * 2 + 0) * GJG + g) * WIDE_CH + ll) * PKN + h] = real ? Y[j * (int64_t)d + sl] * gamma : (T)0;
+    base[(((int64_t)(ch * 2 + 0) * GJG + g) * WIDE_CH + ll) * PKN + h] = real ? (Y[j * (int64_t)d + sl] - (Cn ? Cn[sl] : (T)0)) * gamma : (T)0;
     base[(((int64_t)(ch * 2 + 1) * GJG + g) * WIDE_CH + ll) * PKN + h] = (real && !pad) ? A[j * (int64_t)(d + vg) + vg + sl] : (T)0;
     // value-gradient blocks: the value weight of each column, [block][group][packed column]
     if (vg && sl == 0) A0P[(blk * GJG + g) * PKN + h] = pad ? (T)0 : A[j * (int64_t)(d + 1)];
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict_
                                                             const typename Pk<T>::V* __restrict__ P,
                                                             typename Pk<T>::V* __restrict__ C1, typename Pk<T>::V* __restrict__ C2,
                                                             int64_t npad, const typename Pk<T>::V* __restrict__ A0P, T* __restrict__ C0,
-                                                            T vg_c, T vg_b, const typename ParamsOf<FAM, T>::type kp) {
+                                                            T vg_c, T vg_b, const T* __restrict__ Cn,
+                                                            const typename ParamsOf<FAM, T>::type kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -71,10 +73,10 @@ __global__ __launch_bounds__(64) void grad_wide_coef_kernel(const T* __restrict_
         const int l0 = ch * WIDE_CH;
         if (l0 + WIDE_CH <= d) {
 #pragma unroll
-            for (int l = 0; l < WIDE_CH; ++l) x[l] = xr[l0 + l] * kp.gamma;
+            for (int l = 0; l < WIDE_CH; ++l) x[l] = (ISO ? xr[l0 + l] - Cn[l0 + l] : xr[l0 + l]) * kp.gamma;
         } else {
 #pragma unroll
-            for (int l = 0; l < WIDE_CH; ++l) x[l] = (l0 + l < d) ? xr[l0 + l] * kp.gamma : (T)0;
+            for (int l = 0; l < WIDE_CH; ++l) x[l] = (l0 + l < d) ? (ISO ? xr[l0 + l] - Cn[l0 + l] : xr[l0 + l]) * kp.gamma : (T)0;
         }
         const V* __restrict__ py = pb + (int64_t)ch * (2 * GJG * WIDE_CH);
         const V* __restrict__ pa = py + GJG * WIDE_CH;
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
                                                              const typename Pk<T>::V* __restrict__ C1,
                                                              const typename Pk<T>::V* __restrict__ C2, int64_t npad,
                                                              int64_t nblocks, T* __restrict__ y, T alpha, T beta, int32_t accumulate,
-                                                             T gamma, int32_t vg, const T* __restrict__ C0, T alpha0, int64_t zstride) {
+                                                             T gamma, int32_t vg, const T* __restrict__ C0, T alpha0, int64_t zstride,
+                                                             const T* __restrict__ Cn) {
     using PK = Pk<T>;
     using V = typename PK::V;
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64) void grad_wide_apply_kernel(const T* __restrict
     V bv[WIDE_CH];
 #pragma unroll
     for (int l = 0; l < WIDE_CH; ++l) {
-        x[l] = (l0 + l < d) ? xr[l0 + l] * gamma : (T)0;
+        x[l] = (l0 + l < d) ? (ISO ? xr[l0 + l] - Cn[l0 + l] : xr[l0 + l]) * gamma : (T)0;
         bv[l] = PK::splat((T)0);
     }
     for (int64_t b = b_begin; b < b_end; ++b) {
@@ -250,6 +253,7 @@ struct GradWideArgs {
     void* y; double alpha, beta; int32_t accumulate;
     int32_t vg = 0; const void* A0P = nullptr; void* C0 = nullptr; double alpha0 = 0, vg_c = 0, vg_b = 0;
     int32_t zs = 1; int64_t zstride = 0;   // column split of the apply kernel (y then points at the slice slab)
+    const void* Cn = nullptr;              // common centre of isotropic kernels (dense_mvm.hpp)
     const HostKernel* hk;
     hipStream_t stream;
 };
@@ -264,13 +268,13 @@ static int launch_grad_wide_T(const GradWideArgs& a) {
     constexpr bool POWT = !fam_is_expr<FAM>;
 #define CG_COEF_LAUNCH(POWV, VGV)                                                                                                       \
     hipLaunchKernelGGL((grad_wide_coef_kernel<T, FAM, POWV, VGV>), dim3(rb, (unsigned)a.nblocks), dim3(64), 0, a.stream, (const T*)a.X, a.n, \
-                       a.d, a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, (const V*)a.A0P, (T*)a.C0, (T)a.vg_c, (T)a.vg_b, kp)
+                       a.d, a.dpad, (const V*)a.P, (V*)a.C1, (V*)a.C2, a.npad, (const V*)a.A0P, (T*)a.C0, (T)a.vg_c, (T)a.vg_b, (const T*)a.Cn, kp)
     if (a.vg) { if (pow) CG_COEF_LAUNCH(POWT, true); else CG_COEF_LAUNCH(false, true); }
     else { if (pow) CG_COEF_LAUNCH(POWT, false); else CG_COEF_LAUNCH(false, false); }
 #undef CG_COEF_LAUNCH
     hipLaunchKernelGGL((grad_wide_apply_kernel<T, ISO>), dim3(rb, (unsigned)(a.dpad / WIDE_CH), (unsigned)a.zs), dim3(64), 0, a.stream,
                        (const T*)a.X, a.n, a.d, a.dpad, (const V*)a.P, (const V*)a.C1, (const V*)a.C2, a.npad, a.nblocks, (T*)a.y, (T)a.alpha,
-                       (T)a.beta, a.accumulate, kp.gamma, a.vg, (const T*)a.C0, (T)a.alpha0, a.zstride);
+                       (T)a.beta, a.accumulate, kp.gamma, a.vg, (const T*)a.C0, (T)a.alpha0, a.zstride, (const T*)a.Cn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_wide launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -535,8 +535,9 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
 
 
 def test_eq_matrix_core_gate(cg, oracle):
-    """The expanded exponent is only used while max|x~| max|y~| <= 128; far-from-origin or short-lengthscale data falls back
-    to direct differences (and stays accurate); fp64, other profiles, several right-hand sides never take it."""
+    """The expanded exponent is only used while max|x~| max|y~| <= 128, x~ = (x - c) / l relative to the set's own centre c
+    (its first point): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
+    changes nothing; fp64 and the profiles that are not smooth in s never take it."""
     rng = np.random.default_rng(5)
     n, d = 600, 3
     X0 = rng.standard_normal((n, d)).astype(np.float32)
@@ -546,14 +547,22 @@ def test_eq_matrix_core_gate(cg, oracle):
     G = cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X0, X0, a, dtype=np.float32)) <= 1e-5
     # right below the gate (P = max|x~| max|y~| = 125): still far inside the fp32 tolerance
-    s = np.sqrt(125.0 / (1.4426950408889634 * float((X0.astype(np.float64) ** 2).sum(1).max())))
+    s = np.sqrt(125.0 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0[0]) ** 2).sum(1).max())))
     Xg = (X0 * s).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xg).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xg, Xg, a, dtype=np.float32)) <= 2e-6
-    # the same cloud shifted far from the origin: |x|^2 ~ 3e4 -> cancellation would cost ~1e-3; the gate sends it to the exact kernel
+    # right above it: the exact kernel
+    Xa = (X0 * (s * 1.02)).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(Xa).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 1 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xa, Xa, a, dtype=np.float32)) <= 1e-5
+    # the same cloud shifted far from the origin (|x|^2 ~ 3e4): both sides are centred first, so the gate and the accuracy are unchanged
     Xs = (X0 + 100.0).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xs).cuda()); b = (G @ ad).cpu().numpy()
-    assert cg.get_info("last_dense_path") == 1 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xs, Xs, a, dtype=np.float32)) <= 1e-5
+    assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xs, Xs, a, dtype=np.float32)) <= 1e-5
+    # two clouds far from EACH OTHER: |x - c_Y| is large whatever the centre -> exact kernel (all entries underflow to 0 here)
+    Ys = (X0 - 100.0).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(Xs).cuda(), torch.from_numpy(Ys).cuda()); b = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 1 and np.all(b == 0)
     # short lengthscale: |x/l| large
     G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.05), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 1
@@ -825,3 +834,61 @@ def test_neural_network_kernel(cg, oracle):
     Xf = X.astype(np.float32)
     Gf = cg.gramian(cg.NN(), torch.from_numpy(Xf).cuda())
     assert relerr((Gf @ torch.from_numpy(a[:1].repeat(n).astype(np.float32)).cuda()).cpu().numpy(), oracle.nn_matrix(0.0, Xf) @ a[:1].repeat(n)) <= 1e-5
+
+
+def test_gramian_follows_in_place_point_updates(cg, oracle):
+    """A lazy Gramian holds its points by reference (src/gramian.jl:10-21): after an in-place update of x the next mul! must
+    see the new points — also on the matrix-core path, whose norm gate and packed fragments are cached per handle."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((500, 3)).astype(np.float32); a = rng.standard_normal(500).astype(np.float32)
+    Xd = torch.from_numpy(X.copy()).cuda(); ad = torch.from_numpy(a).cuda()
+    G = cg.gramian(cg.EQ(), Xd)
+    b0 = (G @ ad).cpu().numpy()
+    assert cg.get_info("last_dense_path") == 2 and relerr(b0, oracle.mul(None, oracle.Kernel(oracle.EQ), X, X, a, dtype=np.float32)) <= 1e-5
+    Xd.mul_(0.5).add_(0.25)                                                # in place
+    X2 = (X * 0.5 + 0.25).astype(np.float32)
+    assert relerr((G @ ad).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.EQ), X2, X2, a, dtype=np.float32)) <= 1e-5
+    Xd.add_(200.0)                                                         # far from the origin: kernels and gate work relative
+    X3 = (X2 + 200.0).astype(np.float32)                                   # to the set's own centre, so nothing changes
+    assert relerr((G @ ad).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.EQ), X3, X3, a, dtype=np.float32)) <= 1e-5
+    assert cg.get_info("last_dense_path") == 2
+
+
+@pytest.mark.parametrize("shift", [0.0, 1.0e3, -3.0e4])
+def test_isotropic_paths_are_translation_invariant(cg, oracle, shift):
+    """r = |x - y| does not depend on where the cloud sits (src/util.jl:40-47 subtracts first): every isotropic device path
+    centres both sides on a common point before its pre-scale, so fp32 parity holds far from the origin, on the direct,
+    matrix-core, wide, gradient and value-gradient kernels alike."""
+    rng = np.random.default_rng(11)
+    n, m = 300, 260
+    for d in (2, 5, 70):
+        X = (rng.standard_normal((n, d)) + shift).astype(np.float32)
+        Y = (rng.standard_normal((m, d)) + shift).astype(np.float32)
+        a = rng.standard_normal(m).astype(np.float32)
+        Xd, Yd, ad = (torch.from_numpy(t).cuda() for t in (X, Y, a))
+        l = 1.0 if d <= 5 else 6.0
+        for kern, ok in ((cg.Lengthscale(cg.EQ(), l), oracle.Kernel(oracle.EQ, lengthscale=l)),
+                         (cg.Lengthscale(cg.MaternP(2), 1.7 * l), oracle.Kernel(oracle.MATERNP, p=2, lengthscale=1.7 * l)),
+                         (cg.Lengthscale(cg.RQ(1.5), l), oracle.Kernel(oracle.RQ, param=1.5, lengthscale=l))):
+            want = oracle.mul(None, ok, X, Y, a, dtype=np.float32)
+            for variant in (0, 1):
+                cg.set_option("dense_variant", variant)
+                try:
+                    got = (cg.gramian(kern, Xd, Yd) @ ad).cpu().numpy()
+                finally:
+                    cg.set_option("dense_variant", 0)
+                assert relerr(got, want) <= 1e-5, (shift, d, variant, type(kern).__name__, relerr(got, want))
+    # gradient blocks (lane-per-row and panel kernels) and value-gradient blocks
+    for d in (3, 70):
+        X = (rng.standard_normal((120, d)) + shift).astype(np.float32)
+        A = rng.standard_normal((120, d)).astype(np.float32)
+        l = 1.0 if d == 3 else 6.0
+        kern, ok = cg.Lengthscale(cg.EQ(), l), oracle.Kernel(oracle.EQ, lengthscale=l)
+        Xd, Ad = torch.from_numpy(X).cuda(), torch.from_numpy(A).cuda()
+        got = (cg.gramian(cg.GradientKernel(kern), Xd) @ Ad.reshape(-1)).cpu().numpy()
+        want = oracle.grad_mul(None, ok, X, X, A.reshape(-1), dtype=np.float32)
+        assert relerr(got, want) <= 1e-5, (shift, d, relerr(got, want))
+        Av = rng.standard_normal((120, d + 1)).astype(np.float32)
+        got = (cg.gramian(cg.ValueGradientKernel(kern), Xd) @ torch.from_numpy(Av).cuda().reshape(-1)).cpu().numpy()
+        want = oracle.valgrad_mul(None, ok, X, X, Av.reshape(-1), dtype=np.float32)
+        assert relerr(got, want) <= 1e-5, (shift, d, relerr(got, want))
