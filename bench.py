@@ -173,13 +173,15 @@ def main():
                 traffic = None
         # which kernel ran (the library picks the matrix-core EQ path when its norm bound holds)
         if dense_path == 2:
-            kname = "covgram::dense_mfma_eq_kernel<K2=2, RT=2> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + 1 v_fma_f32 per pair)"
-            ceiling = 1024 * 2.4e9 * 64 / 12.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (4 cyc) per 64 pairs per SIMD
+            kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=4, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+                     "1 v_fma_f32 per pair; 4 waves share each column tile through LDS)")
+            ceiling = 1024 * 2.4e9 * 64 / 10.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (2 cyc) per 64 pairs per SIMD
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
-                    "products), the VALU does 1 v_exp_f32 (8 issue cycles) + 1 v_fma_f32 (4) per 64 pairs per SIMD -> ceiling "
-                    "1.31e13 pairs/s at 2.4 GHz; rocprof SQ counters show the VALU ~100% busy at the ~1.85 GHz the chip sustains "
-                    "under this load (profiles/r01_mfma_eq_counters.txt). 'achieved' uses the reference's algorithmic 3d+3 flops per "
-                    "pair (SURVEY.md §8d), not the instructions executed. 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
+                    "products), the VALU does 1 v_exp_f32 (8 issue cycles: quarter rate) + 1 v_fma_f32 (2) per 64 pairs per SIMD -> "
+                    "ceiling 1.57e13 pairs/s at the 2.4 GHz peak clock (issue_roofline_frac); rocprof SQ counters show the VALU "
+                    "~100% busy at the ~1.85 GHz the chip sustains under this load (profiles/r01_mfma_eq_counters.txt), i.e. "
+                    "~1.2e13 pairs/s at the sustained clock. 'achieved' uses the reference's algorithmic 3d+3 flops per "
+                    "pair (SURVEY.md \u00a78d), not the instructions executed. 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
         else:
             kname = "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>"
             ceiling = 7.15e12

@@ -435,6 +435,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
+    else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;

@@ -147,6 +147,7 @@ struct covgram_ctx {
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
+    int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
@@ -228,6 +229,7 @@ grad_launch_fn grad_launcher(int family);
 // P = max|x~| max|y~| up to which the expanded exponent is used.  Its absolute error is a few fp32 roundings of O(P):
 // measured contribution to the MVM's 2-norm relative error ~4e-9 P (C2: P = 40, +0.7e-7; P = 125: 5e-7, tests), against
 // the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is ~1.7e-7 P per entry.
+constexpr int MFMA_LDS_MIN_TILES = 64;
 constexpr double MFMA_GATE = 128.0;
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);

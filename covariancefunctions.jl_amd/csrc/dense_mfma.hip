@@ -63,13 +63,15 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     }
 }
 
-template <int K2, int RT>
-__global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+template <int K2, int RT, int WPB = 1, bool LDS = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ? (K2 <= 2 ? 4 : 3) : 1, LDS ? (K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
                                                            float alpha, float beta, int32_t final_store, const float* __restrict__ Cn) {
-    const int l = threadIdx.x, t = l & 31, h = l >> 5;
-    const int64_t i0 = (int64_t)blockIdx.x * (32 * RT);
+    // WPB waves per workgroup take consecutive row tiles and walk the SAME column tiles at the same pace (no barrier,
+    // nothing shared explicitly): their fragment loads coalesce in the CU's vector L1 instead of each going to L2
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * (32 * RT);
     // A fragments: lane (t, h) holds the split of x~[row][c = 2 mm + h]; the row norm from the same fp32 values
     Frag a[RT][K2];
     float nx[RT];
@@ -111,15 +113,71 @@ __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restri
         w = wbase[tc * 32 + t];
     };
     auto process = [&](const Frag (&f)[K2], float w) {
+        f32x16 D[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            D[r] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[r][v] = __builtin_fmaf(w, __builtin_amdgcn_exp2f(D[v]), acc[r][v]);
+            for (int mm = 0; mm < K2; ++mm) D[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D[r], 0, 0, 0);
         }
+        // all exponentials of the tile first, then the weighted accumulation: no exp -> fma wait states in between
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[r][v] = __builtin_amdgcn_exp2f(D[r][v]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][v] = __builtin_fmaf(w, D[r][v], acc[r][v]);
     };
+    if constexpr (LDS) {
+        // The WPB waves of the workgroup walk the same column tiles: each stage of WPB tiles is fetched ONCE — wave w moves
+        // tile w of the NEXT stage straight from global memory into LDS (global_load_lds_dwordx4: no staging registers; lane
+        // order in LDS = lane order of the packed fragments) while the current stage is read by all waves from the other
+        // buffer — which cuts the L2 -> L1 fragment traffic by WPB.  Two buffers as two distinct arrays (the compiler's
+        // LDS-DMA wait tracking tells them apart), the stage loop unrolled by two, one barrier per stage.
+        __shared__ uint4 sfA[WPB][K2][64], sfB[WPB][K2][64];
+        __shared__ float swA[WPB][32], swB[WPB][32];
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nstage = (nt + WPB - 1) / WPB;
+        float gw;
+#define CG_DMA(stage, SF)                                                                       \
+        {                                                                                       \
+            const int ti_ = (stage) * WPB + wv;                                                 \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
+                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
+            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
+        }
+#define CG_STAGE(SF, SW)                                                                        \
+        _Pragma("unroll 1") for (int k = 0; k < WPB; k += 2) {                                  \
+            Frag f0[K2], f1[K2];                                                                \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
+            const float w0 = SW[k][t];                                                          \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f1[mm].u = SF[k + 1][mm][l];      \
+            const float w1 = SW[k + 1][t];                                                      \
+            process(f0, w0);                                                                    \
+            process(f1, w1);                                                                    \
+        }
+        CG_DMA(0, sfA)
+        if (h == 0) swA[wv][t] = gw;
+        __syncthreads();
+        for (int st = 0; st < nstage; st += 2) {
+            CG_DMA(st + 1 < nstage ? st + 1 : st, sfB)              // past the last stage: a re-fetch nobody reads
+            CG_STAGE(sfA, swA)
+            if (h == 0) swB[wv][t] = gw;
+            __syncthreads();
+            if (st + 1 >= nstage) break;
+            CG_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
+            CG_STAGE(sfB, swB)
+            if (h == 0) swA[wv][t] = gw;
+            __syncthreads();
+        }
+#undef CG_DMA
+#undef CG_STAGE
+    } else {
     Frag f0[K2], f1[K2];
     float w0, w1;
     load_tile(0, f0, w0);
@@ -128,6 +186,7 @@ __global__ __launch_bounds__(64) void dense_mfma_eq_kernel(const float* __restri
         process(f0, w0);
         load_tile(ti + 2, f0, w0);
         if (ti + 1 < nt) process(f1, w1);
+    }
     }
 
     // lane (t, h) owns output row t of each row tile iff bit 2 of t equals h; its register is v = (t & 3) + 4 (t >> 3)
@@ -298,7 +357,9 @@ static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : 
 template <int K2>
 static void launch_mfma(int rt, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
                         float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
-    if (rt == 2)
+    if (rt == 22)
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, (K2 <= 4)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+    else if (rt == 2)
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
@@ -355,9 +416,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
     const dim3 grid((unsigned)rowtiles, (unsigned)js);
     const int fs = js == 1 ? 1 : 0;
+    // long column chunks: four waves of a workgroup share every column tile through LDS (K2 <= 4 instances); short chunks
+    // would only pay its prologue and barriers (tools/c2_pk_ab.py)
+    const bool lds4 = rt == 2 && K2 <= 4 && (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(lds4 ? 22 : rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;

@@ -511,27 +511,30 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
     k = 1.7 * cg.Lengthscale(cg.EQ(), 0.9)
     ko = oracle.Kernel(oracle.EQ, lengthscale=0.9, scale=1.7)
     try:
-        for (n, m) in ((1, 1), (33, 31), (257, 1000), (1500, 700)):
+        for (n, m) in ((1, 1), (33, 31), (257, 1000), (1500, 700), (300, 3000)):
             X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
             a = rng.standard_normal(m).astype(np.float32); y0 = rng.standard_normal(n).astype(np.float32)
             G = cg.gramian(k, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
             ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, np.float32)
             outs = {}
-            for variant, rpl in ((1, 0), (2, 1), (2, 2), (0, 0)):
-                cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl)
+            # (dense_variant, rows_per_lane, mfma_lds, jsplit): mfma_lds = 1 makes four waves share the column tiles through
+            # LDS (d <= 8 instances), jsplit = 3 gives ragged column chunks (stage counts not a multiple of the 4 waves)
+            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, -1, 0), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (0, 0, -1, 0)):
+                cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds); cg.set_option("jsplit", js)
                 yd = torch.from_numpy(y0.copy()).cuda()
                 cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
                 assert cg.get_info("last_dense_path") == (1 if variant == 1 else 2), (variant, d)
-                outs[(variant, rpl)] = yd.cpu().numpy()
-                assert relerr(outs[(variant, rpl)], ref) <= 1e-5, (variant, rpl, d, n, m, relerr(outs[(variant, rpl)], ref))
-            assert relerr(outs[(2, 2)], outs[(1, 0)]) <= 5e-6
+                outs[(variant, rpl, lds, js)] = yd.cpu().numpy()
+                assert relerr(yd.cpu().numpy(), ref) <= 1e-5, (variant, rpl, lds, js, d, n, m, relerr(yd.cpu().numpy(), ref))
+            assert relerr(outs[(2, 2, 0, 0)], outs[(1, 0, -1, 0)]) <= 5e-6
+            assert np.array_equal(outs[(2, 2, 0, 0)], outs[(2, 2, 1, 0)])      # same tiles, same order: bit-identical
             # beta == 0 ignores NaN in y
-            cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", 0)
+            cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
             yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
             cg.mul_(yn, G, torch.from_numpy(a).cuda(), 1.0, 0.0)
             assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, Y, a, 1.0, 0.0, np.float32)) <= 1e-5
     finally:
-        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0)
+        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
 
 
 def test_eq_matrix_core_gate(cg, oracle):
