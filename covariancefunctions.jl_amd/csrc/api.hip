@@ -436,6 +436,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
+    else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -555,10 +556,115 @@ static void choose_split(const covgram_ctx* ctx, int64_t rowblocks, int64_t m, i
     *jsplit = (int)js;
 }
 
+// A composite whose every term is ONE profile (times constants) is a plain Sum (src/algebra.jl:5-14): G = sum_t c_t G_t, so
+// every MVM is the sum of the terms' MVMs, each on its own single-profile path (matrix cores, folded constants, lane-per-row
+// gradient kernel) instead of the per-block interpreter of the composite kernels.  Fills the terms; false = not such a sum.
+// Constant-only terms (k = c: G = c 1 1', src/stationary.jl:27-34) add up in *constant: their MVM is c * sum(a) on every row.
+// Product terms (several profiles) stay composite, one single-term composite each, and run on the interpreter by themselves;
+// when EVERY term is a product the whole composite stays on the interpreter (one pass shares the distances).
+struct SumTerm {
+    bool simple;
+    covgram_kernel k;                     // simple
+    covgram_kernel_composite c;           // product term
+    const covgram_kernel* ptr() const { return simple ? &k : &c.head; }
+};
+static bool composite_sum_terms(const covgram_ctx* ctx, const covgram_kernel* k, int32_t loc, SumTerm* terms, int* nterms,
+                                double* constant) {
+    if (k == nullptr || k->family != COVGRAM_COMPOSITE || ctx->composite_termwise == 0) return false;
+    const covgram_kernel_composite* c = (const covgram_kernel_composite*)k;
+    if (c->nterms < 1 || c->nterms > COVGRAM_COMPOSITE_MAX_TERMS) return false;
+    int nin = 0, nt = 0, nsimple = 0;
+    *constant = 0.0;
+    for (int t = 0; t < c->nterms; ++t) {
+        double coef = c->head.scale;
+        int profiles = 0;
+        SumTerm& st = terms[nt];
+        memset(&st.c, 0, sizeof(st.c));
+        for (int f = 0; f < c->nfactors[t]; ++f, ++nin) {
+            if (nin >= COVGRAM_COMPOSITE_MAX_FACTORS) return false;
+            const covgram_kernel& fk = c->factors[nin];
+            if (fk.family == COVGRAM_CONSTANT) { coef *= fk.scale; continue; }
+            st.c.factors[profiles++] = fk;
+        }
+        if (profiles == 0) { *constant += coef; continue; }
+        st.simple = profiles == 1;
+        if (st.simple) { st.k = st.c.factors[0]; st.k.scale *= coef; ++nsimple; }
+        else {
+            st.c.head = c->head; st.c.head.scale = coef;
+            st.c.nterms = 1; st.c.nfactors[0] = profiles;
+        }
+        ++nt;
+    }
+    if (nt == 0) return false;                                 // a profile term goes first: it applies beta
+    if (nsimple == 0 && *constant == 0.0) return false;        // products only: one interpreter pass
+    if (nsimple == 0 && nt > 1) return false;
+    if (*constant != 0.0 && loc != COVGRAM_DEVICE) return false;   // the constant term works on device vectors only
+    *nterms = nt;
+    return true;
+}
+
+extern "C++" {
+// y[i * ys + r * ldy] += coef * sum_j a[j * as + r * lda]   (as = ys = 1: dense; d + 1: the value row of value-gradient blocks)
+template <typename T>
+__global__ __launch_bounds__(1024) void const_sum_kernel(const T* __restrict__ a, int64_t m, int64_t lda, int64_t as, T* __restrict__ S) {
+    const T* __restrict__ ar = a + (int64_t)blockIdx.x * lda;
+    T s = 0;
+    for (int64_t j = threadIdx.x; j < m; j += 1024) s += ar[j * as];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ T part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T tot = 0;
+        for (int w = 0; w < 16; ++w) tot += part[w];           // fixed order: deterministic
+        S[blockIdx.x] = tot;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void const_add_kernel(T* __restrict__ y, int64_t n, int64_t ldy, int64_t ys, const T* __restrict__ S, T coef) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[(int64_t)blockIdx.y * ldy + i * ys] += coef * S[blockIdx.y];
+}
+}  // extern "C++"
+static int constant_term_mvm(covgram_ctx* ctx, int dtype, const void* a, int64_t m, int64_t lda, int64_t as, void* y, int64_t n, int64_t ldy,
+                             int64_t ys, int nrhs, double coef) {
+    if (n == 0 || m == 0 || coef == 0.0) return COVGRAM_OK;
+    void* S;
+    int rc = ws_reserve(ctx, 0, (size_t)nrhs * 8, &S);
+    if (rc) return rc;
+    const dim3 ag((unsigned)((n + 255) / 256), (unsigned)nrhs);
+    if (dtype == COVGRAM_F32) {
+        hipLaunchKernelGGL(const_sum_kernel<float>, dim3(nrhs), dim3(1024), 0, ctx->stream, (const float*)a, m, lda, as, (float*)S);
+        hipLaunchKernelGGL(const_add_kernel<float>, ag, dim3(256), 0, ctx->stream, (float*)y, n, ldy, ys, (const float*)S, (float)coef);
+    } else {
+        hipLaunchKernelGGL(const_sum_kernel<double>, dim3(nrhs), dim3(1024), 0, ctx->stream, (const double*)a, m, lda, as, (double*)S);
+        hipLaunchKernelGGL(const_add_kernel<double>, ag, dim3(256), 0, ctx->stream, (double*)y, n, ldy, ys, (const double*)S, coef);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("constant-term kernels failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
 int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
                 int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc) {
     int rc = check_pair(ctx, X, Y);
     if (rc) return rc;
+    {
+        SumTerm terms[COVGRAM_COMPOSITE_MAX_TERMS];
+        int nt = 0;
+        double constant = 0.0;
+        if (composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {
+            HostKernel chk;
+            rc = make_host_kernel(k, X->dtype, false, &chk);   // the composite's own validation (traits, limits) still applies
+            if (rc) return rc;
+            for (int t = 0; t < nt; ++t) {
+                rc = covgram_mvm(ctx, terms[t].ptr(), X, Y, a, lda, y, ldy, nrhs, alpha, t == 0 ? beta : 1.0, loc);
+                if (rc) return rc;
+            }
+            return constant_term_mvm(ctx, X->dtype, a, Y->n, lda, 1, y, X->n, ldy, 1, nrhs, alpha * constant);
+        }
+    }
     CG_REQUIRE(nrhs >= 1, COVGRAM_EINVAL, "nrhs must be >= 1");
     const int64_t n = X->n, m = Y->n;
     CG_REQUIRE(lda >= m && ldy >= n, COVGRAM_EINVAL, "DimensionMismatch: lda=%lld < m=%lld or ldy=%lld < n=%lld",
@@ -721,6 +827,23 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
                          void* y, double alpha, double beta, int32_t loc, int vg) {
     int rc = check_pair(ctx, X, Y);
     if (rc) return rc;
+    {
+        SumTerm terms[COVGRAM_COMPOSITE_MAX_TERMS];
+        int nt = 0;
+        double constant = 0.0;
+        if (composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {   // derivatives are linear in the kernel: term by term as well
+            HostKernel chk;
+            rc = make_host_kernel(k, X->dtype, true, &chk);
+            if (rc) return rc;
+            for (int t = 0; t < nt; ++t) {
+                rc = grad_mvm_impl(ctx, terms[t].ptr(), X, Y, a, y, alpha, t == 0 ? beta : 1.0, loc, vg);
+                if (rc) return rc;
+            }
+            // a constant has zero derivatives: only the value-value entry of the value-gradient blocks sees it
+            if (!vg) return COVGRAM_OK;
+            return constant_term_mvm(ctx, X->dtype, a, Y->n, 0, X->d + 1, y, X->n, 0, X->d + 1, 1, alpha * constant);
+        }
+    }
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
     const int bd = d + vg;                                  // entries per block of a and y

@@ -147,6 +147,7 @@ struct covgram_ctx {
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
+    int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;

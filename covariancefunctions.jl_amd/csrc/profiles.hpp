@@ -97,12 +97,13 @@ struct Phi<COVGRAM_IMQ, T, F> {
 template <typename T>
 struct Phi<COVGRAM_MATERNP, T, true> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        // The reference's Taylor branch below eps^(1/p) (src/stationary.jl:135-146) exists for the DERIVATIVES at 0; the value
+        // q(r) exp(-r) has no cancellation there and agrees with the truncated series to << eps at the bound (the first term
+        // the series drops is r^(2p+1) <= eps^(1 + 1/(2p))), so the value-only kernels skip it: s is a sum of squares >= 0.
         T rr = cg_sqrt(s);
         T e = cg_exp2(-rr);
-        T q, t;
-        if (kp.p <= 3) { q = horner3(kp.h0, rr); t = horner3(kp.ty, s); }
-        else { q = horner(kp.h0, kp.p, rr); t = horner(kp.ty, kp.p, s); }
-        return (s < kp.mp_bound) ? t : q * e;
+        T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
+        return q * e;
     }
 };
 template <typename T>

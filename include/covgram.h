@@ -128,7 +128,8 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 /* tuning / A-B knobs: "dense_variant" (0 = auto: fp32 EQ runs on the matrix cores when the norm bound of dense_mfma.hip
  * holds, 1 = always the direct-difference kernel, 2 = matrix cores whenever the shape allows), "rows_per_lane", "jsplit",
  * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused", "mfma_lds" (matrix-core EQ path: four waves share the
- * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8). */
+ * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
+ * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix-core EQ, 3 wide rows), "num_cus". */

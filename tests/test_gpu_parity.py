@@ -416,6 +416,51 @@ def test_composite_kernels_dense_gradient_matrix(cg, oracle, dtype, d):
         assert relerr(bd.cpu().numpy(), ref) <= gtol, (name, d, relerr(bd.cpu().numpy(), ref))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_plain_sums_run_term_by_term(cg, oracle, dtype):
+    """A Sum of single-profile kernels (src/algebra.jl:5-14) is evaluated as one MVM per term on that term's own path
+    (option composite_termwise = 1, the default) — same results as the composite interpreter (= 0) and the oracle, for the
+    dense, gradient and value-gradient Gramians, with alpha / beta (beta applies once, NaNs in y are ignored for beta = 0)."""
+    o = oracle
+    tol = TOL[dtype]; gtol = 3e-5 if dtype == torch.float32 else 1e-12
+    rng = np.random.default_rng(0xC0F + 91)
+    sums = [("iso", 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0) + 0.25 * cg.RQ(1.5) ** 2,
+             o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=0.7, scale=1.5),), (o.Kernel(o.EQ, lengthscale=2.0, scale=0.5),),
+                          (o.Kernel(o.RQ, param=1.5, power=2, scale=0.25),)), o.ISOTROPIC, 1.0)),
+            # constant-only terms (G = c 1 1'): c sum(a) on every row, no derivative entries
+            ("iso_plus_constants", 2.0 * (0.3 + cg.EQ() + 0.5 * cg.Cauchy() + 0.2),
+             o.Composite(((o.Kernel(o.CONSTANT, scale=0.3),), (o.Kernel(o.EQ),), (o.Kernel(o.CAUCHY, scale=0.5),),
+                          (o.Kernel(o.CONSTANT, scale=0.2),)), o.ISOTROPIC, 2.0)),
+            kernel_cases.composite_cases(cg)[2]]
+    for d in (3, 70):
+        n, m = 150, 90
+        X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt(dtype)); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt(dtype))
+        a = rng.standard_normal(m).astype(npdt(dtype)); y0 = rng.standard_normal(n).astype(npdt(dtype))
+        ag = rng.standard_normal(m * d).astype(npdt(dtype)); yg0 = rng.standard_normal(n * d).astype(npdt(dtype))
+        av = rng.standard_normal(m * (d + 1)).astype(npdt(dtype)); A3 = rng.standard_normal((m, 3)).astype(npdt(dtype))
+        Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+        for name, k, ko in sums:
+            want = o.mul(y0, ko, X, Y, a, -0.7, 1.3, npdt(dtype))
+            wantg = o.grad_mul(yg0, ko, X, Y, ag, 0.6, -0.4, npdt(dtype))
+            wantv = o.valgrad_mul(None, ko, X, Y, av, 1.0, 0.0, npdt(dtype))
+            try:
+                for tw in (1, 0):
+                    cg.set_option("composite_termwise", tw)
+                    yd = torch.from_numpy(y0.copy()).cuda()
+                    cg.mul_(yd, cg.gramian(k, Xd, Yd), torch.from_numpy(a).cuda(), -0.7, 1.3)
+                    assert relerr(yd.cpu().numpy(), want) <= tol, (name, d, tw)
+                    got3 = (cg.gramian(k, Xd, Yd) @ torch.from_numpy(A3).cuda()).cpu().numpy()
+                    assert relerr(got3, o.mul(None, ko, X, Y, A3, dtype=npdt(dtype))) <= tol, (name, d, tw)
+                    bd = torch.from_numpy(yg0.copy()).cuda()
+                    cg.mul_(bd, cg.gramian(cg.GradientKernel(k), Xd, Yd), torch.from_numpy(ag).cuda(), 0.6, -0.4)
+                    assert relerr(bd.cpu().numpy(), wantg) <= gtol, (name, d, tw, relerr(bd.cpu().numpy(), wantg))
+                    bv = torch.full((n * (d + 1),), float("nan"), dtype=dtype, device="cuda")
+                    cg.mul_(bv, cg.gramian(cg.ValueGradientKernel(k), Xd, Yd), torch.from_numpy(av).cuda(), 1.0, 0.0)
+                    assert relerr(bv.cpu().numpy(), wantv) <= gtol, (name, d, tw, relerr(bv.cpu().numpy(), wantv))
+            finally:
+                cg.set_option("composite_termwise", 1)
+
+
 def test_composite_golden_and_toeplitz(cg, oracle):
     g = np.load(f"{GOLD}/composite.npz")
     for d in (1, 3, 8):
