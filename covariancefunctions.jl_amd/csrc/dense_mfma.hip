@@ -63,8 +63,10 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     }
 }
 
-template <int K2, int RT, int WPB = 1, bool LDS = false>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ? (K2 <= 2 ? 4 : 3) : 1, LDS ? (K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+// LDS: 0 = every wave loads its own column tiles; 1 = stages of WPB tiles shared through LDS (K2 <= 4, RT = 2);
+//      2 = ONE tile per stage, its K2 fragment slices fetched by the WPB waves in turn (K2 > 4, RT = 1)
+template <int K2, int RT, int WPB = 1, int LDS = 0>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS == 1 ? (K2 <= 2 ? 4 : 3) : 1, LDS == 1 ? (K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
                                                            float alpha, float beta, int32_t final_store, const float* __restrict__ Cn) {
@@ -130,7 +132,55 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ? 
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][v] = __builtin_fmaf(w, D[r][v], acc[r][v]);
     };
-    if constexpr (LDS) {
+    if constexpr (LDS == 2) {
+        // Long fragments (K2 KB per tile): the workgroup stages ONE tile at a time, wave w fetching the fragment slices
+        // mm = w, w + WPB, ... of the NEXT tile (global_load_lds_dwordx4) while all waves stream the CURRENT tile's slices
+        // from the other buffer into their MFMA chain; one barrier per tile (a tile is >= 32 K2 matrix-pipe cycles).
+        static_assert(RT == 1, "split-tile staging is built for one row tile per wave");
+        __shared__ uint4 tfA[K2][64], tfB[K2][64];
+        __shared__ float twA[32], twB[32];
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        float gw = 0.0f;
+#define CG_DMA2(tile, TF)                                                                       \
+        {                                                                                       \
+            const int ti_ = (tile);                                                             \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int q = 0; q < (K2 + WPB - 1) / WPB; ++q) {                  \
+                const int mm = wv + q * WPB;                                                    \
+                if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
+            }                                                                                   \
+            if (wv == 0) gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);                   \
+        }
+#define CG_TILE2(TF, TW)                                                                        \
+        {                                                                                       \
+            f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
+                Frag f; f.u = TF[mm][l];                                                        \
+                D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mm].v, f.v, D, 0, 0, 0);       \
+            }                                                                                   \
+            const float w = TW[t];                                                              \
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]); \
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[0][v] = __builtin_fmaf(w, D[v], acc[0][v]); \
+        }
+        CG_DMA2(0, tfA)
+        if (wv == 0 && h == 0) twA[t] = gw;
+        __syncthreads();
+        for (int ti = 0; ti < nt; ti += 2) {
+            CG_DMA2(ti + 1, tfB)                                    // past the chunk: a re-fetch nobody reads
+            CG_TILE2(tfA, twA)
+            if (wv == 0 && h == 0) twB[t] = gw;
+            __syncthreads();
+            if (ti + 1 >= nt) break;
+            CG_DMA2(ti + 2, tfA)
+            CG_TILE2(tfB, twB)
+            if (wv == 0 && h == 0) twA[t] = gw;
+            __syncthreads();
+        }
+#undef CG_DMA2
+#undef CG_TILE2
+    } else if constexpr (LDS == 1) {
         // The WPB waves of the workgroup walk the same column tiles: each stage of WPB tiles is fetched ONCE — wave w moves
         // tile w of the NEXT stage straight from global memory into LDS (global_load_lds_dwordx4: no staging registers; lane
         // order in LDS = lane order of the packed fragments) while the current stage is read by all waves from the other
@@ -358,7 +408,7 @@ template <int K2>
 static void launch_mfma(int rt, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
                         float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
     if (rt == 22)
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, (K2 <= 4)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (K2 <= 4 ? 2 : 1), 4, (K2 <= 4 ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else if (rt == 2)
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else
@@ -418,7 +468,8 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const int fs = js == 1 ? 1 : 0;
     // long column chunks: four waves of a workgroup share every column tile through LDS (K2 <= 4 instances); short chunks
     // would only pay its prologue and barriers (tools/c2_pk_ab.py)
-    const bool lds4 = rt == 2 && K2 <= 4 && (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
+    const bool lds4 = ((rt == 2 && K2 <= 4) || (rt == 1 && K2 > 4)) &&
+                      (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
 #define CG_MFMA_CASE(K) case K: launch_mfma<K>(lds4 ? 22 : rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;

@@ -548,7 +548,7 @@ def test_value_gradient_golden_and_limits(cg, oracle):
 
 
 # ---- the matrix-core EQ path (dense_mfma.hip) ---------------------------------------------------------------------------
-@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16, 32])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 12, 16, 24, 32])
 def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
     """fp32 EQ: the bf16x3-split MFMA path against the fp64 oracle and against the direct-difference kernel, ragged
     shapes (tile padding on both sides), one and two row tiles per wave, alpha/beta, lengthscale and scale."""
@@ -563,8 +563,9 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
             ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, np.float32)
             outs = {}
             # (dense_variant, rows_per_lane, mfma_lds, jsplit): mfma_lds = 1 makes four waves share the column tiles through
-            # LDS (d <= 8 instances), jsplit = 3 gives ragged column chunks (stage counts not a multiple of the 4 waves)
-            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, -1, 0), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (0, 0, -1, 0)):
+            # LDS (d <= 8 with two row tiles per wave, d > 8 with one), jsplit = 3 gives ragged column chunks (stage counts
+            # not a multiple of the 4 waves / odd tile counts)
+            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 3), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (0, 0, -1, 0)):
                 cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds); cg.set_option("jsplit", js)
                 yd = torch.from_numpy(y0.copy()).cuda()
                 cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
@@ -573,6 +574,7 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
                 assert relerr(yd.cpu().numpy(), ref) <= 1e-5, (variant, rpl, lds, js, d, n, m, relerr(yd.cpu().numpy(), ref))
             assert relerr(outs[(2, 2, 0, 0)], outs[(1, 0, -1, 0)]) <= 5e-6
             assert np.array_equal(outs[(2, 2, 0, 0)], outs[(2, 2, 1, 0)])      # same tiles, same order: bit-identical
+            assert np.array_equal(outs[(2, 1, 0, 0)], outs[(2, 1, 1, 0)])      # (d > 8: one tile per stage, slices split over the waves)
             # beta == 0 ignores NaN in y
             cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
             yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
