@@ -15,11 +15,17 @@ from .gramian import LazyOperator
 
 
 def cg(A: LazyOperator, b: torch.Tensor, x0: Optional[torch.Tensor] = None, reltol: float = 1e-8, abstol: float = 0.0,
-       maxiter: Optional[int] = None, precond=None) -> Tuple[torch.Tensor, dict]:
+       maxiter: Optional[int] = None, precond=None, graph: bool = False, check_every: int = 8) -> Tuple[torch.Tensor, dict]:
     """Solve A x = b for a symmetric positive definite lazy operator A (cg!, IterativeSolvers 0.9.2 semantics:
     stops when ‖r‖ ≤ max(reltol·‖r₀‖, abstol)); `precond(r)` applies an SPD preconditioner M⁻¹ (Pl = M in the reference's
     keyword).  Returns (x, {"iterations", "residual_norm", "converged"}).  All scalars of the recurrence stay on the device;
-    the only host synchronisation per iteration is the convergence test."""
+    the only host synchronisation per iteration is the convergence test.
+
+    graph=True (small, launch-bound systems): one iteration — the MVM's kernels and the vector updates — is captured once
+    into a HIP graph and replayed; the residual is read back only every `check_every` iterations, so the solve may run up
+    to check_every − 1 iterations past the tolerance (they only refine x)."""
+    if graph:
+        return _cg_graph(A, b, x0, reltol, abstol, maxiter, precond, max(1, int(check_every)))
     n = A.shape[0]
     if A.shape[0] != A.shape[1] or b.shape[0] != n:
         raise ValueError("cg: A must be square and match b")
@@ -49,6 +55,60 @@ def cg(A: LazyOperator, b: torch.Tensor, x0: Optional[torch.Tensor] = None, relt
         res = float(torch.linalg.vector_norm(r))
         it += 1
     return x, {"iterations": it, "residual_norm": res, "converged": res <= tol}
+
+
+def _cg_graph(A, b, x0, reltol, abstol, maxiter, precond, check_every):
+    """cg with the iteration body as a replayed HIP graph (torch.cuda.CUDAGraph on ROCm = hipGraph).  The body is warmed up
+    once eagerly (one real iteration: libcovgram sizes its workspaces and fragment caches outside the capture), then captured;
+    every tensor the body touches is persistent, scalars are 0-dim device tensors."""
+    n = A.shape[0]
+    if A.shape[0] != A.shape[1] or b.shape[0] != n:
+        raise ValueError("cg: A must be square and match b")
+    b = b.to(device=A.device, dtype=A.dtype)
+    x = torch.zeros_like(b) if x0 is None else x0.to(device=A.device, dtype=A.dtype).clone()
+    r = b.clone()
+    Ap = torch.empty_like(b)
+    if x0 is not None:
+        A.mul_(Ap, x)
+        r -= Ap
+    z = precond(r) if precond is not None else r
+    p = z.clone()
+    rz = torch.dot(r, z).clone()
+    res = torch.linalg.vector_norm(r).clone()
+    r0 = float(res)
+    tol = max(reltol * r0, abstol)
+    maxiter = n if maxiter is None else maxiter
+    it = 0
+    if not (r0 > tol) or maxiter <= 0:
+        return x, {"iterations": 0, "residual_norm": r0, "converged": r0 <= tol}
+
+    def body():
+        A.mul_(Ap, p)
+        alpha = rz / torch.dot(p, Ap)
+        x.addcmul_(p, alpha)
+        r.addcmul_(Ap, -alpha)
+        zz = precond(r) if precond is not None else r
+        rz_new = torch.dot(r, zz)
+        p.mul_(rz_new / rz).add_(zz)
+        rz.copy_(rz_new)
+        res.copy_(torch.linalg.vector_norm(r))
+
+    side = torch.cuda.Stream(device=A.device)
+    side.wait_stream(torch.cuda.current_stream(A.device))
+    with torch.cuda.stream(side):
+        body(); it += 1                                    # eager warm-up = iteration 1 (on the capture stream)
+    torch.cuda.current_stream(A.device).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        body()
+    resf = float(res)
+    while it < maxiter and resf > tol:
+        k = min(check_every, maxiter - it)
+        for _ in range(k):
+            g.replay()
+        it += k
+        resf = float(res)
+    return x, {"iterations": it, "residual_norm": resf, "converged": resf <= tol, "graph": True}
 
 
 def solve(A: LazyOperator, b: torch.Tensor, **kw) -> torch.Tensor:

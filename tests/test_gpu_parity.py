@@ -288,6 +288,14 @@ def test_cg_solve_through_the_hot_path(cg, oracle):
     assert info["converged"]
     M = oracle.matrix(oracle.Kernel(oracle.MATERNP, p=2), X) + 1e-2 * np.eye(400)
     assert relerr(x.cpu().numpy(), np.linalg.solve(M, bvec.cpu().numpy())) < 1e-7
+    # the same solve with the iteration body replayed as a HIP graph (residual read back every 4 iterations), also
+    # with a preconditioner and a start vector
+    xg, ig = cg.cg(S, bvec, reltol=1e-10, graph=True, check_every=4)
+    assert ig["converged"] and ig["graph"] and info["iterations"] <= ig["iterations"] < info["iterations"] + 5
+    assert relerr(xg.cpu().numpy(), np.linalg.solve(M, bvec.cpu().numpy())) < 1e-7
+    dinv = 1.0 / torch.from_numpy(np.diag(M).copy()).cuda()
+    xg2, ig2 = cg.cg(S, bvec, x0=0.5 * xg, reltol=1e-10, graph=True, precond=lambda r: dinv * r)
+    assert ig2["converged"] and relerr(xg2.cpu().numpy(), np.linalg.solve(M, bvec.cpu().numpy())) < 1e-7
     n, d = 16, 3
     Xg = rng.standard_normal((n, d)) / np.sqrt(d)
     K = cg.gramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(Xg).cuda())
