@@ -405,9 +405,9 @@ template <int K2>
 static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : mfma_blocks_per_cu<K2, 1>(); }
 
 template <int K2>
-static void launch_mfma(int rt, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
+static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
                         float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
-    if (rt == 22)
+    if (lds4)   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (K2 <= 4 ? 2 : 1), 4, (K2 <= 4 ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else if (rt == 2)
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
@@ -467,12 +467,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const dim3 grid((unsigned)rowtiles, (unsigned)js);
     const int fs = js == 1 ? 1 : 0;
     // long column chunks: four waves of a workgroup share every column tile through LDS (K2 <= 4 instances); short chunks
-    // would only pay its prologue and barriers (tools/c2_pk_ab.py)
+    // would only pay its prologue and barriers (tools/mfma_lds_ab.py)
     const bool lds4 = ((rt == 2 && K2 <= 4) || (rt == 1 && K2 > 4)) &&
                       (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(lds4 ? 22 : rt, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
