@@ -445,6 +445,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     CG_REQUIRE(ctx && key && value, COVGRAM_EINVAL, "NULL argument");
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
+    else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else { set_error("unknown info key '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;

@@ -154,6 +154,7 @@ struct covgram_ctx {
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
+    int64_t last_mfma_lds = 0;   // the last matrix-core EQ MVM shared its column tiles through LDS
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
     int64_t time_kernels = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;

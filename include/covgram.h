@@ -132,7 +132,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
- * 2 matrix-core EQ, 3 wide rows), "num_cus". */
+ * 2 matrix-core EQ, 3 wide rows), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "num_cus". */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
 /* With option "time_kernels" = 1 every dense / gradient MVM brackets its dominant kernel with HIP events on the

@@ -592,6 +592,32 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
         cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
 
 
+@pytest.mark.parametrize("d", [3, 7, 20])
+def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
+    """Shapes at which the library itself turns on the LDS-shared column tiles (long column chunks, >= 64 row tiles): ragged
+    n and m, row blocks of 256 / 128 rows that end past n; checked on the first, last and some middle rows against the fp64
+    oracle, and bit-for-bit against the one-wave-per-workgroup kernel."""
+    rng = np.random.default_rng(400 + d)
+    n, m = 20011, 131072 - 37
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    a = rng.standard_normal(m).astype(np.float32)
+    G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.8), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+    ad = torch.from_numpy(a).cuda()
+    try:
+        cg.set_option("mfma_lds", 0); b0 = (G @ ad).cpu().numpy()
+        assert cg.get_info("last_mfma_lds") == 0
+        cg.set_option("mfma_lds", -1); b1 = (G @ ad).cpu().numpy()
+        assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_lds") == 1
+        cg.set_option("mfma_lds", 1); b2 = (G @ ad).cpu().numpy()
+    finally:
+        cg.set_option("mfma_lds", -1)
+    rows = np.r_[0:40, n // 2:n // 2 + 40, n - 40:n]
+    want = oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.8), X[rows], Y, a, dtype=np.float32)
+    assert relerr(b1[rows], want) <= 1e-5
+    assert np.array_equal(b0, b1) and np.array_equal(b1, b2)
+    assert np.isfinite(b1).all()
+
+
 def test_eq_matrix_core_gate(cg, oracle):
     """The expanded exponent is only used while max|x~| max|y~| <= 128, x~ = (x - c) / l relative to the set's own centre c
     (its first point): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
