@@ -137,6 +137,7 @@ def main():
     kernel_ms, launches = cg.kernel_time()
     cg.set_option("time_kernels", 0)
     dense_path = cg.get_info("last_dense_path")
+    sym_path = cg.get_info("last_mfma_sym") == 1
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
@@ -165,14 +166,35 @@ def main():
         kern_s = kern_avg_ms * 1e-3
         achieved_tflops = flops_launch / kern_s * 1e-12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_dense_mfma_pmc.json" if dense_path == 2 else "r01_dense_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", ("r01_dense_mfma_sym_pmc.json" if sym_path else "r01_dense_mfma_pmc.json") if dense_path == 2
+                           else "r01_dense_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # which kernel ran (the library picks the matrix-core EQ path when its norm bound holds)
-        if dense_path == 2:
+        evaluated_pairs = float(n_local) * m
+        if dense_path == 2 and sym_path:
+            # gramian(k, x) on one GPU: tiles on / above the diagonal are evaluated once and feed row AND column sums
+            evaluated_pairs = float(n) * (n + 32) / 2
+            # this algorithm's own work: per evaluated pair the reference's 3d+3 flops + the second weighted sum
+            flops_launch = evaluated_pairs * (3 * d + 3 + 2)
+            achieved_tflops = flops_launch / kern_s * 1e-12
+            kname = ("covgram::dense_mfma_eq_sym_kernel<K2=2> (upper triangle only: bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+                     "2 v_fma_f32 per EVALUATED pair, each evaluated pair serves the entries (i,j) and (j,i); 8 waves share each column "
+                     "tile through LDS)")
+            ceiling = 1024 * 2.4e9 * 64 / 12.0     # evaluated pairs/s: 1 v_exp_f32 (8 cyc) + 2 v_fma_f32 (2 cyc each) per 64 pairs per SIMD
+            note = ("FP32 VALU + transcendental issue bound. The Gramian of one point set is symmetric: every 32x32 tile on or above the "
+                    "diagonal is evaluated once (distance on the bf16 matrix pipe, three-way split) and used for the row sums and — "
+                    "strictly above the diagonal — for the column sums, so one MVM costs n(n+32)/2 exponentials instead of n^2 "
+                    "(the reference evaluates all n^2, src/gramian.jl:78-87). 'achieved' counts THIS algorithm's flops: evaluated pairs x "
+                    "(3d+3 of SURVEY.md \u00a78d + 2 for the second weighted sum) over the measured kernel time; 'reference_algorithm_tflops' "
+                    "is the reference's n^2 x (3d+3) over the same time (what the caller gets). 'issue_roofline_frac' prices the executed VALU stream: "
+                    "evaluated pairs/s against 1 v_exp_f32 (8 issue cycles) + 2 v_fma_f32 (2 each) per 64 evaluated pairs per SIMD at "
+                    "2.4 GHz (1.31e13/s); SQ counters show the VALU ~100% busy at the ~1.85 GHz the chip sustains "
+                    "(profiles/r01_mfma_eq_counters.txt). 'hbm' does not bound this kernel.")
+        elif dense_path == 2:
             kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=4, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
                      "1 v_fma_f32 per pair; 4 waves share each column tile through LDS)")
             ceiling = 1024 * 2.4e9 * 64 / 10.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (2 cyc) per 64 pairs per SIMD
@@ -194,7 +216,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "EQ dense Gramian mul!, d=3 n=131072 fp32 (BASELINE.json configs[1]); x ~ N(0, I_3), a ~ N(0,1), "
-                                   "alpha=1, beta=0, y == x, symmetry not exploited; points/a/b resident in HBM",
+                                   "alpha=1, beta=0, y == x" + ("; the single-GPU kernel evaluates the upper triangle once" if sym_path else "; all n*m entries evaluated (row shards are not symmetric)") + "; points/a/b resident in HBM",
                        "n": n, "d": d, "kernel": "EQ", "pairs_per_mvm": float(n) * m,
                        "parallelism": "1 GPU" if world == 1 else f"row-shard x{world} + 1 RCCL all-gather of b per MVM"},
             "pairs_per_s": mvms * float(n) * m,
@@ -207,7 +229,9 @@ def main():
                 "kernel_avg_ms": kern_avg_ms, "launches": int(launches),
                 "algorithmic_flops_per_launch": flops_launch,
                 "note": note,
-                "issue_roofline_frac": (float(n_local) * m / kern_s) / ceiling,
+                "reference_algorithm_tflops": float(n_local) * m * (3 * d + 3) / kern_s * 1e-12,
+                "issue_roofline_frac": (evaluated_pairs / kern_s) / ceiling,
+                "evaluated_pairs_per_launch": evaluated_pairs,
                 "hbm_algorithmic_bytes_per_launch": bytes_launch,
                 "hbm_achieved_GBps": bytes_launch / kern_s * 1e-9,
                 "hbm_frac": bytes_launch / kern_s * 1e-9 / HBM_PEAK_GBPS,

@@ -436,6 +436,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
+    else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
@@ -446,6 +447,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     CG_REQUIRE(ctx && key && value, COVGRAM_EINVAL, "NULL argument");
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
+    else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else { set_error("unknown info key '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -708,7 +710,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // isotropic kernels work relative to the column side's centre (common.hpp: covgram_points::center)
     const void* Cn = (hk.k.trait == COVGRAM_ISOTROPIC) ? Y->center : nullptr;
     bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
-    if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
+    const bool sym = mfma && mfma_eq_sym_eligible(ctx, hk, X, Y, nrhs);
+    ctx->last_mfma_sym = sym ? 1 : 0;
+    if (sym) { rc = mvm_eq_mfma_sym(ctx, hk, X, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
+    else if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
         mfma = true;
         rc = mvm_mfma_gen(ctx, k, X, Y, (const float*)a_dev, lda_d, (float*)y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;

@@ -148,12 +148,14 @@ struct covgram_ctx {
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
+    int64_t mfma_sym = -1;       // matrix-core EQ path on gramian(k, x): evaluate the upper triangle once (-1 auto, 0 never, 1 always)
     int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
+    int64_t last_mfma_sym = 0;   // the last dense MVM ran the symmetric (upper-triangle) matrix-core kernel
     int64_t last_mfma_lds = 0;   // the last matrix-core EQ MVM shared its column tiles through LDS
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
     int64_t time_kernels = 0;
@@ -232,12 +234,15 @@ grad_launch_fn grad_launcher(int family);
 // measured contribution to the MVM's 2-norm relative error ~4e-9 P (C2: P = 40, +0.7e-7; P = 125: 5e-7, tests), against
 // the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is ~1.7e-7 P per entry.
 constexpr int MFMA_LDS_MIN_TILES = 64;
+constexpr int64_t MFMA_SYM_MIN_N = 40000;
 constexpr double MFMA_GATE = 128.0;
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,
                 double alpha, double beta);
 // the other smooth fp32 profiles, dot-product kernels and several right-hand sides (dense_mfma.hpp)
+bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
+int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta);
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);

@@ -489,6 +489,258 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Symmetric Gramian (gramian(k, x): y IS x): every tile on or above the diagonal is evaluated ONCE and used twice,
+//     b_i += e_i sum_j (a_j e_j) E_ij          (row sums, as dense_mfma_eq_kernel)
+//     b_j += e_j sum_i (a_i e_i) E_ij          (column sums of the same exponentials, tiles strictly above the diagonal)
+// with E_ij = exp2(x~_i . x~_j), e_i = exp2(-|x~_i|^2 / 2): one v_exp_f32 and TWO v_fma_f32 per evaluated pair, i.e. 6 VALU
+// issue cycles per Gramian entry instead of 10, and half the MFMAs.  The reference evaluates all n^2 entries
+// (src/gramian.jl:78-87 does not look at issymmetric); the sums are the same numbers in a different order.
+//
+// Work decomposition: a workgroup = 8 waves x 1 row tile = a PANEL of 256 rows; workgroup (p, c) walks the column tiles
+// [max(8 p, c tchunk), (c + 1) tchunk) — everything from the panel's own first tile to the right — with the LDS staging
+// of the non-symmetric kernel.  Inside the panel's diagonal block the tiles below the diagonal are masked (weight 0 for
+// the row sums of tiles J < I, for the column sums of tiles J <= I): < 0.5 % wasted work.  Row sums leave through the
+// per-chunk slab R[c][i]; the column sums of a tile are added over the 8 waves in LDS in fixed order and stored to
+// S[p][j] (each (p, tile) exactly once); dense_mfma_sym_reduce_kernel adds R over the panel's chunks and S over the panels
+// p <= panel(j) in fixed order: deterministic, no float atomics.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int K2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_eq_sym_kernel(
+    const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
+    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn) {
+    // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
+    // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
+    constexpr int NW = 8, ST = (K2 <= 2) ? 8 : 4;
+    // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
+    // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
+    // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
+    const int64_t p = blockIdx.x;
+    const int64_t T1a = ((int64_t)blockIdx.y + 1) * tchunk;
+    if (T1a <= NW * p) return;                                     // chunk entirely left of the panel (whole workgroup, before any barrier)
+    const int64_t T0 = ((int64_t)blockIdx.y * tchunk > NW * p) ? (int64_t)blockIdx.y * tchunk : NW * p;
+    if (T0 >= ntile) return;
+    const int64_t T1 = T1a < ntile ? T1a : ntile;
+    const int nt = (int)(T1 - T0);
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t I0 = NW * p + wv;                                // this wave's row tile
+    const int64_t i0 = I0 * 32;
+    Frag a[K2];
+    float nx;
+    float u[16];                                                   // a_i e_i of the 16 rows this lane's accumulators belong to
+    {
+        int64_t row = i0 + t;
+        if (row >= n) row = n - 1;                                 // clamp: computed, never stored, weight 0 below
+        const float* __restrict__ xr = X + row * (int64_t)d;
+        float part = 0.0f;
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) {
+            const int c = 2 * mm + h;
+            const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
+            part = __builtin_fmaf(xt, xt, part);
+            unsigned x1, x2, x3;
+            split3(xt, x1, x2, x3);
+            a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+        }
+        nx = part + __shfl_xor(part, 32);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {                             // MFMA 32x32 output: register v of half h is row 8 (v / 4) + 4 h + v % 4
+            int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
+            const float keep = ri < n ? 1.0f : 0.0f;
+            if (ri >= n) ri = n - 1;
+            u[v] = W[ri] * keep;
+        }
+    }
+    float acc[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+
+    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
+    const float* __restrict__ wbase = W + T0 * 32;
+    __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
+    __shared__ float swA[ST][32], swB[ST][32];
+    __shared__ float csA[NW][ST][32], csB[NW][ST][32];             // [wave][tile of the stage][column]: column sums per wave
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int nstage = (nt + ST - 1) / ST;
+    float gw = 0.0f;
+    // one tile: E once, row sums with the column weight w (masked below the diagonal), column sums with the row weights u
+    auto process = [&](const Frag (&f)[K2], float w, int64_t J, float& cpart) {
+        f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]);
+        const float wr = (J >= I0) ? w : 0.0f;                     // wave-uniform masks: only inside the diagonal block
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; v += 4) {
+            acc[v] = __builtin_fmaf(wr, D[v], acc[v]);
+            acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);
+            acc[v + 2] = __builtin_fmaf(wr, D[v + 2], acc[v + 2]);
+            acc[v + 3] = __builtin_fmaf(wr, D[v + 3], acc[v + 3]);
+            c0 = __builtin_fmaf(u[v], D[v], c0);
+            c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);
+            c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
+            c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
+        }
+        cpart = (J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;
+        cpart += __shfl_xor(cpart, 32);                            // the other 16 rows of the tile live in the other half-wave
+    };
+#define CG_DMA(stage, SF)                                                                       \
+        if (wv < ST) {                                                                          \
+            const int ti_ = (stage) * ST + wv;                                                  \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
+                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
+            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
+        }
+#define CG_STAGE(st_, SF, SW, CS)                                                               \
+        _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
+            Frag f0[K2], f1[K2];                                                                \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
+            const float w0 = SW[k][t];                                                          \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f1[mm].u = SF[k + 1][mm][l];      \
+            const float w1 = SW[k + 1][t];                                                      \
+            float cp0, cp1;                                                                     \
+            process(f0, w0, T0 + (int64_t)(st_) * ST + k, cp0);                                 \
+            process(f1, w1, T0 + (int64_t)(st_) * ST + k + 1, cp1);                             \
+            if (h == 0) { CS[wv][k][t] = cp0; CS[wv][k + 1][t] = cp1; }                         \
+        }
+    // after the stage's barrier: wave w < ST adds the eight waves' column sums of tile w of that stage (fixed order), stores them
+#define CG_FLUSH(st_, CS)                                                                       \
+        if (wv < ST) {                                                                          \
+            const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
+            if (h == 0 && J_ < T1)                                                              \
+                S[p * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
+                                            ((CS[4][wv][t] + CS[5][wv][t]) + (CS[6][wv][t] + CS[7][wv][t]));    \
+        }
+    CG_DMA(0, sfA)
+    if (wv < ST && h == 0) swA[wv][t] = gw;
+    __syncthreads();
+    for (int st = 0; st < nstage; st += 2) {
+        CG_DMA(st + 1 < nstage ? st + 1 : st, sfB)                  // past the last stage: a re-fetch nobody reads
+        if (st > 0) CG_FLUSH(st - 1, csB)
+        CG_STAGE(st, sfA, swA, csA)
+        if (wv < ST && h == 0) swB[wv][t] = gw;
+        __syncthreads();
+        if (st + 1 >= nstage) { CG_FLUSH(st, csA) break; }
+        CG_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
+        CG_FLUSH(st, csA)
+        CG_STAGE(st + 1, sfB, swB, csB)
+        if (wv < ST && h == 0) swA[wv][t] = gw;
+        __syncthreads();
+        if (st + 2 >= nstage) { CG_FLUSH(st + 1, csB) }
+    }
+#undef CG_DMA
+#undef CG_STAGE
+#undef CG_FLUSH
+
+    const int vsel = (t & 3) + 4 * (t >> 3);
+    float tot = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float s = acc[v];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+        tot = (vsel == v) ? s : tot;
+    }
+    const int64_t i = i0 + t;
+    if (((t >> 2) & 1) != h || i >= n) return;
+    R[(int64_t)blockIdx.y * npad + i] = __builtin_amdgcn_exp2f(-0.5f * nx) * tot;
+}
+
+// b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order.
+// 64 rows per workgroup, the panel index strided over the 4 waves (as dense_reduce_kernel).
+__global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
+                                                                    const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
+                                                                    float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
+                                                                    float beta) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ float red[4][64];
+    float s = 0.0f;
+    if (i < n) {
+        const int64_t pi = i >> 8;                                                   // the row's panel (256 rows)
+        for (int64_t p = part; p <= pi; p += 4) s += S[p * npad + i];
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    const float cs = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int64_t pi = i >> 8;
+    const int64_t cfirst = (8 * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
+    float rs = 0.0f;
+    for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
+    float ni = 0.0f;
+    for (int c = 0; c < d; ++c) { const float xc = g * (X[i * (int64_t)d + c] - Cn[c]); ni = __builtin_fmaf(xc, xc, ni); }
+    float v = alpha * __builtin_fmaf(__builtin_amdgcn_exp2f(-0.5f * ni), cs, rs);
+    if (beta != 0.0f) v = __builtin_fmaf(beta, y[i], v);
+    y[i] = v;
+}
+
+bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
+    if (ctx->mfma_sym == 0 || X->dptr != Y->dptr || X->n != Y->n) return false;       // gramian(k, x): the same point set on both sides
+    if (!mfma_eq_eligible(ctx, hk, X, Y, nrhs) || X->d > 8) return false;
+    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + 7) / 8;
+    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)2 << 30)) return false;   // column-sum slab <= 2 GiB
+    return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
+}
+
+// y <- alpha * scale * G a + beta * y for the symmetric Gramian of ONE point set and one right-hand side
+int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta) {
+    const int64_t n = X->n;
+    const int d = X->d;
+    const int D = pad_dim(d);
+    const int K2 = (D + 1) / 2;
+    const int64_t ntile = (n + 31) / 32, panels = (ntile + 7) / 8, npad = panels * 256;
+    const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
+    const float* Cn = (const float*)X->center;
+    const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
+    void* Wp;
+    int rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
+    if (rc) return rc;
+    float* W = (float*)Wp;
+    if (X->frag_cache == nullptr || X->frag_bytes != fbytes || X->frag_g != g || X->frag_k2 != K2) {
+        if (X->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(X->frag_cache); X->frag_cache = nullptr; }
+        hipError_t me = hipMalloc(&X->frag_cache, fbytes);
+        if (me != hipSuccess) { X->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
+        X->frag_bytes = fbytes; X->frag_g = g; X->frag_k2 = K2;
+        const int64_t pe = ntile * K2 * 64;
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
+                           (uint4*)X->frag_cache, W, K2, g, Cn);
+    } else {
+        hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a, W,
+                           ntile * 32, g, Cn);
+    }
+    // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
+    const int64_t tileops = panels * ntile / 2 + panels * 4;                     // (panel, tile) visits
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 2 * 8;
+    int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
+    tchunk = std::max<int64_t>(32, std::min<int64_t>(((tchunk + 7) / 8) * 8, 1024));
+    const int64_t maxc = (ntile + tchunk - 1) / tchunk;
+    void *Rp, *Sp;
+    rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
+    rc = ws_reserve(ctx, 4, (size_t)panels * npad * sizeof(float), &Sp); if (rc) return rc;
+    const double alpha_eff = alpha * hk.kp.scale;
+    const dim3 grid((unsigned)panels, (unsigned)maxc);
+    auto* tm = timer_next(ctx);
+    if (tm) (void)hipEventRecord(tm->first, ctx->stream);
+#define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_eq_sym_kernel<K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn); break;
+    switch (K2) {
+        CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
+        default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
+    }
+#undef CG_SYM_CASE
+    if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d,
+                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // generic profiles / several right-hand sides (dense_mfma.hpp)
 // ------------------------------------------------------------------------------------------------------------------------
 #define CG_DECL(n) int launch_mfma_family_##n(const MfmaArgs&, bool query);

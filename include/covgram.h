@@ -129,10 +129,13 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * holds, 1 = always the direct-difference kernel, 2 = matrix cores whenever the shape allows), "rows_per_lane", "jsplit",
  * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused", "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
+ * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
+ * -1 = from n = 40000, 0 = never, 1 = always),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
- * 2 matrix-core EQ, 3 wide rows), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "num_cus". */
+ * 2 matrix-core EQ, 3 wide rows), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
+ * MVM ran the symmetric upper-triangle kernel), "num_cus". */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
 /* With option "time_kernels" = 1 every dense / gradient MVM brackets its dominant kernel with HIP events on the

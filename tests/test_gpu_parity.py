@@ -618,6 +618,55 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
     assert np.isfinite(b1).all()
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8])
+def test_eq_symmetric_matrix_core_kernel(cg, oracle, d):
+    """gramian(EQ, x) on the matrix cores with the upper triangle evaluated once (row sums + column sums of the same tiles,
+    mfma_sym = 1): ragged n (row tiles, 256-row panels and 4/8-tile stages all end past n), ragged column chunks (jsplit),
+    alpha / beta, NaN in y with beta = 0, against the fp64 oracle and against the full kernel; a Gramian of two different
+    point sets never takes it."""
+    rng = np.random.default_rng(900 + d)
+    k = 1.3 * cg.Lengthscale(cg.EQ(), 0.9)
+    ko = oracle.Kernel(oracle.EQ, lengthscale=0.9, scale=1.3)
+    try:
+        for n in (1, 31, 33, 257, 1000, 2309):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+            a = rng.standard_normal(n).astype(np.float32); y0 = rng.standard_normal(n).astype(np.float32)
+            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+            G = cg.gramian(k, Xd)
+            ref = oracle.mul(y0, ko, X, X, a, -0.7, 1.3, np.float32)
+            cg.set_option("mfma_sym", 0)
+            yf = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yf, G, ad, -0.7, 1.3)
+            assert cg.get_info("last_mfma_sym") == 0
+            for js in (0, 1, 3):
+                cg.set_option("mfma_sym", 1); cg.set_option("jsplit", js)
+                ys = torch.from_numpy(y0.copy()).cuda(); cg.mul_(ys, G, ad, -0.7, 1.3)
+                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 1
+                assert relerr(ys.cpu().numpy(), ref) <= 1e-5, (d, n, js, relerr(ys.cpu().numpy(), ref))
+                assert relerr(ys.cpu().numpy(), yf.cpu().numpy()) <= 5e-6
+            cg.set_option("jsplit", 0)
+            yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+            cg.mul_(yn, G, ad, 1.0, 0.0)
+            assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, X, a, 1.0, 0.0, np.float32)) <= 1e-5
+            # two point sets (even equal values in different buffers): the general kernel
+            G2 = cg.gramian(k, Xd, Xd.clone()); (G2 @ ad)
+            assert cg.get_info("last_mfma_sym") == 0
+    finally:
+        cg.set_option("mfma_sym", -1); cg.set_option("jsplit", 0)
+
+
+def test_eq_symmetric_kernel_at_size(cg, oracle):
+    """The size at which the library picks the symmetric kernel by itself (n >= 40000): sampled rows against the oracle."""
+    rng = np.random.default_rng(77)
+    n, d = 50021, 3
+    X = rng.standard_normal((n, d)).astype(np.float32); a = rng.standard_normal(n).astype(np.float32)
+    G = cg.gramian(cg.EQ(), torch.from_numpy(X).cuda())
+    b = (G @ torch.from_numpy(a).cuda()).cpu().numpy()
+    assert cg.get_info("last_mfma_sym") == 1
+    rows = np.r_[0:50, n // 2:n // 2 + 50, n - 50:n]
+    assert relerr(b[rows], oracle.mul(None, oracle.Kernel(oracle.EQ), X[rows], X, a, dtype=np.float32)) <= 1e-5
+    assert np.isfinite(b).all()
+
+
 def test_eq_matrix_core_gate(cg, oracle):
     """The expanded exponent is only used while max|x~| max|y~| <= 128, x~ = (x - c) / l relative to the set's own centre c
     (its first point): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
