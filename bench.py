@@ -177,7 +177,7 @@ def main():
         evaluated_pairs = float(n_local) * m
         if dense_path == 2 and sym_path:
             # gramian(k, x) on one GPU: tiles on / above the diagonal are evaluated once and feed row AND column sums
-            evaluated_pairs = float(n) * (n + 32) / 2
+            evaluated_pairs = float(n) * (n + 32) / 2 / world       # per rank: cyclic panels of the triangle
             # this algorithm's own work: per evaluated pair the reference's 3d+3 flops + the second weighted sum
             flops_launch = evaluated_pairs * (3 * d + 3 + 2)
             achieved_tflops = flops_launch / kern_s * 1e-12
@@ -216,9 +216,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "EQ dense Gramian mul!, d=3 n=131072 fp32 (BASELINE.json configs[1]); x ~ N(0, I_3), a ~ N(0,1), "
-                                   "alpha=1, beta=0, y == x" + ("; the single-GPU kernel evaluates the upper triangle once" if sym_path else "; all n*m entries evaluated (row shards are not symmetric)") + "; points/a/b resident in HBM",
+                                   "alpha=1, beta=0, y == x" + ("; the upper triangle is evaluated once" if sym_path else "; all n*m entries evaluated") + "; points/a/b resident in HBM",
                        "n": n, "d": d, "kernel": "EQ", "pairs_per_mvm": float(n) * m,
-                       "parallelism": "1 GPU" if world == 1 else f"row-shard x{world} + 1 RCCL all-gather of b per MVM"},
+                       "parallelism": "1 GPU" if world == 1 else (
+                           f"upper triangle by cyclic 256-row panels x{world} + 1 RCCL all-reduce of b per MVM" if sym_path
+                           else f"row-shard x{world} + 1 RCCL all-gather of b per MVM")},
             "pairs_per_s": mvms * float(n) * m,
             "rel_err_vs_fp64_oracle": rel_err,
             "roofline": {

@@ -95,6 +95,8 @@ PROTOTYPES = {
     "covgram_matrix": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _I32]),
     "covgram_grad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
     "covgram_valgrad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
+    "covgram_mvm_sym_supported": (C.c_int, [_P, _KP, _P, C.POINTER(C.c_int32)]),
+    "covgram_mvm_sym_partial": (C.c_int, [_P, _KP, _P, _P, _P, _I32, _I32]),
     "covgram_toeplitz_create": (C.c_int, [_P, C.POINTER(_P), _P, _P, _I64, _I64, _I32, _I32, _I32]),
     "covgram_toeplitz_mvm": (C.c_int, [_P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_destroy": (C.c_int, [_P]),

@@ -6,6 +6,12 @@ with the single-GPU kernel, and ONE all-gather (RCCL over xGMI; torch.distribute
 complete on every rank — which is exactly the replicated `a` the next Krylov iteration needs.  There is
 no other exchange.  Shards are padded to ceil(n/P) rows so the collective is a single
 all_gather_into_tensor of equal pieces.
+
+Symmetric form (gramian(k, x), vectors, where the library's symmetric matrix-core kernel applies — fp32 EQ): the n(n+1)/2
+unordered pairs are independent too, so rank g evaluates the upper-triangle tiles of the 256-row panels p ≡ g (mod P) — a
+cyclic assignment that gives every rank the same share of the triangle — and produces the partial product of those entries
+and their mirror images (covgram_mvm_sym_partial); ONE all-reduce (sum) completes b on every rank.  Half the kernel
+evaluations of the row-sharded form for one n-vector all-reduce instead of the all-gather.
 """
 from __future__ import annotations
 
@@ -13,6 +19,12 @@ from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+# The symmetric form pays from ~4e9 evaluated pairs per rank (tools/sym_shard_probe.py, n = 131072: 707 vs 785 us per rank at
+# P = 2, a tie at P = 4, 260 vs 238 us at P = 8 — its 8-wave workgroups have a heavier prologue than the general kernel's, which
+# short column chunks do not amortise — and its all-reduce moves n scalars per rank where the all-gather moves n / P).
+SYM_MIN_PAIRS_PER_RANK = 4.0e9
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -29,7 +41,8 @@ class ShardedGramian:
     `local_factory(k, x_rows, y)` builds the local operator; by default the device `gramian`.  (The CPU
     multi-process tests inject a factory so that the sharding + collective logic runs under gloo.)"""
 
-    def __init__(self, k, x, y=None, group=None, local_factory: Optional[Callable] = None, block: Optional[int] = None):
+    def __init__(self, k, x, y=None, group=None, local_factory: Optional[Callable] = None, block: Optional[int] = None,
+                 sym_partial_factory: Optional[Callable] = None, symmetric: Optional[bool] = None):
         """block: entries per point of the flat vectors — 1 for scalar kernels, d for GradientKernel, d + 1 for
         ValueGradientKernel Gramians (inferred from the kernel when not given): rank g then owns the rows
         [lo_g * block, hi_g * block) of the flat output and the all-gather moves ceil(n/P) * block entries per rank."""
@@ -41,6 +54,7 @@ class ShardedGramian:
         self.lo, self.hi = shard_bounds(self.n, self.world, self.rank)
         y_full = x if y is None else y
         self.m = y_full.shape[0]
+        local_factory_is_default = local_factory is None
         if local_factory is None:
             from .gramian import gramian as local_factory
         x_rows = x[self.lo:self.hi]
@@ -56,6 +70,18 @@ class ShardedGramian:
         self.shape = (self.n * self.block, self.m * self.block)
         # exercise the collective even on one rank (used to validate the RCCL path on single-GPU boxes)
         self.force_collective = bool(int(__import__("os").environ.get("COVGRAM_FORCE_COLLECTIVE", "0"))) and dist.is_initialized()
+        # symmetric form: `sym_partial(out, a, rank, world)` fills out with this rank's partial product.  By default the
+        # device Gramian's own method when it says the symmetric kernel applies (the answer depends on k and x only, so all
+        # ranks agree); the CPU multi-process tests inject a factory.  symmetric=False forces row shards.
+        self.sym_partial = None
+        if symmetric is not False and y is None and self.block == 1 and (self.world > 1 or self.force_collective):
+            if sym_partial_factory is not None:
+                self.sym_partial = sym_partial_factory(k, x)
+            elif local_factory_is_default and (symmetric is True or self.n * (self.n / 2.0) / self.world >= SYM_MIN_PAIRS_PER_RANK):
+                full = local_factory(k, x)
+                if hasattr(full, "sym_partial_supported") and full.sym_partial_supported():
+                    self._full_op = full
+                    self.sym_partial = full.sym_partial_
 
     def _buffers(self, a: torch.Tensor):
         key = (tuple(a.shape[1:]), a.dtype, a.device)
@@ -83,6 +109,18 @@ class ShardedGramian:
             if self.local is not None:
                 self._local_into(out, a)
             return out
+        if self.sym_partial is not None and a.dim() == 1:
+            # symmetric form: this rank's partial product, then ONE all-reduce (the only collective of the MVM)
+            if out is None or not out.is_contiguous():
+                res = torch.empty(self.n, dtype=a.dtype, device=a.device)
+            else:
+                res = out
+            self.sym_partial(res, a, self.rank, self.world)
+            dist.all_reduce(res, op=dist.ReduceOp.SUM, group=self.group)
+            if out is not None and res is not out:
+                out.copy_(res)
+                return out
+            return res
         shard, full = self._buffers(a)
         if self.local is not None:
             self._local_into(shard[:rows], a)

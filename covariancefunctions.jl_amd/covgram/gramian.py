@@ -315,6 +315,32 @@ class Gramian(LazyOperator):
             y.copy_(y_cm.t())
         return y
 
+    # -- multi-GPU symmetric form (include/covgram.h: covgram_mvm_sym_partial) ---------------------
+    def sym_partial_supported(self) -> bool:
+        """True when rank r of P can take the cyclic 256-row panels of the upper triangle (fp32 EQ on the matrix cores, one
+        point set on both sides); depends on the kernel and the points only, so every rank answers alike."""
+        if self._px is not self._py and not (self._px.t.data_ptr() == self._py.t.data_ptr() and self.shape[0] == self.shape[1]):
+            return False
+        try:
+            spec = self._spec()
+        except Exception:
+            return False
+        ok = C.c_int32(0)
+        _ffi.check(_ffi.lib().covgram_mvm_sym_supported(self._px.ctx.bind_stream(), _ffi.kref(spec), self._px.handle, C.byref(ok)))
+        return bool(ok.value)
+
+    def sym_partial_(self, y, a, rank: int, world: int):
+        """y <- the part of G a that comes from the upper-triangle tiles of the panels p ≡ rank (mod world) and their mirror
+        images; the partials of all ranks sum to G a.  Vectors only."""
+        n, m = self.shape
+        a = _vec_arg(a, m, self.dtype, self.device, "a")
+        if a.dim() != 1 or y.shape != (n,) or y.dtype != self.dtype or not y.is_contiguous():
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, "sym_partial_: contiguous vectors of length n expected")
+        a_c = a.contiguous()
+        _ffi.check(_ffi.lib().covgram_mvm_sym_partial(self._px.ctx.bind_stream(), _ffi.kref(self._spec()), self._px.handle,
+                                                      _ffi._P(a_c.data_ptr()), _ffi._P(y.data_ptr()), int(rank), int(world)))
+        return y
+
     def to_dense(self):
         """Matrix(G) (src/gramian.jl:102-114) on the device."""
         n, m = self.shape

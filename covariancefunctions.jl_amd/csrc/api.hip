@@ -995,6 +995,35 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     return COVGRAM_OK;
 }
 
+int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported) {
+    CG_REQUIRE(supported != nullptr, COVGRAM_EINVAL, "NULL argument");
+    *supported = 0;
+    int rc = check_pair(ctx, X, X);
+    if (rc) return rc;
+    if (k == nullptr || k->family == COVGRAM_COMPOSITE) return COVGRAM_OK;
+    HostKernel hk;
+    rc = make_host_kernel(k, X->dtype, false, &hk);
+    if (rc) return rc;
+    *supported = (X->n > 0 && mfma_eq_sym_eligible(ctx, hk, X, X, 1)) ? 1 : 0;
+    return COVGRAM_OK;
+}
+
+int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y,
+                            int32_t rank, int32_t world) {
+    CG_REQUIRE(world >= 1 && rank >= 0 && rank < world, COVGRAM_EINVAL, "rank %d outside [0, %d)", rank, world);
+    CG_REQUIRE(a != nullptr && y != nullptr, COVGRAM_EINVAL, "a or y is NULL");
+    int32_t ok = 0;
+    int rc = covgram_mvm_sym_supported(ctx, k, X, &ok);
+    if (rc) return rc;
+    if (!ok) { set_error("symmetric matrix-core kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
+    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    HostKernel hk;
+    rc = make_host_kernel(k, X->dtype, false, &hk);
+    if (rc) return rc;
+    ctx->last_dense_path = 2; ctx->last_mfma_sym = 1;
+    return mvm_eq_mfma_sym(ctx, hk, X, (const float*)a, (float*)y, 1.0, 0.0, rank, world);
+}
+
 int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
                      void* y, double alpha, double beta, int32_t loc) {
     return grad_mvm_impl(ctx, k, X, Y, a, y, alpha, beta, loc, 0);

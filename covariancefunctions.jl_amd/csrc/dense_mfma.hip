@@ -507,14 +507,17 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 template <int K2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_eq_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
-    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn) {
+    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
+    int32_t pfirst, int32_t pstride) {
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
     constexpr int NW = 8, ST = (K2 <= 2) ? 8 : 4;
     // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
     // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
     // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
-    const int64_t p = blockIdx.x;
+    // panels pfirst, pfirst + pstride, ...: all of them on one GPU (0, 1); rank g of P GPUs takes (g, P) — cyclic, so that
+    // every rank gets the same share of the triangle — and S is indexed by the LOCAL panel number blockIdx.x
+    const int64_t p = pfirst + (int64_t)pstride * blockIdx.x;
     const int64_t T1a = ((int64_t)blockIdx.y + 1) * tchunk;
     if (T1a <= NW * p) return;                                     // chunk entirely left of the panel (whole workgroup, before any barrier)
     const int64_t T0 = ((int64_t)blockIdx.y * tchunk > NW * p) ? (int64_t)blockIdx.y * tchunk : NW * p;
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (wv < ST) {                                                                          \
             const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
             if (h == 0 && J_ < T1)                                                              \
-                S[p * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
+                S[(int64_t)blockIdx.x * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
                                             ((CS[4][wv][t] + CS[5][wv][t]) + (CS[6][wv][t] + CS[7][wv][t]));    \
         }
     CG_DMA(0, sfA)
@@ -654,14 +657,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
                                                                     const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
                                                                     float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
-                                                                    float beta) {
+                                                                    float beta, int32_t pfirst, int32_t pstride) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     __shared__ float red[4][64];
     float s = 0.0f;
     if (i < n) {
         const int64_t pi = i >> 8;                                                   // the row's panel (256 rows)
-        for (int64_t p = part; p <= pi; p += 4) s += S[p * npad + i];
+        // local panels lp (global pfirst + pstride lp) up to the row's own panel
+        const int64_t nlp = pi >= pfirst ? (pi - pfirst) / pstride + 1 : 0;
+        for (int64_t lp = part; lp < nlp; lp += 4) s += S[lp * npad + i];
     }
     red[part][lane] = s;
     __syncthreads();
@@ -670,7 +675,8 @@ __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float*
     const int64_t pi = i >> 8;
     const int64_t cfirst = (8 * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
     float rs = 0.0f;
-    for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
+    if (pi >= pfirst && (pi - pfirst) % pstride == 0)                                 // the row sums exist only where this rank owns the panel
+        for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
     float ni = 0.0f;
     for (int c = 0; c < d; ++c) { const float xc = g * (X[i * (int64_t)d + c] - Cn[c]); ni = __builtin_fmaf(xc, xc, ni); }
     float v = alpha * __builtin_fmaf(__builtin_amdgcn_exp2f(-0.5f * ni), cs, rs);
@@ -686,13 +692,18 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
 }
 
-// y <- alpha * scale * G a + beta * y for the symmetric Gramian of ONE point set and one right-hand side
-int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta) {
+// y <- alpha * scale * G_part a + beta * y for the symmetric Gramian of ONE point set and one right-hand side, where G_part
+// holds the entries (i, j), (j, i) whose upper-triangle tile lies in the panels pfirst, pfirst + pstride, ... — all of G
+// for (0, 1); the partial products of the ranks (g, P), g < P, add up to G a (covgram_mvm_sym_partial).
+int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta,
+                    int pfirst, int pstride) {
     const int64_t n = X->n;
     const int d = X->d;
     const int D = pad_dim(d);
     const int K2 = (D + 1) / 2;
-    const int64_t ntile = (n + 31) / 32, panels = (ntile + 7) / 8, npad = panels * 256;
+    // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
+    // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
+    const int64_t ntile = (n + 31) / 32, panels = (ntile + 7) / 8, npad = panels * 256 + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
@@ -713,20 +724,22 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
                            ntile * 32, g, Cn);
     }
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
-    const int64_t tileops = panels * ntile / 2 + panels * 4;                     // (panel, tile) visits
+    const int64_t lpanels = panels > pfirst ? (panels - pfirst + pstride - 1) / pstride : 0;   // this call's panels
+    const int64_t tileops = (panels * ntile / 2 + panels * 4) / pstride;         // (panel, tile) visits
     int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 2 * 8;
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
-    tchunk = std::max<int64_t>(32, std::min<int64_t>(((tchunk + 7) / 8) * 8, 1024));
+    // >= 64 tiles: shorter chunks do not amortise a workgroup's prologue (rows, row weights, first stage) — tools/sym_tchunk_sweep.py
+    tchunk = std::max<int64_t>(64, std::min<int64_t>(((tchunk + 7) / 8) * 8, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
     void *Rp, *Sp;
     rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
-    rc = ws_reserve(ctx, 4, (size_t)panels * npad * sizeof(float), &Sp); if (rc) return rc;
+    rc = ws_reserve(ctx, 4, (size_t)std::max<int64_t>(lpanels, 1) * npad * sizeof(float), &Sp); if (rc) return rc;
     const double alpha_eff = alpha * hk.kp.scale;
-    const dim3 grid((unsigned)panels, (unsigned)maxc);
+    const dim3 grid((unsigned)std::max<int64_t>(lpanels, 1), (unsigned)maxc);
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
 #define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_eq_sym_kernel<K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
-                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn); break;
+                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride); break;
     switch (K2) {
         CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
         default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
@@ -734,7 +747,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #undef CG_SYM_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d,
-                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta);
+                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -163,6 +163,18 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
 int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y,
                    void* out, int64_t ldo, int32_t loc);
 
+/* Multi-GPU form of the symmetric dense MVM (one process per GPU, every rank holds all of x and a): rank r of `world`
+ * evaluates the upper-triangle tiles of gramian(k, x) whose 256-row panel p satisfies p % world == r — cyclic, so every rank
+ * gets the same share of the triangle — and returns in y (n scalars, device) the partial product of those entries AND their
+ * mirror images; the partials of all ranks add up to G a, so ONE all-reduce (RCCL) completes b on every rank
+ * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  Only where the symmetric
+ * matrix-core kernel applies (fp32 EQ, d <= 8, norm gate, n >= 40000 or option "mfma_sym" = 1): `*supported` of
+ * covgram_mvm_sym_supported says so (identically on every rank: it depends on k and x only), and
+ * covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED otherwise — callers then shard rows and all-gather (covgram_mvm). */
+int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported);
+int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y,
+                            int32_t rank, int32_t world);
+
 /* Gradient-kernel Gramian (nd × md): y <- alpha * G a + beta * y with flat point-major block vectors
  * a (length m*d) and y (length n*d). */
 int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,

@@ -63,6 +63,48 @@ def _grad_worker(rank, world, port, n, m, d, nrhs, q):
     dist.destroy_process_group()
 
 
+def _sym_worker(rank, world, port, n, m, d, nrhs, q):
+    """Symmetric form: every rank holds all of x, takes the cyclic panels p = rank (mod world) of the upper triangle (here
+    panels of 4 rows, as a CPU stand-in for covgram_mvm_sym_partial) and ONE all-reduce completes b; a matrix right-hand side
+    falls back to row shards + all-gather on the same object."""
+    sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import covgram as cg
+    import covgram_oracle as o
+    rng = np.random.default_rng(77)
+    X = torch.from_numpy(rng.standard_normal((n, d)))
+    a = torch.from_numpy(rng.standard_normal(n)); A3 = torch.from_numpy(rng.standard_normal((n, 3)))
+    ko = o.Kernel(o.EQ)
+    calls = []
+
+    def sym_factory(k, x):
+        Gm = o.matrix(ko, x.numpy(), x.numpy())
+        i = np.arange(x.shape[0])
+        owner = (np.minimum(i[:, None], i[None, :]) // 4)                      # panel of the pair's upper-triangle entry
+        def partial(out, vec, r, w):
+            calls.append((r, w))
+            out.copy_(torch.from_numpy((Gm * (owner % w == r)) @ vec.numpy()))
+            return out
+        return partial
+
+    def factory(k, x_rows, y_full):
+        return lambda vec: torch.from_numpy(o.mul(None, ko, x_rows.numpy(), y_full.numpy(), vec.numpy()))
+
+    G = cg.ShardedGramian(cg.EQ(), X, local_factory=factory, sym_partial_factory=sym_factory)
+    b = G @ a
+    out = torch.full((n,), float("nan"), dtype=torch.float64); G.mul_(out, a)
+    B3 = G @ A3                                                                 # several right-hand sides: row shards
+    ref = o.mul(None, ko, X.numpy(), X.numpy(), a.numpy()); ref3 = o.mul(None, ko, X.numpy(), X.numpy(), A3.numpy())
+    err = max(float(np.linalg.norm(b.numpy() - ref) / np.linalg.norm(ref)), float(np.linalg.norm(out.numpy() - ref) / np.linalg.norm(ref)),
+              float(np.linalg.norm(B3.numpy() - ref3) / np.linalg.norm(ref3)))
+    Gr = cg.ShardedGramian(cg.EQ(), X, local_factory=factory, sym_partial_factory=sym_factory, symmetric=False)
+    err = max(err, float(np.linalg.norm((Gr @ a).numpy() - ref) / np.linalg.norm(ref)))
+    q.put((rank, len(calls), calls[0] if calls else None, tuple(b.shape), err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _run(n, m, d, nrhs, world=2, worker=None):
     worker = worker or _worker
     ctx = mp.get_context("spawn")
@@ -96,3 +138,9 @@ def test_row_sharded_gradient_gramian_world2():
     assert [r[1:3] for r in res] == [(0, 6), (6, 11)]
     for r in res:
         assert r[3] == (33,) and r[4] < 1e-13
+
+
+def test_symmetric_cyclic_panels_allreduce_world2():
+    res = _run(n=37, m=37, d=2, nrhs=1, worker=_sym_worker)
+    for rank, (r, ncalls, first, shape, err) in enumerate(res):
+        assert r == rank and ncalls == 2 and first == (rank, 2) and shape == (37,) and err < 1e-13

@@ -654,6 +654,35 @@ def test_eq_symmetric_matrix_core_kernel(cg, oracle, d):
         cg.set_option("mfma_sym", -1); cg.set_option("jsplit", 0)
 
 
+def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
+    """covgram_mvm_sym_partial (the multi-GPU form): rank r of P takes the upper-triangle tiles of the panels p = r (mod P) and
+    their mirror images; emulated on one GPU, the partials of all ranks must sum to G a — also when there are fewer panels
+    than ranks — and a kernel / point set the symmetric kernel does not serve must say so."""
+    rng = np.random.default_rng(31)
+    try:
+        cg.set_option("mfma_sym", 1)
+        for n, d in ((1500, 3), (5, 2), (777, 8)):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); a = rng.standard_normal(n).astype(np.float32)
+            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+            G = cg.gramian(2.0 * cg.EQ(), Xd)
+            assert G.sym_partial_supported()
+            want = oracle.mul(None, oracle.Kernel(oracle.EQ, scale=2.0), X, X, a, dtype=np.float32)
+            for world in (1, 2, 3, 8):
+                tot = torch.zeros(n, dtype=torch.float32, device="cuda")
+                for r in range(world):
+                    part = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+                    G.sym_partial_(part, ad, r, world)
+                    tot += part
+                assert relerr(tot.cpu().numpy(), want) <= 1e-5, (n, d, world, relerr(tot.cpu().numpy(), want))
+        assert not cg.gramian(cg.MaternP(2), Xd).sym_partial_supported()
+        assert not cg.gramian(cg.EQ(), Xd.double()).sym_partial_supported()
+        assert not cg.gramian(cg.EQ(), Xd, Xd.clone()).sym_partial_supported()
+        cg.set_option("mfma_sym", -1)
+        assert not cg.gramian(cg.EQ(), Xd).sym_partial_supported()          # below the size from which it pays
+    finally:
+        cg.set_option("mfma_sym", -1)
+
+
 def test_eq_symmetric_kernel_at_size(cg, oracle):
     """The size at which the library picks the symmetric kernel by itself (n >= 40000): sampled rows against the oracle."""
     rng = np.random.default_rng(77)
