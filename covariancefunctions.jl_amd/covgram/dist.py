@@ -21,10 +21,10 @@ import torch
 import torch.distributed as dist
 
 
-# The symmetric form pays from ~4e9 evaluated pairs per rank (tools/sym_shard_probe.py, n = 131072: 707 vs 785 us per rank at
-# P = 2, a tie at P = 4, 260 vs 238 us at P = 8 — its 8-wave workgroups have a heavier prologue than the general kernel's, which
-# short column chunks do not amortise — and its all-reduce moves n scalars per rank where the all-gather moves n / P).
-SYM_MIN_PAIRS_PER_RANK = 4.0e9
+# The symmetric form pays from ~1e9 evaluated pairs per rank (tools/sym_shard_probe.py, n = 131072 on one GPU emulating rank r of
+# P: 653 vs 778 us per rank at P = 2, 351 vs 405 at P = 4, 197-206 vs 221 at P = 8; below that its 8-wave workgroups leave the
+# chip under-filled) — its all-reduce moves n scalars per rank where the all-gather moves n / P, a few microseconds apart at these sizes.
+SYM_MIN_PAIRS_PER_RANK = 1.0e9
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:

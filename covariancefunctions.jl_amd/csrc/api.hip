@@ -406,6 +406,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx_blas_destroy(ctx);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
+    if (ctx->sym_map) (void)hipFree(ctx->sym_map);
     for (auto& t : ctx->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -155,6 +155,9 @@ struct covgram_ctx {
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
+    int32_t* sym_map = nullptr;  // symmetric kernel: device list of its (local panel, chunk) workgroups, keyed by sym_key
+    size_t sym_map_cap = 0, sym_map_len = 0;
+    int64_t sym_key[4] = {-1, -1, -1, -1};
     int64_t last_mfma_sym = 0;   // the last dense MVM ran the symmetric (upper-triangle) matrix-core kernel
     int64_t last_mfma_lds = 0;   // the last matrix-core EQ MVM shared its column tiles through LDS
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)

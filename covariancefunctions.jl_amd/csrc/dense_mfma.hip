@@ -508,7 +508,7 @@ template <int K2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_eq_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride) {
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap) {
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
     constexpr int NW = 8, ST = (K2 <= 2) ? 8 : 4;
@@ -517,11 +517,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
     // panels pfirst, pfirst + pstride, ...: all of them on one GPU (0, 1); rank g of P GPUs takes (g, P) — cyclic, so that
     // every rank gets the same share of the triangle — and S is indexed by the LOCAL panel number blockIdx.x
-    const int64_t p = pfirst + (int64_t)pstride * blockIdx.x;
-    const int64_t T1a = ((int64_t)blockIdx.y + 1) * tchunk;
-    if (T1a <= NW * p) return;                                     // chunk entirely left of the panel (whole workgroup, before any barrier)
-    const int64_t T0 = ((int64_t)blockIdx.y * tchunk > NW * p) ? (int64_t)blockIdx.y * tchunk : NW * p;
-    if (T0 >= ntile) return;
+    // wgmap[blockIdx.x] = (local panel << 12) | absolute chunk: the host lists only the (panel, chunk) pairs that exist — a
+    // rectangular (panel, chunk) grid is half empty, and an empty 512-thread workgroup still waits for a full slot (LDS,
+    // registers) in dispatch order before it can exit, which left the chip 40 % idle on short launches (1/8 of C2).
+    const int32_t wm = wgmap[blockIdx.x];
+    const int64_t lp = wm >> 12;
+    const int64_t cabs = wm & 4095;
+    const int64_t p = pfirst + (int64_t)pstride * lp;
+    const int64_t T1a = (cabs + 1) * tchunk;
+    const int64_t T0 = (cabs * tchunk > NW * p) ? cabs * tchunk : NW * p;
+    if (T1a <= NW * p || T0 >= ntile) return;                      // (never for a listed pair; whole workgroup, before any barrier)
     const int64_t T1 = T1a < ntile ? T1a : ntile;
     const int nt = (int)(T1 - T0);
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (wv < ST) {                                                                          \
             const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
             if (h == 0 && J_ < T1)                                                              \
-                S[(int64_t)blockIdx.x * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
+                S[lp * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
                                             ((CS[4][wv][t] + CS[5][wv][t]) + (CS[6][wv][t] + CS[7][wv][t]));    \
         }
     CG_DMA(0, sfA)
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const int64_t i = i0 + t;
     if (((t >> 2) & 1) != h || i >= n) return;
-    R[(int64_t)blockIdx.y * npad + i] = __builtin_amdgcn_exp2f(-0.5f * nx) * tot;
+    R[cabs * npad + i] = __builtin_amdgcn_exp2f(-0.5f * nx) * tot;
 }
 
 // b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order.
@@ -735,11 +740,34 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
     rc = ws_reserve(ctx, 4, (size_t)std::max<int64_t>(lpanels, 1) * npad * sizeof(float), &Sp); if (rc) return rc;
     const double alpha_eff = alpha * hk.kp.scale;
-    const dim3 grid((unsigned)std::max<int64_t>(lpanels, 1), (unsigned)maxc);
+    // the (local panel, absolute chunk) pairs that exist, chunk-major (the workgroups in flight share a chunk's fragments in
+    // L2); cached in the context by its key
+    CG_REQUIRE(maxc <= 4096 && lpanels < ((int64_t)1 << 19), COVGRAM_EUNSUPPORTED, "dense_mfma_sym: work list out of range");
+    const int64_t key[4] = {ntile, tchunk, pfirst, pstride};
+    if (ctx->sym_map == nullptr || memcmp(ctx->sym_key, key, sizeof(key)) != 0) {
+        std::vector<int32_t> list;
+        for (int64_t c = 0; c < maxc; ++c)
+            for (int64_t lp = 0; lp < lpanels; ++lp) {
+                const int64_t p8 = 8 * ((int64_t)pfirst + (int64_t)pstride * lp);
+                if (p8 >= (c + 1) * tchunk) break;                 // panels are ascending: the rest start right of this chunk
+                if (std::max(c * tchunk, p8) < ntile) list.push_back((int32_t)((lp << 12) | c));
+            }
+        if (list.size() > ctx->sym_map_cap) {
+            if (ctx->sym_map) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->sym_map); ctx->sym_map = nullptr; }
+            ctx->sym_map_cap = std::max<size_t>(list.size(), 4096);
+            CG_CHECK_HIP(hipMalloc((void**)&ctx->sym_map, ctx->sym_map_cap * sizeof(int32_t)));
+        } else if (ctx->sym_map) {
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // a launch in flight may still read the old list
+        }
+        if (!list.empty()) CG_CHECK_HIP(hipMemcpy(ctx->sym_map, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        memcpy(ctx->sym_key, key, sizeof(key));
+        ctx->sym_map_len = list.size();
+    }
+    const dim3 grid((unsigned)std::max<size_t>(ctx->sym_map_len, 1));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
 #define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_eq_sym_kernel<K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
-                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride); break;
+                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map); break;
     switch (K2) {
         CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
         default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;

@@ -24,9 +24,9 @@ for P in (2, 4, 8):
     per = (n + P - 1) // P
     Gs = cg.gramian(cg.EQ(), X[:per], X); ys = torch.empty(per, dtype=torch.float32, device="cuda")
     rs = timeit(lambda: Gs.mul_(ys, a))
-    print(f"world={P}: symmetric partial per rank max {max(ts):.1f} us  min {min(ts):.1f} us  (ideal {full / P:.1f});  row shard of the general kernel {rs:.1f} us")
-for js in (128, 64, 32, 16, 8):
+    print(f"world={P}: symmetric partial per rank max {max(ts):.1f} us  min {min(ts):.1f} us  (ideal {full / P:.1f});  row shard of the general kernel {rs:.1f} us   per rank: " + " ".join(f"{t:.0f}" for t in ts))
+for js in (128, 64, 43, 32, 16):
     cg.set_option("jsplit", js)
-    ts = [timeit(lambda r=r: G.sym_partial_(part, a, r, 8)) for r in (0, 3, 7)]
-    print(f"world=8, column chunk of {4096 // js} tiles: symmetric partial per rank {max(ts):.1f} us")
+    ts = [timeit(lambda r=r: G.sym_partial_(part, a, r, 8)) for r in range(8)]
+    print(f"world=8, column chunk of {-(-4096 // js)} tiles: per rank " + " ".join(f"{t:.0f}" for t in ts))
 cg.set_option("jsplit", 0)
