@@ -693,7 +693,7 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
     if (ctx->mfma_sym == 0 || X->dptr != Y->dptr || X->n != Y->n) return false;       // gramian(k, x): the same point set on both sides
     if (!mfma_eq_eligible(ctx, hk, X, Y, nrhs) || X->d > 8) return false;
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + 7) / 8;
-    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)2 << 30)) return false;   // column-sum slab <= 2 GiB
+    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)16 << 30)) return false;   // column-sum slab <= 16 GiB of the 288
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
 }
 
