@@ -77,7 +77,18 @@ def main():
          ms_median=med, ms_min=mn, pairs_per_s=float(shard) * n3 / (med * 1e-3), rel_err_vs_fp64_oracle=err, checked_rows=512,
          projected_8gpu_mvm_per_s=1e3 / (med + 0.03), note="projection = shard time + ~30 us all-gather of 256 KiB per rank; the 8-GPU run itself is the driver's",
          roofline={"bound": "valu", "achieved_TFLOPs": flops / (med * 1e-3) * 1e-12, "peak_TFLOPs": FP32_PEAK * 1e-12, "frac": flops / (med * 1e-3) / FP32_PEAK})
-    del G, X, a, y
+    # the form the 8-GPU run actually takes (covgram.ShardedGramian): rank r's cyclic panels of the upper triangle + one all-reduce
+    Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n3, dtype=torch.float32, device="cuda"); tot = torch.zeros(n3, dtype=torch.float32, device="cuda")
+    per_rank = []
+    for r in range(8):
+        med_r, _ = timeit(lambda r=r: Gf.sym_partial_(part, a, r, 8), warm=2, reps=4)
+        per_rank.append(med_r); tot += part
+    err = rel(tot.cpu().numpy()[rows], o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32))
+    emit(config="C3-sym-partial", what="dense EQ mul!, d=8, n=524288 fp32: rank r of 8 of the symmetric form (cyclic 256-row panels of the upper "
+         "triangle, covgram_mvm_sym_partial), every rank timed on this one GPU; the 8 partials summed and checked",
+         ms_per_rank=per_rank, ms_median=max(per_rank), rel_err_vs_fp64_oracle=err, checked_rows=512,
+         projected_8gpu_mvm_per_s=1e3 / (max(per_rank) + 0.06), note="projection = slowest rank + ~60 us all-reduce of 2 MiB; the 8-GPU run itself is the driver's")
+    del G, Gf, X, a, y, part, tot
     # C4: GradientKernel(EQ), d=32, n=16384, fp64
     n4, d4 = 16384, 32
     rng = np.random.default_rng(0xC0F + 3)
