@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap) {
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
-    constexpr int NW = 8, ST = (K2 <= 2) ? 8 : 4;
+    constexpr int NW = 8, ST = 4;
     // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
     // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
     // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
@@ -567,19 +567,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float* __restrict__ wbase = W + T0 * 32;
     __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
     __shared__ float swA[ST][32], swB[ST][32];
-    __shared__ float csA[NW][ST][32], csB[NW][ST][32];             // [wave][tile of the stage][column]: column sums per wave
+    __shared__ float csA[NW][ST][64], csB[NW][ST][64];             // [wave][tile of the stage][half-wave, column]: column sums per half-wave
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int nstage = (nt + ST - 1) / ST;
     float gw = 0.0f;
     // one tile: E once, row sums with the column weight w (masked below the diagonal), column sums with the row weights u
-    auto process = [&](const Frag (&f)[K2], float w, int64_t J, float& cpart) {
+    // (masked: only the stages that touch the panel's own diagonal block carry the two wave-uniform masks)
+    auto process = [&](auto masked, const Frag (&f)[K2], float w, int64_t J, float& cpart) {
+        constexpr bool MASKED = decltype(masked)::value;
         f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]);
-        const float wr = (J >= I0) ? w : 0.0f;                     // wave-uniform masks: only inside the diagonal block
+        const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
 #pragma unroll
         for (int v = 0; v < 16; v += 4) {
@@ -592,8 +594,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
             c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
         }
-        cpart = (J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;
-        cpart += __shfl_xor(cpart, 32);                            // the other 16 rows of the tile live in the other half-wave
+        cpart = (!MASKED || J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;   // this half-wave's 16 rows; the halves meet in the flush
     };
 #define CG_DMA(stage, SF)                                                                       \
         if (wv < ST) {                                                                          \
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
             gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
         }
-#define CG_STAGE(st_, SF, SW, CS)                                                               \
+#define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
         _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
             Frag f0[K2], f1[K2];                                                                \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
@@ -611,17 +612,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f1[mm].u = SF[k + 1][mm][l];      \
             const float w1 = SW[k + 1][t];                                                      \
             float cp0, cp1;                                                                     \
-            process(f0, w0, T0 + (int64_t)(st_) * ST + k, cp0);                                 \
-            process(f1, w1, T0 + (int64_t)(st_) * ST + k + 1, cp1);                             \
-            if (h == 0) { CS[wv][k][t] = cp0; CS[wv][k + 1][t] = cp1; }                         \
+            process(std::integral_constant<bool, M_>(), f0, w0, T0 + (int64_t)(st_) * ST + k, cp0);     \
+            process(std::integral_constant<bool, M_>(), f1, w1, T0 + (int64_t)(st_) * ST + k + 1, cp1); \
+            CS[wv][k][l] = cp0; CS[wv][k + 1][l] = cp1;                                         \
         }
-    // after the stage's barrier: wave w < ST adds the eight waves' column sums of tile w of that stage (fixed order), stores them
+    // a stage whose first tile lies beyond the panel's diagonal block (tiles NW p .. NW p + NW - 1) needs no masks
+#define CG_STAGE(st_, SF, SW, CS)                                                               \
+        if (T0 + (int64_t)(st_) * ST >= NW * p + NW) { CG_STAGE_M(false, st_, SF, SW, CS) }     \
+        else { CG_STAGE_M(true, st_, SF, SW, CS) }
+    // after the stage's barrier: wave w < ST adds the 8 waves x 2 half-waves' column sums of tile w of that stage (fixed order)
 #define CG_FLUSH(st_, CS)                                                                       \
         if (wv < ST) {                                                                          \
             const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
-            if (h == 0 && J_ < T1)                                                              \
-                S[lp * npad + 32 * J_ + t] = ((CS[0][wv][t] + CS[1][wv][t]) + (CS[2][wv][t] + CS[3][wv][t])) +   \
-                                            ((CS[4][wv][t] + CS[5][wv][t]) + (CS[6][wv][t] + CS[7][wv][t]));    \
+            if (h == 0 && J_ < T1) {                                                            \
+                float s_ = 0.0f;                                                                \
+                _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][wv][t] + CS[w_][wv][32 + t]; \
+                S[lp * npad + 32 * J_ + t] = s_;                                                \
+            }                                                                                   \
         }
     CG_DMA(0, sfA)
     if (wv < ST && h == 0) swA[wv][t] = gw;
@@ -642,6 +649,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #undef CG_DMA
 #undef CG_STAGE
+#undef CG_STAGE_M
 #undef CG_FLUSH
 
     const int vsel = (t & 3) + 4 * (t >> 3);
@@ -734,7 +742,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 2 * 8;
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     // >= 64 tiles: shorter chunks do not amortise a workgroup's prologue (rows, row weights, first stage) — tools/sym_tchunk_sweep.py
-    tchunk = std::max<int64_t>(64, std::min<int64_t>(((tchunk + 7) / 8) * 8, 1024));
+    tchunk = std::max<int64_t>(64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
     void *Rp, *Sp;
     rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
