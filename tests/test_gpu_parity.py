@@ -684,7 +684,7 @@ def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
 
 
 def test_eq_symmetric_kernel_at_size(cg, oracle):
-    """The size at which the library picks the symmetric kernel by itself (n >= 40000): sampled rows against the oracle."""
+    """The size at which the library picks the symmetric kernel by itself (n >= 24000): sampled rows against the oracle."""
     rng = np.random.default_rng(77)
     n, d = 50021, 3
     X = rng.standard_normal((n, d)).astype(np.float32); a = rng.standard_normal(n).astype(np.float32)
