@@ -717,7 +717,12 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     else if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
         mfma = true;
-        rc = mvm_mfma_gen(ctx, k, X, Y, (const float*)a_dev, lda_d, (float*)y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
+        if (mfma_gen_sym_eligible(ctx, hk, X, Y, nrhs)) {              // gramian(k, x): upper triangle once, any matrix-core profile
+            ctx->last_mfma_sym = 1;
+            rc = mvm_eq_mfma_sym(ctx, hk, X, (const float*)a_dev, (float*)y_dev, alpha, beta, 0, 1, k); if (rc) return rc;
+        } else {
+            rc = mvm_mfma_gen(ctx, k, X, Y, (const float*)a_dev, lda_d, (float*)y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
+        }
     }
     if (m > 0) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
@@ -1005,7 +1010,7 @@ int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const c
     HostKernel hk;
     rc = make_host_kernel(k, X->dtype, false, &hk);
     if (rc) return rc;
-    *supported = (X->n > 0 && mfma_eq_sym_eligible(ctx, hk, X, X, 1)) ? 1 : 0;
+    *supported = (X->n > 0 && (mfma_eq_sym_eligible(ctx, hk, X, X, 1) || mfma_gen_sym_eligible(ctx, hk, X, X, 1))) ? 1 : 0;
     return COVGRAM_OK;
 }
 
@@ -1022,7 +1027,8 @@ int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const cov
     rc = make_host_kernel(k, X->dtype, false, &hk);
     if (rc) return rc;
     ctx->last_dense_path = 2; ctx->last_mfma_sym = 1;
-    return mvm_eq_mfma_sym(ctx, hk, X, (const float*)a, (float*)y, 1.0, 0.0, rank, world);
+    const bool fast = mfma_eq_sym_eligible(ctx, hk, X, X, 1);
+    return mvm_eq_mfma_sym(ctx, hk, X, (const float*)a, (float*)y, 1.0, 0.0, rank, world, fast ? nullptr : k);
 }
 
 int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,

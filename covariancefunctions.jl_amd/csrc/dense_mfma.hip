@@ -504,173 +504,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 // S[p][j] (each (p, tile) exactly once); dense_mfma_sym_reduce_kernel adds R over the panel's chunks and S over the panels
 // p <= panel(j) in fixed order: deterministic, no float atomics.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int K2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_eq_sym_kernel(
-    const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
-    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap) {
-    // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
-    // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
-    constexpr int NW = 8, ST = 4;
-    // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
-    // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
-    // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
-    // panels pfirst, pfirst + pstride, ...: all of them on one GPU (0, 1); rank g of P GPUs takes (g, P) — cyclic, so that
-    // every rank gets the same share of the triangle — and S is indexed by the LOCAL panel number blockIdx.x
-    // wgmap[blockIdx.x] = (local panel << 12) | absolute chunk: the host lists only the (panel, chunk) pairs that exist — a
-    // rectangular (panel, chunk) grid is half empty, and an empty 512-thread workgroup still waits for a full slot (LDS,
-    // registers) in dispatch order before it can exit, which left the chip 40 % idle on short launches (1/8 of C2).
-    const int32_t wm = wgmap[blockIdx.x];
-    const int64_t lp = wm >> 12;
-    const int64_t cabs = wm & 4095;
-    const int64_t p = pfirst + (int64_t)pstride * lp;
-    const int64_t T1a = (cabs + 1) * tchunk;
-    const int64_t T0 = (cabs * tchunk > NW * p) ? cabs * tchunk : NW * p;
-    if (T1a <= NW * p || T0 >= ntile) return;                      // (never for a listed pair; whole workgroup, before any barrier)
-    const int64_t T1 = T1a < ntile ? T1a : ntile;
-    const int nt = (int)(T1 - T0);
-    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t I0 = NW * p + wv;                                // this wave's row tile
-    const int64_t i0 = I0 * 32;
-    Frag a[K2];
-    float nx;
-    float u[16];                                                   // a_i e_i of the 16 rows this lane's accumulators belong to
-    {
-        int64_t row = i0 + t;
-        if (row >= n) row = n - 1;                                 // clamp: computed, never stored, weight 0 below
-        const float* __restrict__ xr = X + row * (int64_t)d;
-        float part = 0.0f;
-#pragma unroll
-        for (int mm = 0; mm < K2; ++mm) {
-            const int c = 2 * mm + h;
-            const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
-            part = __builtin_fmaf(xt, xt, part);
-            unsigned x1, x2, x3;
-            split3(xt, x1, x2, x3);
-            a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-        }
-        nx = part + __shfl_xor(part, 32);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {                             // MFMA 32x32 output: register v of half h is row 8 (v / 4) + 4 h + v % 4
-            int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
-            const float keep = ri < n ? 1.0f : 0.0f;
-            if (ri >= n) ri = n - 1;
-            u[v] = W[ri] * keep;
-        }
-    }
-    float acc[16];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-
-    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    const float* __restrict__ wbase = W + T0 * 32;
-    __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
-    __shared__ float swA[ST][32], swB[ST][32];
-    __shared__ float csA[NW][ST][64], csB[NW][ST][64];             // [wave][tile of the stage][half-wave, column]: column sums per half-wave
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const int nstage = (nt + ST - 1) / ST;
-    float gw = 0.0f;
-    // one tile: E once, row sums with the column weight w (masked below the diagonal), column sums with the row weights u
-    // (masked: only the stages that touch the panel's own diagonal block carry the two wave-uniform masks)
-    auto process = [&](auto masked, const Frag (&f)[K2], float w, int64_t J, float& cpart) {
-        constexpr bool MASKED = decltype(masked)::value;
-        f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]);
-        const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
-        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-#pragma unroll
-        for (int v = 0; v < 16; v += 4) {
-            acc[v] = __builtin_fmaf(wr, D[v], acc[v]);
-            acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);
-            acc[v + 2] = __builtin_fmaf(wr, D[v + 2], acc[v + 2]);
-            acc[v + 3] = __builtin_fmaf(wr, D[v + 3], acc[v + 3]);
-            c0 = __builtin_fmaf(u[v], D[v], c0);
-            c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);
-            c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
-            c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
-        }
-        cpart = (!MASKED || J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;   // this half-wave's 16 rows; the halves meet in the flush
-    };
-#define CG_DMA(stage, SF)                                                                       \
-        if (wv < ST) {                                                                          \
-            const int ti_ = (stage) * ST + wv;                                                  \
-            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
-            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
-                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
-            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
-        }
-#define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
-        _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
-            Frag f0[K2], f1[K2];                                                                \
-            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
-            const float w0 = SW[k][t];                                                          \
-            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f1[mm].u = SF[k + 1][mm][l];      \
-            const float w1 = SW[k + 1][t];                                                      \
-            float cp0, cp1;                                                                     \
-            process(std::integral_constant<bool, M_>(), f0, w0, T0 + (int64_t)(st_) * ST + k, cp0);     \
-            process(std::integral_constant<bool, M_>(), f1, w1, T0 + (int64_t)(st_) * ST + k + 1, cp1); \
-            CS[wv][k][l] = cp0; CS[wv][k + 1][l] = cp1;                                         \
-        }
-    // a stage whose first tile lies beyond the panel's diagonal block (tiles NW p .. NW p + NW - 1) needs no masks
-#define CG_STAGE(st_, SF, SW, CS)                                                               \
-        if (T0 + (int64_t)(st_) * ST >= NW * p + NW) { CG_STAGE_M(false, st_, SF, SW, CS) }     \
-        else { CG_STAGE_M(true, st_, SF, SW, CS) }
-    // after the stage's barrier: wave w < ST adds the 8 waves x 2 half-waves' column sums of tile w of that stage (fixed order)
-#define CG_FLUSH(st_, CS)                                                                       \
-        if (wv < ST) {                                                                          \
-            const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
-            if (h == 0 && J_ < T1) {                                                            \
-                float s_ = 0.0f;                                                                \
-                _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][wv][t] + CS[w_][wv][32 + t]; \
-                S[lp * npad + 32 * J_ + t] = s_;                                                \
-            }                                                                                   \
-        }
-    CG_DMA(0, sfA)
-    if (wv < ST && h == 0) swA[wv][t] = gw;
-    __syncthreads();
-    for (int st = 0; st < nstage; st += 2) {
-        CG_DMA(st + 1 < nstage ? st + 1 : st, sfB)                  // past the last stage: a re-fetch nobody reads
-        if (st > 0) CG_FLUSH(st - 1, csB)
-        CG_STAGE(st, sfA, swA, csA)
-        if (wv < ST && h == 0) swB[wv][t] = gw;
-        __syncthreads();
-        if (st + 1 >= nstage) { CG_FLUSH(st, csA) break; }
-        CG_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
-        CG_FLUSH(st, csA)
-        CG_STAGE(st + 1, sfB, swB, csB)
-        if (wv < ST && h == 0) swA[wv][t] = gw;
-        __syncthreads();
-        if (st + 2 >= nstage) { CG_FLUSH(st + 1, csB) }
-    }
-#undef CG_DMA
-#undef CG_STAGE
-#undef CG_STAGE_M
-#undef CG_FLUSH
-
-    const int vsel = (t & 3) + 4 * (t >> 3);
-    float tot = 0.0f;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        float s = acc[v];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
-        tot = (vsel == v) ? s : tot;
-    }
-    const int64_t i = i0 + t;
-    if (((t >> 2) & 1) != h || i >= n) return;
-    R[cabs * npad + i] = __builtin_amdgcn_exp2f(-0.5f * nx) * tot;
-}
-
 // b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order.
 // 64 rows per workgroup, the panel index strided over the 4 waves (as dense_reduce_kernel).
 __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
                                                                     const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
                                                                     float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
-                                                                    float beta, int32_t pfirst, int32_t pstride) {
+                                                                    float beta, int32_t pfirst, int32_t pstride, int32_t use_e) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     __shared__ float red[4][64];
@@ -690,9 +529,13 @@ __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float*
     float rs = 0.0f;
     if (pi >= pfirst && (pi - pfirst) % pstride == 0)                                 // the row sums exist only where this rank owns the panel
         for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
-    float ni = 0.0f;
-    for (int c = 0; c < d; ++c) { const float xc = g * (X[i * (int64_t)d + c] - Cn[c]); ni = __builtin_fmaf(xc, xc, ni); }
-    float v = alpha * __builtin_fmaf(__builtin_amdgcn_exp2f(-0.5f * ni), cs, rs);
+    float ei = 1.0f;                                                                 // EQ form: the column sums still lack e_i
+    if (use_e) {
+        float ni = 0.0f;
+        for (int c = 0; c < d; ++c) { const float xc = g * (X[i * (int64_t)d + c] - Cn[c]); ni = __builtin_fmaf(xc, xc, ni); }
+        ei = __builtin_amdgcn_exp2f(-0.5f * ni);
+    }
+    float v = alpha * __builtin_fmaf(ei, cs, rs);
     if (beta != 0.0f) v = __builtin_fmaf(beta, y[i], v);
     y[i] = v;
 }
@@ -705,36 +548,74 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
 }
 
+static int mfma_k2_for(int dims);
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
+// the generic profiles' symmetric form: same conditions on top of the generic matrix-core gate (hk: gamma = 1/l parameter block)
+bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
+    if (ctx->mfma_sym == 0 || nrhs != 1 || X->dptr != Y->dptr || X->n != Y->n) return false;
+    if (!mfma_gen_eligible(ctx, hk, X, Y)) return false;
+    const int k2 = mfma_k2_for(X->d + (hk.k.trait == COVGRAM_ISOTROPIC ? 1 : 0));
+    if (k2 < 0 || k2 > 4) return false;
+    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + 7) / 8;
+    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)16 << 30)) return false;
+    return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
+}
+
 // y <- alpha * scale * G_part a + beta * y for the symmetric Gramian of ONE point set and one right-hand side, where G_part
 // holds the entries (i, j), (j, i) whose upper-triangle tile lies in the panels pfirst, pfirst + pstride, ... — all of G
 // for (0, 1); the partial products of the ranks (g, P), g < P, add up to G a (covgram_mvm_sym_partial).
 int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta,
-                    int pfirst, int pstride) {
+                    int pfirst, int pstride, const covgram_kernel* kgen) {
+    // kgen == nullptr: the EQ form (hk is the dense EQ parameter block); else the generic form for kernel *kgen
+    const bool fast = kgen == nullptr;
+    HostKernel hkg;
+    if (!fast) {   // gamma = 1/l and the profile sees s / l^2 — EQ / MaternP: the folded block (dense_mfma.hpp: mfma_folded)
+        int rcg = make_host_kernel(kgen, COVGRAM_F32, !(kgen->family == COVGRAM_EQ || kgen->family == COVGRAM_MATERNP), &hkg);
+        if (rcg) return rcg;
+    }
+    const HostKernel& hku = fast ? hk : hkg;
+    const bool iso = hku.k.trait == COVGRAM_ISOTROPIC;
     const int64_t n = X->n;
     const int d = X->d;
     const int D = pad_dim(d);
-    const int K2 = (D + 1) / 2;
+    const int K2 = fast ? (D + 1) / 2 : mfma_k2_for(d + (iso ? 1 : 0));
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
     const int64_t ntile = (n + 31) / 32, panels = (ntile + 7) / 8, npad = panels * 256 + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
-    void* Wp;
-    int rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
-    if (rc) return rc;
-    float* W = (float*)Wp;
-    if (X->frag_cache == nullptr || X->frag_bytes != fbytes || X->frag_g != g || X->frag_k2 != K2) {
-        if (X->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(X->frag_cache); X->frag_cache = nullptr; }
-        hipError_t me = hipMalloc(&X->frag_cache, fbytes);
-        if (me != hipSuccess) { X->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
-        X->frag_bytes = fbytes; X->frag_g = g; X->frag_k2 = K2;
+    int rc;
+    float* W;
+    const uint4* PBu;
+    if (fast) {
+        void* Wp;
+        rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
+        if (rc) return rc;
+        W = (float*)Wp;
+        if (X->frag_cache == nullptr || X->frag_bytes != fbytes || X->frag_g != g || X->frag_k2 != K2) {
+            if (X->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(X->frag_cache); X->frag_cache = nullptr; }
+            hipError_t me = hipMalloc(&X->frag_cache, fbytes);
+            if (me != hipSuccess) { X->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
+            X->frag_bytes = fbytes; X->frag_g = g; X->frag_k2 = K2;
+            const int64_t pe = ntile * K2 * 64;
+            hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
+                               (uint4*)X->frag_cache, W, K2, g, Cn);
+        } else {
+            hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a, W,
+                               ntile * 32, g, Cn);
+        }
+        PBu = (const uint4*)X->frag_cache;
+    } else {                                                       // generic fragments (norm pseudo-coordinate) + W = a, packed per MVM
+        void* P;
+        rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + 32 * sizeof(float)), &P);
+        if (rc) return rc;
+        uint4* PB = (uint4*)P;
+        W = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
-        hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                           (uint4*)X->frag_cache, W, K2, g, Cn);
-    } else {
-        hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a, W,
-                           ntile * 32, g, Cn);
+        hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
+                           n, 1, 0, PB, W, K2, 1, (float)hku.kp.gamma, iso ? 1 : 0, Cn);
+        PBu = PB;
     }
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
     const int64_t lpanels = panels > pfirst ? (panels - pfirst + pstride - 1) / pstride : 0;   // this call's panels
@@ -747,7 +628,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     void *Rp, *Sp;
     rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
     rc = ws_reserve(ctx, 4, (size_t)std::max<int64_t>(lpanels, 1) * npad * sizeof(float), &Sp); if (rc) return rc;
-    const double alpha_eff = alpha * hk.kp.scale;
+    const double alpha_eff = alpha * hku.kp.scale;
     // the (local panel, absolute chunk) pairs that exist, chunk-major (the workgroups in flight share a chunk's fragments in
     // L2); cached in the context by its key
     CG_REQUIRE(maxc <= 4096 && lpanels < ((int64_t)1 << 19), COVGRAM_EUNSUPPORTED, "dense_mfma_sym: work list out of range");
@@ -774,16 +655,30 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     const dim3 grid((unsigned)std::max<size_t>(ctx->sym_map_len, 1));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
-#define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_eq_sym_kernel<K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
-                                                  (const uint4*)X->frag_cache, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map); break;
-    switch (K2) {
-        CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
-        default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
+#define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                  PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
+                                                  KParams<float>{}); break;
+    if (fast) {
+        switch (K2) {
+            CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
+            default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
+        }
+    } else {
+        MfmaArgs ma;
+        ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PBu; ma.W = W; ma.ntile = ntile; ma.out = nullptr; ma.npad = npad; ma.ldy = n;
+        ma.nrhs = 1; ma.tchunk = tchunk; ma.alpha = 1.0f; ma.beta = 0.0f; ma.final_store = 0; ma.K2 = K2; ma.RT = 1; ma.NR = 1;
+        ma.hk = &hku; ma.stream = ctx->stream; ma.grid = grid; ma.Cn = Cn;
+        ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride;
+        mfma_launch_fn launch = mfma_launcher(hku.tu_family);
+        CG_REQUIRE(launch != nullptr, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: family %d has no matrix-core path", hku.tu_family);
+        rc = launch(ma, false);
+        if (rc) return rc;
     }
 #undef CG_SYM_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d,
-                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride);
+                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride,
+                       fast ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
@@ -843,7 +738,8 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta) {
     HostKernel hk;
-    int rc = make_host_kernel(k, COVGRAM_F32, true, &hk);     // gamma = 1/l, unfolded EQ: the profile sees s / l^2
+    // gamma = 1/l and the profile sees s / l^2 — EQ / MaternP: the folded block (dense_mfma.hpp: mfma_folded)
+    int rc = make_host_kernel(k, COVGRAM_F32, !(k->family == COVGRAM_EQ || k->family == COVGRAM_MATERNP), &hk);
     if (rc) return rc;
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;

@@ -38,6 +38,10 @@ union Frag {
 
 constexpr unsigned BF16_ONE = 0x3F80u;
 
+// EQ and MaternP take the dense path's FOLDED parameter block here too (log2(e) and sqrt(2p+1) in the coordinate pre-scale,
+// rescaled tables: exp2 of the MFMA result, no multiplications in front) — the host passes make_host_kernel(.., for_gradient = false)
+template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
+
 template <int FAM, int K2, int RT, int NR>
 __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
             for (int v = 0; v < 16; ++v) {
                 float s = D[v];
                 if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);          // sqrt of a rounding-negative s
-                float kv = Phi<FAM, float, false>::eval(s, kp);
+                float kv = Phi<FAM, float, mfma_folded<FAM>>::eval(s, kp);
                 if (kp.power != 1) kv = ipow(kv, kp.power);
 #pragma unroll
                 for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv, acc[r][c][v]);
@@ -150,6 +154,206 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
     }
 }
 
+// ---- symmetric Gramians: upper triangle once (design notes: dense_mfma.hip, "Symmetric Gramian") ----------------------------
+// FAM = FAM_EQFAST: the EQ form of dense_mfma.hip (exponent straight from the MFMA, norms in the weights); any other family:
+// the generic form above (the MFMA yields the profile argument s, the norms ride in a pseudo-coordinate, weights are a_j).
+constexpr int FAM_EQFAST = 1000;
+
+template <int FAM, int K2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_sym_kernel(
+    const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
+    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const KParams<float> kp) {
+    constexpr bool FAST = (FAM == FAM_EQFAST);
+    constexpr bool ISO = FAST || fam_is_iso<FAM>;
+    // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
+    // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
+    constexpr int NW = 8, ST = 4;
+    // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
+    // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
+    // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
+    // panels pfirst, pfirst + pstride, ...: all of them on one GPU (0, 1); rank g of P GPUs takes (g, P) — cyclic, so that
+    // every rank gets the same share of the triangle — and S is indexed by the LOCAL panel number blockIdx.x
+    // wgmap[blockIdx.x] = (local panel << 12) | absolute chunk: the host lists only the (panel, chunk) pairs that exist — a
+    // rectangular (panel, chunk) grid is half empty, and an empty 512-thread workgroup still waits for a full slot (LDS,
+    // registers) in dispatch order before it can exit, which left the chip 40 % idle on short launches (1/8 of C2).
+    const int32_t wm = wgmap[blockIdx.x];
+    const int64_t lp = wm >> 12;
+    const int64_t cabs = wm & 4095;
+    const int64_t p = pfirst + (int64_t)pstride * lp;
+    const int64_t T1a = (cabs + 1) * tchunk;
+    const int64_t T0 = (cabs * tchunk > NW * p) ? cabs * tchunk : NW * p;
+    if (T1a <= NW * p || T0 >= ntile) return;                      // (never for a listed pair; whole workgroup, before any barrier)
+    const int64_t T1 = T1a < ntile ? T1a : ntile;
+    const int nt = (int)(T1 - T0);
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t I0 = NW * p + wv;                                // this wave's row tile
+    const int64_t i0 = I0 * 32;
+    Frag a[K2];
+    float nx;
+    float u[16];                                                   // a_i e_i of the 16 rows this lane's accumulators belong to
+    {
+        int64_t row = i0 + t;
+        if (row >= n) row = n - 1;                                 // clamp: computed, never stored, weight 0 below
+        const float* __restrict__ xr = X + row * (int64_t)d;
+        float part = 0.0f;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int mm = 0; mm < K2; ++mm) {
+                const int c = 2 * mm + h;
+                const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
+                part = __builtin_fmaf(xt, xt, part);
+                unsigned x1, x2, x3;
+                split3(xt, x1, x2, x3);
+                a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+            }
+            nx = part + __shfl_xor(part, 32);
+        } else {
+            const float gg = kp.gamma;
+            if constexpr (ISO)
+                for (int cc = 0; cc < d; ++cc) { const float xc = gg * (xr[cc] - Cn[cc]); part = __builtin_fmaf(xc, xc, part); }
+#pragma unroll
+            for (int mm = 0; mm < K2; ++mm) {
+                const int c = 2 * mm + h;
+                uint4 f = make_uint4(0, 0, 0, 0);
+                if (c < d) {
+                    unsigned x1, x2, x3;
+                    split3(ISO ? gg * (xr[c] - Cn[c]) : gg * xr[c], x1, x2, x3);
+                    f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+                } else if (ISO && c == d) {                         // the norm pseudo-coordinate of dense_mfma_gen_kernel
+                    unsigned n1, n2, n3;
+                    split3(part, n1, n2, n3);
+                    f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
+                }
+                a[mm].u = f;
+            }
+            nx = 0.0f;
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {                             // MFMA 32x32 output: register v of half h is row 8 (v / 4) + 4 h + v % 4
+            int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
+            const float keep = ri < n ? 1.0f : 0.0f;
+            if (ri >= n) ri = n - 1;
+            u[v] = W[ri] * keep;
+        }
+    }
+    float acc[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+
+    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
+    const float* __restrict__ wbase = W + T0 * 32;
+    __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
+    __shared__ float swA[ST][32], swB[ST][32];
+    __shared__ float csA[NW][ST][64], csB[NW][ST][64];             // [wave][tile of the stage][half-wave, column]: column sums per half-wave
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int nstage = (nt + ST - 1) / ST;
+    float gw = 0.0f;
+    // one tile: E once, row sums with the column weight w (masked below the diagonal), column sums with the row weights u
+    // (masked: only the stages that touch the panel's own diagonal block carry the two wave-uniform masks)
+    auto process = [&](auto masked, const Frag (&f)[K2], float w, int64_t J, float& cpart) {
+        constexpr bool MASKED = decltype(masked)::value;
+        f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);
+            else {
+                float s = D[v];
+                if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);          // sqrt of a rounding-negative s
+                float kv = Phi<FAST ? COVGRAM_EQ : FAM, float, mfma_folded<FAST ? COVGRAM_EQ : FAM>>::eval(s, kp);
+                if (kp.power != 1) kv = ipow(kv, kp.power);
+                D[v] = kv;
+            }
+        }
+        const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; v += 4) {
+            acc[v] = __builtin_fmaf(wr, D[v], acc[v]);
+            acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);
+            acc[v + 2] = __builtin_fmaf(wr, D[v + 2], acc[v + 2]);
+            acc[v + 3] = __builtin_fmaf(wr, D[v + 3], acc[v + 3]);
+            c0 = __builtin_fmaf(u[v], D[v], c0);
+            c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);
+            c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
+            c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
+        }
+        cpart = (!MASKED || J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;   // this half-wave's 16 rows; the halves meet in the flush
+    };
+#define CG_DMA(stage, SF)                                                                       \
+        if (wv < ST) {                                                                          \
+            const int ti_ = (stage) * ST + wv;                                                  \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
+                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
+            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
+        }
+#define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
+        _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
+            Frag f0[K2], f1[K2];                                                                \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
+            const float w0 = SW[k][t];                                                          \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f1[mm].u = SF[k + 1][mm][l];      \
+            const float w1 = SW[k + 1][t];                                                      \
+            float cp0, cp1;                                                                     \
+            process(std::integral_constant<bool, M_>(), f0, w0, T0 + (int64_t)(st_) * ST + k, cp0);     \
+            process(std::integral_constant<bool, M_>(), f1, w1, T0 + (int64_t)(st_) * ST + k + 1, cp1); \
+            CS[wv][k][l] = cp0; CS[wv][k + 1][l] = cp1;                                         \
+        }
+    // a stage whose first tile lies beyond the panel's diagonal block (tiles NW p .. NW p + NW - 1) needs no masks
+#define CG_STAGE(st_, SF, SW, CS)                                                               \
+        if (T0 + (int64_t)(st_) * ST >= NW * p + NW) { CG_STAGE_M(false, st_, SF, SW, CS) }     \
+        else { CG_STAGE_M(true, st_, SF, SW, CS) }
+    // after the stage's barrier: wave w < ST adds the 8 waves x 2 half-waves' column sums of tile w of that stage (fixed order)
+#define CG_FLUSH(st_, CS)                                                                       \
+        if (wv < ST) {                                                                          \
+            const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
+            if (h == 0 && J_ < T1) {                                                            \
+                float s_ = 0.0f;                                                                \
+                _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][wv][t] + CS[w_][wv][32 + t]; \
+                S[lp * npad + 32 * J_ + t] = s_;                                                \
+            }                                                                                   \
+        }
+    CG_DMA(0, sfA)
+    if (wv < ST && h == 0) swA[wv][t] = gw;
+    __syncthreads();
+    for (int st = 0; st < nstage; st += 2) {
+        CG_DMA(st + 1 < nstage ? st + 1 : st, sfB)                  // past the last stage: a re-fetch nobody reads
+        if (st > 0) CG_FLUSH(st - 1, csB)
+        CG_STAGE(st, sfA, swA, csA)
+        if (wv < ST && h == 0) swB[wv][t] = gw;
+        __syncthreads();
+        if (st + 1 >= nstage) { CG_FLUSH(st, csA) break; }
+        CG_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
+        CG_FLUSH(st, csA)
+        CG_STAGE(st + 1, sfB, swB, csB)
+        if (wv < ST && h == 0) swA[wv][t] = gw;
+        __syncthreads();
+        if (st + 2 >= nstage) { CG_FLUSH(st + 1, csB) }
+    }
+#undef CG_DMA
+#undef CG_STAGE
+#undef CG_STAGE_M
+#undef CG_FLUSH
+
+    const int vsel = (t & 3) + 4 * (t >> 3);
+    float tot = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float s = acc[v];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+        tot = (vsel == v) ? s : tot;
+    }
+    const int64_t i = i0 + t;
+    if (((t >> 2) & 1) != h || i >= n) return;
+    R[cabs * npad + i] = FAST ? __builtin_amdgcn_exp2f(-0.5f * nx) * tot : tot;
+}
+
+
 struct MfmaArgs {
     const float* X; int64_t n; int32_t d;
     const uint4* PB; const float* W; int64_t ntile;
@@ -160,6 +364,11 @@ struct MfmaArgs {
     hipStream_t stream;
     dim3 grid;
     const float* Cn = nullptr;   // common centre of isotropic kernels (dense_mvm.hpp)
+    // symmetric form (dense_mfma_sym_kernel): row-sum slab R, column-sum slab S, the explicit workgroup list
+    int32_t sym = 0;
+    float* R = nullptr; float* S = nullptr;
+    const int32_t* wgmap = nullptr;
+    int32_t pfirst = 0, pstride = 1;
 };
 
 // returns the resident blocks per CU of the instance when `query` is set (no launch), COVGRAM_OK / error otherwise
@@ -180,7 +389,18 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
 }
 
 template <int FAM, int K2>
+static int mfma_sym_one(const MfmaArgs& a) {
+    hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                       (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
+    return COVGRAM_OK;
+}
+
+template <int FAM, int K2>
 static int mfma_gen_K(const MfmaArgs& a, bool query) {
+    if (a.sym) {
+        if constexpr (K2 <= 4) return mfma_sym_one<FAM, K2>(a);
+        else { set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED; }
+    }
     if (a.NR == 4) return mfma_gen_one<FAM, K2, 1, 4>(a, query);
     if constexpr (K2 <= 4) { if (a.RT == 2) return mfma_gen_one<FAM, K2, 2, 1>(a, query); }
     return mfma_gen_one<FAM, K2, 1, 1>(a, query);

@@ -109,17 +109,12 @@ struct Phi<COVGRAM_MATERNP, T, true> {
 template <typename T>
 struct Phi<COVGRAM_MATERNP, T, false> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
+        // value only: no Taylor branch (see the folded specialisation above; the derivative jets keep it)
         T r = cg_sqrt(kp.mp_c * s);
         T e = cg_exp(-r);
-        T q, t;                                         // t: Taylor branch (src/stationary.jl:139-146)
-        if (kp.p <= 3) {   // nu <= 7/2: fixed-degree Horner on the zero-padded tables (same values, no loop, no indexed loads)
-            q = horner3(kp.h0, r);
-            t = horner3(kp.ty, s);
-        } else {
-            q = horner(kp.h0, kp.p, r);
-            t = horner(kp.ty, kp.p, s);
-        }
-        return (s < kp.mp_bound) ? t : q * e;
+        // nu <= 7/2: fixed-degree Horner on the zero-padded table (same values, no loop, no indexed loads)
+        T q = (kp.p <= 3) ? horner3(kp.h0, r) : horner(kp.h0, kp.p, r);
+        return q * e;
     }
 };
 // ---- Matern with real nu (src/stationary.jl:87-114): modified Bessel function of the second kind -----------------------

@@ -683,6 +683,45 @@ def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
         cg.set_option("mfma_sym", -1)
 
 
+@pytest.mark.parametrize("d", [1, 3, 6, 7])
+def test_generic_symmetric_matrix_core_kernels(cg, oracle, d):
+    """The other matrix-core profiles on gramian(k, x) with the upper triangle evaluated once (mfma_sym = 1): RQ, Cauchy, IMQ,
+    MaternP(1..3), Dot^p, ExponentialDot, EQ^2 — against the fp64 oracle and against the general matrix-core kernel, ragged n,
+    alpha / beta; the multi-GPU partial form summed over emulated ranks."""
+    o = oracle
+    rng = np.random.default_rng(1200 + d)
+    kernels = [(cg.Lengthscale(cg.RQ(1.5), 1.3), o.Kernel(o.RQ, param=1.5, lengthscale=1.3)),
+               (2.0 * cg.Cauchy(), o.Kernel(o.CAUCHY, scale=2.0)),
+               (cg.InverseMultiQuadratic(1.2), o.Kernel(o.IMQ, param=1.2)),
+               (cg.MaternP(1), o.Kernel(o.MATERNP, p=1)), (cg.Lengthscale(cg.MaternP(2), 1.5), o.Kernel(o.MATERNP, p=2, lengthscale=1.5)),
+               (cg.MaternP(3), o.Kernel(o.MATERNP, p=3)),
+               (cg.Dot() ** 3, o.Kernel(o.DOT, power=3)), (cg.ExponentialDot(), o.Kernel(o.EXPDOT)), (cg.EQ() ** 2, o.Kernel(o.EQ, power=2))]
+    try:
+        for n in (33, 700, 1601):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+            a = rng.standard_normal(n).astype(np.float32); y0 = rng.standard_normal(n).astype(np.float32)
+            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+            for k, ko in kernels:
+                G = cg.gramian(k, Xd)
+                ref = o.mul(y0, ko, X, X, a, 0.8, -0.6, np.float32)
+                cg.set_option("mfma_sym", 0); cg.set_option("dense_variant", 2)
+                yf = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yf, G, ad, 0.8, -0.6)
+                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 0
+                cg.set_option("mfma_sym", 1)
+                ys = torch.from_numpy(y0.copy()).cuda(); cg.mul_(ys, G, ad, 0.8, -0.6)
+                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 1, type(k).__name__
+                assert relerr(ys.cpu().numpy(), ref) <= 1e-5, (type(k).__name__, d, n, relerr(ys.cpu().numpy(), ref))
+                assert relerr(ys.cpu().numpy(), yf.cpu().numpy()) <= 5e-6
+                if n == 700:
+                    assert G.sym_partial_supported()
+                    tot = torch.zeros(n, dtype=torch.float32, device="cuda"); part = torch.empty_like(tot)
+                    for r in range(3):
+                        G.sym_partial_(part, ad, r, 3); tot += part
+                    assert relerr(tot.cpu().numpy(), o.mul(None, ko, X, X, a, dtype=np.float32)) <= 1e-5
+    finally:
+        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0)
+
+
 def test_eq_symmetric_kernel_at_size(cg, oracle):
     """The size at which the library picks the symmetric kernel by itself (n >= 24000): sampled rows against the oracle."""
     rng = np.random.default_rng(77)

@@ -7,13 +7,22 @@ sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.i
 import covgram as cg
 import covgram_oracle as o
 cases = [(131072, 3), (65536, 8), (32768, 3), (262144, 3), (100003, 5)]
-if len(sys.argv) > 1: cases = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1:]]
+KERNELS = {"EQ": (lambda l: cg.Lengthscale(cg.EQ(), l), lambda l: o.Kernel(o.EQ, lengthscale=l)),
+           "MaternP2": (lambda l: cg.Lengthscale(cg.MaternP(2), l), lambda l: o.Kernel(o.MATERNP, p=2, lengthscale=l)),
+           "RQ": (lambda l: cg.Lengthscale(cg.RQ(1.5), l), lambda l: o.Kernel(o.RQ, param=1.5, lengthscale=l)),
+           "Cauchy": (lambda l: cg.Lengthscale(cg.Cauchy(), l), lambda l: o.Kernel(o.CAUCHY, lengthscale=l)),
+           "Dot2": (lambda l: cg.Dot() ** 2, lambda l: o.Kernel(o.DOT, power=2))}
+kname = "EQ"
+args = sys.argv[1:]
+if args and args[0] in KERNELS: kname = args.pop(0)
+if args: cases = [tuple(int(v) for v in s.split("x")) for s in args]
 for n, d in cases:
     rng = np.random.default_rng(0xC0F + 1)
     Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
     X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda()
-    l = 1.0 if d <= 3 else 2.0
-    G = cg.gramian(cg.Lengthscale(cg.EQ(), l), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
+    l = (1.0 if d <= 3 else 2.0) * (1.0 if kname == "EQ" else 2.0)
+    if kname == "Dot2": Xh = (Xh / np.sqrt(d)).astype(np.float32); X = torch.from_numpy(Xh).cuda()
+    G = cg.gramian(KERNELS[kname][0](l), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     res = {}; outs = {}; used = {}
     for rep in range(5):
@@ -28,7 +37,7 @@ for n, d in cases:
             outs[v] = y.cpu().numpy().astype(np.float64); used[v] = cg.get_info("last_mfma_sym")
     cg.set_option("mfma_sym", -1)
     rows = np.random.default_rng(1).choice(n, 512, replace=False)
-    ref = o.mul(None, o.Kernel(o.EQ, lengthscale=l), Xh[rows], Xh, ah, dtype=np.float32)
+    ref = o.mul(None, KERNELS[kname][1](l), Xh[rows], Xh, ah, dtype=np.float32)
     err = {v: float(np.linalg.norm(outs[v][rows] - ref) / np.linalg.norm(ref)) for v in (0, 1)}
-    print(f"n={n} d={d}: full {np.median(res[0]):.4f} ms (rel-err {err[0]:.2e})   symmetric {np.median(res[1]):.4f} ms (rel-err {err[1]:.2e}, used={used[1]})"
+    print(f"{kname} n={n} d={d}: full {np.median(res[0]):.4f} ms (rel-err {err[0]:.2e})   symmetric {np.median(res[1]):.4f} ms (rel-err {err[1]:.2e}, used={used[1]})"
           f"   full-vs-sym {float(np.linalg.norm(outs[0] - outs[1]) / np.linalg.norm(outs[0])):.2e}", flush=True)
