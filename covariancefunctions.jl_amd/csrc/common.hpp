@@ -238,7 +238,7 @@ grad_launch_fn grad_launcher(int family);
 // the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is ~1.7e-7 P per entry.
 constexpr int MFMA_LDS_MIN_TILES = 64;
 constexpr int64_t MFMA_SYM_MIN_N = 24000;   // below: the general kernel is as fast (tools/mfma_sym_ab.py: 16384 loses, 24000 wins 7-16 %)
-constexpr double MFMA_GATE = 128.0;
+constexpr double MFMA_GATE = 126.0;   // < 127: exp2 of the largest possible exponent |x~|max |y~|max must stay finite in fp32
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,

@@ -22,7 +22,7 @@
 //
 // Numerics.  This is NOT the reference's direct-difference r^2 (src/util.jl:40-47): the exponent x~.y~ - (|x~|^2+|y~|^2)/2
 // is formed from O(|x~||y~|) terms, so its absolute error is ~1e-7 |x~||y~| and the relative error of an entry
-// ~0.7e-7 |x~||y~|.  The path is therefore taken only when the host-side bound  max|x~| max|y~| <= MFMA_GATE (= 128:
+// ~0.7e-7 |x~||y~|.  The path is therefore taken only when the host-side bound  max|x~| max|y~| <= MFMA_GATE (= 126:
 // measured contribution to the MVM's relative error ~4e-9 per unit of the bound, i.e. <= 5e-7 against the 1e-5 fp32
 // tolerance of BASELINE.json; common.hpp) holds — the point-set norms are computed once when the covgram_points handle
 // is created — and otherwise the exact direct-difference kernel runs.

@@ -736,7 +736,7 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
 
 
 def test_eq_matrix_core_gate(cg, oracle):
-    """The expanded exponent is only used while max|x~| max|y~| <= 128, x~ = (x - c) / l relative to the set's own centre c
+    """The expanded exponent is only used while max|x~| max|y~| <= 126, x~ = (x - c) / l relative to the set's own centre c
     (its first point): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
     changes nothing; fp64 and the profiles that are not smooth in s never take it."""
     rng = np.random.default_rng(5)
@@ -752,6 +752,15 @@ def test_eq_matrix_core_gate(cg, oracle):
     Xg = (X0 * s).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xg).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xg, Xg, a, dtype=np.float32)) <= 2e-6
+    # the largest exponent the path can meet is x~_i . x~_i = P on the diagonal: exp2(125.9) is finite in fp32 (no inf / NaN)
+    s2 = np.sqrt(125.9 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0[0]) ** 2).sum(1).max())))
+    Xe = (X0 * s2).astype(np.float32)
+    for sym in (0, 1):
+        cg.set_option("mfma_sym", sym)
+        G = cg.gramian(cg.EQ(), torch.from_numpy(Xe).cuda()); b = (G @ ad).cpu().numpy()
+        if cg.get_info("last_dense_path") == 2:      # (float rounding of the bound may already send it to the exact kernel)
+            assert np.isfinite(b).all() and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xe, Xe, a, dtype=np.float32)) <= 2e-6
+    cg.set_option("mfma_sym", -1)
     # right above it: the exact kernel
     Xa = (X0 * (s * 1.02)).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xa).cuda()); b = (G @ ad).cpu().numpy()
