@@ -48,6 +48,44 @@ def test_random_dense_cases(cg, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(4))
+def test_random_symmetric_cases(cg, oracle, seed):
+    """gramian(k, x) with the symmetric upper-triangle kernels forced on (mfma_sym = 1, dense_variant = 2 where the shape allows):
+    every kernel case, random n around the 32-row tiles / 256-row panels / 64-tile chunks, random chunk splits, alpha / beta, the
+    multi-GPU partial form for a random world size — whatever path the library ends up taking must match the fp64 oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    cases = kernel_cases.cases(cg) + kernel_cases.composite_cases(cg)
+    try:
+        for _ in range(14):
+            name, k, ko = cases[rng.integers(len(cases))]
+            dt = [np.float32, np.float32, np.float64][rng.integers(3)]
+            d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16]))
+            n = int(rng.choice([1, 2, 31, 33, 255, 256, 257, 511, 513, 1000, 2047, 2049, 2600]))
+            alpha, beta = [(1.0, 0.0), (-0.7, 1.3), (2.0, 0.0)][rng.integers(3)]
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt)
+            a = rng.standard_normal(n).astype(dt); y0 = rng.standard_normal(n).astype(dt)
+            cg.set_option("mfma_sym", 1); cg.set_option("dense_variant", int(rng.choice([0, 2]))); cg.set_option("jsplit", int(rng.choice([0, 0, 2, 5])))
+            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+            G = cg.gramian(k, Xd)
+            yd = torch.from_numpy(y0.copy()).cuda()
+            if beta == 0.0:
+                yd.fill_(float("nan"))
+            cg.mul_(yd, G, ad, alpha, beta)
+            ref = oracle.mul(y0, ko, X, X, a, alpha, beta, dt)
+            tol = 2e-5 if dt == np.float32 else 1e-12
+            e = relerr(yd.cpu().numpy(), ref)
+            assert e <= tol or np.linalg.norm(ref) < 1e-30, (name, dt.__name__, d, n, alpha, beta, cg.get_info("last_mfma_sym"), e)
+            if hasattr(G, "sym_partial_supported") and G.sym_partial_supported():
+                world = int(rng.choice([2, 3, 5]))
+                tot = torch.zeros(n, dtype=torch.float32, device="cuda"); part = torch.empty_like(tot)
+                for r in range(world):
+                    G.sym_partial_(part, ad, r, world); tot += part
+                e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))
+                assert e <= tol, (name, d, n, world, e)
+    finally:
+        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0)
+
+
+@pytest.mark.parametrize("seed", range(4))
 def test_random_gradient_cases(cg, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     cases = kernel_cases.grad_cases(cg) + kernel_cases.composite_cases(cg)
