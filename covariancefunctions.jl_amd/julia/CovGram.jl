@@ -135,6 +135,21 @@ function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFac
     return y
 end
 
+# --- multi-GPU symmetric form (one Julia process per GPU, e.g. under MPI.jl; x and a replicated) -----------------------
+# rank r of `world` evaluates the upper-triangle tiles of gramian(k, x) in the 256-row panels p % world == r and returns the
+# partial product of those entries and their mirror images in `part` (device memory); an all-reduce (sum) of `part` over the
+# ranks is G * a.  `covgram_mvm_sym_supported` tells whether the symmetric matrix-core kernel serves (k, x) — it depends on k
+# and x only, so all ranks take the same branch; otherwise shard rows and all-gather (covgram_mvm on X[lo:hi] × X).
+function sym_partial!(part::Ptr{Cvoid}, G::Gramian, a::Ptr{Cvoid}, rank::Integer, world::Integer)
+    spec = lower(G.k); X = points(G.x, Float32)
+    ok = Ref{Int32}(0)
+    check(ccall((:covgram_mvm_sym_supported, libcovgram), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ref{Int32}), ctx(), spec, X.handle, ok))
+    ok[] == 1 || return false
+    check(ccall((:covgram_mvm_sym_partial, libcovgram), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32),
+                ctx(), spec, X.handle, a, part, Int32(rank), Int32(world)))
+    return true
+end
+
 # --- Sum / Product / Power with a common trait (src/algebra.jl:5-63, src/properties.jl:47-63) ---------------------
 # mirrors `covgram_kernel_composite`: k = head.scale * sum_t prod_f factors; every entry point above accepts a pointer to
 # its first member (`head`, family = 101) in place of a CKernel.  Lowering = flatten the Sum/Product tree to a sum of
