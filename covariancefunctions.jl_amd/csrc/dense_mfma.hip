@@ -509,13 +509,13 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
                                                                     const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
                                                                     float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
-                                                                    float beta, int32_t pfirst, int32_t pstride, int32_t use_e) {
+                                                                    float beta, int32_t pfirst, int32_t pstride, int32_t use_e, int32_t tpp) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     __shared__ float red[4][64];
     float s = 0.0f;
     if (i < n) {
-        const int64_t pi = i >> 8;                                                   // the row's panel (256 rows)
+        const int64_t pi = i / (32 * tpp);                                           // the row's panel (tpp row tiles: 256 or 128 rows)
         // local panels lp (global pfirst + pstride lp) up to the row's own panel
         const int64_t nlp = pi >= pfirst ? (pi - pfirst) / pstride + 1 : 0;
         for (int64_t lp = part; lp < nlp; lp += 4) s += S[lp * npad + i];
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float*
     __syncthreads();
     if (part != 0 || i >= n) return;
     const float cs = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    const int64_t pi = i >> 8;
-    const int64_t cfirst = (8 * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
+    const int64_t pi = i / (32 * tpp);
+    const int64_t cfirst = (tpp * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
     float rs = 0.0f;
     if (pi >= pfirst && (pi - pfirst) % pstride == 0)                                 // the row sums exist only where this rank owns the panel
         for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
@@ -542,9 +542,10 @@ __global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float*
 
 bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
     if (ctx->mfma_sym == 0 || X->dptr != Y->dptr || X->n != Y->n) return false;       // gramian(k, x): the same point set on both sides
-    if (!mfma_eq_eligible(ctx, hk, X, Y, nrhs) || X->d > 8) return false;
-    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + 7) / 8;
-    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)16 << 30)) return false;   // column-sum slab <= 16 GiB of the 288
+    if (!mfma_eq_eligible(ctx, hk, X, Y, nrhs)) return false;
+    const int tpp = X->d > 8 ? 4 : 8;                                                // row tiles per panel (dense_mfma_sym_wide_kernel: 4)
+    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
+    if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;   // column-sum slab <= 16 GiB of the 288
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
 }
 
@@ -555,9 +556,10 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     if (ctx->mfma_sym == 0 || nrhs != 1 || X->dptr != Y->dptr || X->n != Y->n) return false;
     if (!mfma_gen_eligible(ctx, hk, X, Y)) return false;
     const int k2 = mfma_k2_for(X->d + (hk.k.trait == COVGRAM_ISOTROPIC ? 1 : 0));
-    if (k2 < 0 || k2 > 4) return false;
-    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + 7) / 8;
-    if ((size_t)panels * (size_t)(panels * 256) * sizeof(float) > ((size_t)16 << 30)) return false;
+    if (k2 < 0) return false;
+    const int tpp = k2 > 4 ? 4 : 8;
+    const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
+    if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
 }
 
@@ -581,7 +583,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     const int K2 = fast ? (D + 1) / 2 : mfma_k2_for(d + (iso ? 1 : 0));
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
-    const int64_t ntile = (n + 31) / 32, panels = (ntile + 7) / 8, npad = panels * 256 + 1088;
+    const int tpp = K2 > 4 ? 4 : 8;                                  // row tiles per panel: 8 waves x 1 tile, or 4 x 1 for long fragments
+    const int64_t ntile = (n + 31) / 32, panels = (ntile + tpp - 1) / tpp, npad = panels * 32 * tpp + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
@@ -620,7 +623,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
     const int64_t lpanels = panels > pfirst ? (panels - pfirst + pstride - 1) / pstride : 0;   // this call's panels
     const int64_t tileops = (panels * ntile / 2 + panels * 4) / pstride;         // (panel, tile) visits
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 2 * 8;
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 8 ? 2 : 3) * 8;
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     // >= 64 tiles: shorter chunks do not amortise a workgroup's prologue (rows, row weights, first stage) — tools/sym_tchunk_sweep.py
     tchunk = std::max<int64_t>(64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
@@ -632,12 +635,12 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // the (local panel, absolute chunk) pairs that exist, chunk-major (the workgroups in flight share a chunk's fragments in
     // L2); cached in the context by its key
     CG_REQUIRE(maxc <= 4096 && lpanels < ((int64_t)1 << 19), COVGRAM_EUNSUPPORTED, "dense_mfma_sym: work list out of range");
-    const int64_t key[4] = {ntile, tchunk, pfirst, pstride};
+    const int64_t key[4] = {ntile, tchunk * 16 + tpp, pfirst, pstride};
     if (ctx->sym_map == nullptr || memcmp(ctx->sym_key, key, sizeof(key)) != 0) {
         std::vector<int32_t> list;
         for (int64_t c = 0; c < maxc; ++c)
             for (int64_t lp = 0; lp < lpanels; ++lp) {
-                const int64_t p8 = 8 * ((int64_t)pfirst + (int64_t)pstride * lp);
+                const int64_t p8 = tpp * ((int64_t)pfirst + (int64_t)pstride * lp);   // the panel's first tile
                 if (p8 >= (c + 1) * tchunk) break;                 // panels are ascending: the rest start right of this chunk
                 if (std::max(c * tchunk, p8) < ntile) list.push_back((int32_t)((lp << 12) | c));
             }
@@ -658,9 +661,13 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
                                                   KParams<float>{}); break;
+#define CG_SYMW_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
+                                                   KParams<float>{}); break;
     if (fast) {
         switch (K2) {
             CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
+            CG_SYMW_CASE(6) CG_SYMW_CASE(8) CG_SYMW_CASE(12) CG_SYMW_CASE(16)
             default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
         }
     } else {
@@ -675,10 +682,11 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         if (rc) return rc;
     }
 #undef CG_SYM_CASE
+#undef CG_SYMW_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d,
                        (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride,
-                       fast ? 1 : 0);
+                       fast ? 1 : 0, tpp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

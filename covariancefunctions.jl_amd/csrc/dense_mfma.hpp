@@ -354,6 +354,174 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 
+// ---- symmetric form, long fragments (K2 > 4: d = 9 .. 32): 4 waves x ONE row tile = a 128-row panel; ONE column tile per stage,
+// its K2 fragment slices fetched by the four waves in turn (the split-tile staging of dense_mfma_eq_kernel<.., LDS = 2>), one
+// barrier per tile.  Same chunks / slabs / masks / workgroup list as dense_mfma_sym_kernel, with 4 tiles per panel.
+template <int FAM, int K2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym_wide_kernel(
+    const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
+    float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const KParams<float> kp) {
+    constexpr bool FAST = (FAM == FAM_EQFAST);
+    constexpr bool ISO = FAST || fam_is_iso<FAM>;
+    constexpr int NW = 4;
+    const int32_t wm = wgmap[blockIdx.x];
+    const int64_t lp = wm >> 12;
+    const int64_t cabs = wm & 4095;
+    const int64_t p = pfirst + (int64_t)pstride * lp;
+    const int64_t T1a = (cabs + 1) * tchunk;
+    const int64_t T0 = (cabs * tchunk > NW * p) ? cabs * tchunk : NW * p;
+    if (T1a <= NW * p || T0 >= ntile) return;                      // (never for a listed pair; whole workgroup, before any barrier)
+    const int64_t T1 = T1a < ntile ? T1a : ntile;
+    const int nt = (int)(T1 - T0);
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t I0 = NW * p + wv;
+    const int64_t i0 = I0 * 32;
+    Frag a[K2];
+    float nx;
+    float u[16];
+    {
+        int64_t row = i0 + t;
+        if (row >= n) row = n - 1;
+        const float* __restrict__ xr = X + row * (int64_t)d;
+        float part = 0.0f;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int mm = 0; mm < K2; ++mm) {
+                const int c = 2 * mm + h;
+                const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
+                part = __builtin_fmaf(xt, xt, part);
+                unsigned x1, x2, x3;
+                split3(xt, x1, x2, x3);
+                a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+            }
+            nx = part + __shfl_xor(part, 32);
+        } else {
+            const float gg = kp.gamma;
+            if constexpr (ISO)
+                for (int cc = 0; cc < d; ++cc) { const float xc = gg * (xr[cc] - Cn[cc]); part = __builtin_fmaf(xc, xc, part); }
+#pragma unroll
+            for (int mm = 0; mm < K2; ++mm) {
+                const int c = 2 * mm + h;
+                uint4 f = make_uint4(0, 0, 0, 0);
+                if (c < d) {
+                    unsigned x1, x2, x3;
+                    split3(ISO ? gg * (xr[c] - Cn[c]) : gg * xr[c], x1, x2, x3);
+                    f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+                } else if (ISO && c == d) {
+                    unsigned n1, n2, n3;
+                    split3(part, n1, n2, n3);
+                    f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
+                }
+                a[mm].u = f;
+            }
+            nx = 0.0f;
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
+            const float keep = ri < n ? 1.0f : 0.0f;
+            if (ri >= n) ri = n - 1;
+            u[v] = W[ri] * keep;
+        }
+    }
+    float acc[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+
+    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
+    const float* __restrict__ wbase = W + T0 * 32;
+    __shared__ uint4 tfA[K2][64], tfB[K2][64];
+    __shared__ float twA[32], twB[32];
+    __shared__ float csA[NW][64], csB[NW][64];
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float gw = 0.0f;
+#define CG_DMA2(tile, TF)                                                                       \
+        {                                                                                       \
+            const int ti_ = (tile);                                                             \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int q = 0; q < (K2 + NW - 1) / NW; ++q) {                    \
+                const int mm = wv + q * NW;                                                     \
+                if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
+            }                                                                                   \
+            if (wv == 0) gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);                   \
+        }
+#define CG_TILE2(ti_, TF, TW, CS)                                                               \
+        {                                                                                       \
+            const int64_t J = T0 + (ti_);                                                       \
+            f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
+                Frag f; f.u = TF[mm][l];                                                        \
+                D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f.v, D, 0, 0, 0);          \
+            }                                                                                   \
+            const float w = TW[t];                                                              \
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                    \
+                if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);                        \
+                else {                                                                          \
+                    float s = D[v];                                                             \
+                    if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);                   \
+                    float kv = Phi<FAST ? COVGRAM_EQ : FAM, float, mfma_folded<FAST ? COVGRAM_EQ : FAM>>::eval(s, kp); \
+                    if (kp.power != 1) kv = ipow(kv, kp.power);                                 \
+                    D[v] = kv;                                                                  \
+                }                                                                               \
+            }                                                                                   \
+            const float wr = (J >= I0) ? w : 0.0f;                                              \
+            float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;                                   \
+            _Pragma("unroll") for (int v = 0; v < 16; v += 4) {                                 \
+                acc[v] = __builtin_fmaf(wr, D[v], acc[v]);                                      \
+                acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);                          \
+                acc[v + 2] = __builtin_fmaf(wr, D[v + 2], acc[v + 2]);                          \
+                acc[v + 3] = __builtin_fmaf(wr, D[v + 3], acc[v + 3]);                          \
+                c0 = __builtin_fmaf(u[v], D[v], c0);                                            \
+                c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);                                    \
+                c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);                                    \
+                c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);                                    \
+            }                                                                                   \
+            CS[wv][l] = (J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;                                \
+        }
+    // after the tile's barrier: one wave (they take turns) adds the 4 waves x 2 half-waves' column sums in fixed order
+#define CG_FLUSH2(ti_, CS)                                                                      \
+        if (wv == ((ti_) & (NW - 1)) && h == 0 && T0 + (ti_) < T1) {                            \
+            float s_ = 0.0f;                                                                    \
+            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][t] + CS[w_][32 + t]; \
+            S[lp * npad + 32 * (T0 + (ti_)) + t] = s_;                                          \
+        }
+    CG_DMA2(0, tfA)
+    if (wv == 0 && h == 0) twA[t] = gw;
+    __syncthreads();
+    for (int ti = 0; ti < nt; ti += 2) {
+        CG_DMA2(ti + 1, tfB)
+        if (ti > 0) CG_FLUSH2(ti - 1, csB)
+        CG_TILE2(ti, tfA, twA, csA)
+        if (wv == 0 && h == 0) twB[t] = gw;
+        __syncthreads();
+        if (ti + 1 >= nt) { CG_FLUSH2(ti, csA) break; }
+        CG_DMA2(ti + 2, tfA)
+        CG_FLUSH2(ti, csA)
+        CG_TILE2(ti + 1, tfB, twB, csB)
+        if (wv == 0 && h == 0) twA[t] = gw;
+        __syncthreads();
+        if (ti + 2 >= nt) { CG_FLUSH2(ti + 1, csB) }
+    }
+#undef CG_DMA2
+#undef CG_TILE2
+#undef CG_FLUSH2
+
+    const int vsel = (t & 3) + 4 * (t >> 3);
+    float tot = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float s = acc[v];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+        tot = (vsel == v) ? s : tot;
+    }
+    const int64_t i = i0 + t;
+    if (((t >> 2) & 1) != h || i >= n) return;
+    R[cabs * npad + i] = FAST ? __builtin_amdgcn_exp2f(-0.5f * nx) * tot : tot;
+}
+
 struct MfmaArgs {
     const float* X; int64_t n; int32_t d;
     const uint4* PB; const float* W; int64_t ntile;
@@ -390,17 +558,18 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
 
 template <int FAM, int K2>
 static int mfma_sym_one(const MfmaArgs& a) {
-    hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
-                       (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
+    if constexpr (K2 <= 4)
+        hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
+    else
+        hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
+                           a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
     return COVGRAM_OK;
 }
 
 template <int FAM, int K2>
 static int mfma_gen_K(const MfmaArgs& a, bool query) {
-    if (a.sym) {
-        if constexpr (K2 <= 4) return mfma_sym_one<FAM, K2>(a);
-        else { set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED; }
-    }
+    if (a.sym) return mfma_sym_one<FAM, K2>(a);
     if (a.NR == 4) return mfma_gen_one<FAM, K2, 1, 4>(a, query);
     if constexpr (K2 <= 4) { if (a.RT == 2) return mfma_gen_one<FAM, K2, 2, 1>(a, query); }
     return mfma_gen_one<FAM, K2, 1, 1>(a, query);

@@ -168,7 +168,7 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
  * gets the same share of the triangle — and returns in y (n scalars, device) the partial product of those entries AND their
  * mirror images; the partials of all ranks add up to G a, so ONE all-reduce (RCCL) completes b on every rank
  * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  Only where the symmetric
- * matrix-core kernel applies (fp32 EQ, d <= 8, norm gate, n >= 24000 or option "mfma_sym" = 1): `*supported` of
+ * matrix-core kernels apply (fp32, EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm gate, n >= 24000 or option "mfma_sym" = 1): `*supported` of
  * covgram_mvm_sym_supported says so (identically on every rank: it depends on k and x only), and
  * covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED otherwise — callers then shard rows and all-gather (covgram_mvm). */
 int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported);

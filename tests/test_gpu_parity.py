@@ -618,10 +618,11 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
     assert np.isfinite(b1).all()
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 9, 12, 16, 24, 32])
 def test_eq_symmetric_matrix_core_kernel(cg, oracle, d):
     """gramian(EQ, x) on the matrix cores with the upper triangle evaluated once (row sums + column sums of the same tiles,
-    mfma_sym = 1): ragged n (row tiles, 256-row panels and 4/8-tile stages all end past n), ragged column chunks (jsplit),
+    mfma_sym = 1; d > 8: the 128-row-panel kernel with one tile per stage): ragged n (row tiles, panels and stages all end
+    past n), ragged column chunks (jsplit),
     alpha / beta, NaN in y with beta = 0, against the fp64 oracle and against the full kernel; a Gramian of two different
     point sets never takes it."""
     rng = np.random.default_rng(900 + d)
@@ -674,7 +675,8 @@ def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
                     G.sym_partial_(part, ad, r, world)
                     tot += part
                 assert relerr(tot.cpu().numpy(), want) <= 1e-5, (n, d, world, relerr(tot.cpu().numpy(), want))
-        assert not cg.gramian(cg.MaternP(2), Xd).sym_partial_supported()
+        assert cg.gramian(cg.MaternP(2), Xd).sym_partial_supported()             # every smooth matrix-core profile
+        assert not cg.gramian(cg.Exp(), Xd).sym_partial_supported()                # not differentiable in s at 0: direct differences only
         assert not cg.gramian(cg.EQ(), Xd.double()).sym_partial_supported()
         assert not cg.gramian(cg.EQ(), Xd, Xd.clone()).sym_partial_supported()
         cg.set_option("mfma_sym", -1)
@@ -683,7 +685,7 @@ def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
         cg.set_option("mfma_sym", -1)
 
 
-@pytest.mark.parametrize("d", [1, 3, 6, 7])
+@pytest.mark.parametrize("d", [1, 3, 6, 7, 8, 12, 20, 31])
 def test_generic_symmetric_matrix_core_kernels(cg, oracle, d):
     """The other matrix-core profiles on gramian(k, x) with the upper triangle evaluated once (mfma_sym = 1): RQ, Cauchy, IMQ,
     MaternP(1..3), Dot^p, ExponentialDot, EQ^2 — against the fp64 oracle and against the general matrix-core kernel, ragged n,
