@@ -786,6 +786,10 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PB; ma.W = W; ma.ntile = ntile; ma.out = out; ma.npad = npad; ma.ldy = ldy;
         ma.nrhs = nr; ma.tchunk = tchunk; ma.alpha = (float)alpha_eff; ma.beta = (float)beta; ma.final_store = js == 1 ? 1 : 0;
         ma.grid = dim3((unsigned)rowtiles, (unsigned)js);
+        // long fragments (d > 8) and long column chunks: four waves share every column tile through LDS, one tile per stage
+        // (tools/mfma_lds_ab.py <kernel>: 11-28 % faster at d = 12 .. 24; at d <= 8 the barrier per tile costs 5-18 %, so not there)
+        ma.lds = (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && K2 > 4 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64)) ? 1 : 0;
+        ctx->last_mfma_lds = ma.lds;
         auto* tm = timer_next(ctx);
         if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(ma, false);

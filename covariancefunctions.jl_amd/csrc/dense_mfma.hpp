@@ -42,15 +42,18 @@ constexpr unsigned BF16_ONE = 0x3F80u;
 // rescaled tables: exp2 of the MFMA result, no multiplications in front) — the host passes make_host_kernel(.., for_gradient = false)
 template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
 
-template <int FAM, int K2, int RT, int NR>
-__global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+// LDS = 0: one wave per workgroup, its own fragment loads; LDS = 2: four waves on consecutive row tiles share every column tile
+// through LDS, one tile per stage, its K2 fragment slices fetched by the waves in turn (as dense_mfma_eq_kernel<.., 4, 2>)
+template <int FAM, int K2, int RT, int NR, int LDS = 0>
+__global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
                                                             int64_t tchunk, float alpha, float beta, int32_t final_store,
                                                             const float* __restrict__ Cn, const KParams<float> kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
-    const int l = threadIdx.x, t = l & 31, h = l >> 5;
-    const int64_t i0 = (int64_t)blockIdx.x * (32 * RT);
+    constexpr int WPB = LDS ? 4 : 1;
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * (32 * RT);
     const float g = kp.gamma;
     Frag a[RT][K2];
 #pragma unroll
@@ -115,6 +118,52 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
             }
         }
     };
+    if constexpr (LDS == 2) {
+        __shared__ uint4 tfA[K2][64], tfB[K2][64];
+        __shared__ float twA[NR][32], twB[NR][32];
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        float gw[NR];
+#define CG_DMA2(tile, TF)                                                                       \
+        {                                                                                       \
+            const int ti_ = (tile);                                                             \
+            const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
+            _Pragma("unroll") for (int q = 0; q < (K2 + WPB - 1) / WPB; ++q) {                  \
+                const int mm = wv + q * WPB;                                                    \
+                if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
+            }                                                                                   \
+            if (wv == WPB - 1) {                                                                \
+                _Pragma("unroll") for (int c = 0; c < NR; ++c) gw[c] = wbase[(tc_ * NR + c) * 32 + t] * (ti_ < nt ? 1.0f : 0.0f); \
+            }                                                                                   \
+        }
+#define CG_PUTW(TW) if (wv == WPB - 1 && h == 0) { _Pragma("unroll") for (int c = 0; c < NR; ++c) TW[c][t] = gw[c]; }
+#define CG_TILE2(TF, TW)                                                                        \
+        {                                                                                       \
+            Frag f[K2];                                                                         \
+            float w[NR];                                                                        \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f[mm].u = TF[mm][l];              \
+            _Pragma("unroll") for (int c = 0; c < NR; ++c) w[c] = TW[c][t];                     \
+            process(f, w);                                                                      \
+        }
+        CG_DMA2(0, tfA)
+        CG_PUTW(twA)
+        __syncthreads();
+        for (int ti = 0; ti < nt; ti += 2) {
+            CG_DMA2(ti + 1, tfB)                                    // past the chunk: a re-fetch nobody reads
+            CG_TILE2(tfA, twA)
+            CG_PUTW(twB)
+            __syncthreads();
+            if (ti + 1 >= nt) break;
+            CG_DMA2(ti + 2, tfA)
+            CG_TILE2(tfB, twB)
+            CG_PUTW(twA)
+            __syncthreads();
+        }
+#undef CG_DMA2
+#undef CG_PUTW
+#undef CG_TILE2
+    } else {
     Frag f0[K2], f1[K2];
     float w0[NR], w1[NR];
     load_tile(0, f0, w0);
@@ -123,6 +172,7 @@ __global__ __launch_bounds__(64) void dense_mfma_gen_kernel(const float* __restr
         process(f0, w0);
         load_tile(ti + 2, f0, w0);
         if (ti + 1 < nt) process(f1, w1);
+    }
     }
 
     const int vsel = (t & 3) + 4 * (t >> 3);
@@ -533,6 +583,7 @@ struct MfmaArgs {
     dim3 grid;
     const float* Cn = nullptr;   // common centre of isotropic kernels (dense_mvm.hpp)
     // symmetric form (dense_mfma_sym_kernel): row-sum slab R, column-sum slab S, the explicit workgroup list
+    int32_t lds = 0;             // 1: dense_mfma_gen_kernel<.., LDS = 2> (grid.x counts workgroups of 4 waves)
     int32_t sym = 0;
     float* R = nullptr; float* S = nullptr;
     const int32_t* wgmap = nullptr;
@@ -551,8 +602,13 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
         }
         return cached;
     }
-    hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out, a.npad,
-                       a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, cast_params<float>(a.hk->kp));
+    if (a.lds)
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
+                           a.PB, a.W, a.ntile, a.out, a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn,
+                           cast_params<float>(a.hk->kp));
+    else
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
+                           a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, cast_params<float>(a.hk->kp));
     return COVGRAM_OK;
 }
 

@@ -819,8 +819,18 @@ def test_generic_matrix_core_path(cg, oracle, d):
                         got[variant] = yd.cpu().numpy()
                         assert relerr(got[variant], ref) <= 1e-5, (name, d, n, p, variant, relerr(got[variant], ref))
                     assert relerr(got[2], got[1]) <= 5e-6, (name, d, n, p)
+                    # four waves sharing every column tile through LDS (what long column chunks get): bit-identical
+                    for js in (0, 3):
+                        cg.set_option("mfma_lds", 1); cg.set_option("jsplit", js)
+                        yl = torch.from_numpy(Y0.copy()).cuda()
+                        cg.mul_(yl, G, torch.from_numpy(A).cuda(), -0.7, 1.3)
+                        assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_lds") == 1
+                        assert relerr(yl.cpu().numpy(), ref) <= 1e-5, (name, d, n, p, js)
+                        if js == 0:
+                            assert np.array_equal(yl.cpu().numpy(), got[2]), (name, d, n, p)
+                    cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
     finally:
-        cg.set_option("dense_variant", 0)
+        cg.set_option("dense_variant", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
 
 
 # ---- (f)-3 / (f)-4: factorizations and Toeplitz solves on top of the hot path -------------------------------------------
