@@ -26,7 +26,18 @@
 // measured contribution to the MVM's relative error ~4e-9 per unit of the bound, i.e. <= 5e-7 against the 1e-5 fp32
 // tolerance of BASELINE.json; common.hpp) holds — the point-set norms are computed once when the covgram_points handle
 // is created — and otherwise the exact direct-difference kernel runs.
+// (x~ is taken relative to the column set's own centre — common.hpp, covgram_points::center — so the bound does not depend on
+// where the cloud sits; 126 < 127 also keeps exp2 of the largest exponent finite.)
 // Option "dense_variant": 0 = this rule, 1 = always direct differences, 2 = MFMA whenever the shape allows (tests).
+//
+// Kernels in this file and in dense_mfma.hpp (one path each, chosen on the host in covgram_mvm):
+//   dense_mfma_eq_kernel<K2, RT, WPB, LDS>   EQ, any X / Y.  LDS = 0: one wave per workgroup with its own fragment loads;
+//                                            LDS = 1 (d <= 8) / 2 (d > 8): four waves share the column tiles through LDS
+//                                            (global_load_lds DMA, double buffered) when the column chunks are long.
+//   dense_mfma_gen_kernel<FAM, ...>          RQ, Cauchy, IMQ, MaternP, Dot^p, ExponentialDot, EQ^p, several right-hand sides:
+//                                            the MFMA yields the profile argument s (dense_mfma.hpp).
+//   dense_mfma_sym_kernel / _sym_wide_kernel gramian(k, x), one point set: the upper triangle once, row AND column sums
+//                                            ("Symmetric Gramian" below); also rank r of P's share for the multi-GPU form.
 #include "dense_mfma.hpp"
 
 namespace covgram {
