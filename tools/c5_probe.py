@@ -1,0 +1,16 @@
+"""C5 (Exponential Toeplitz, n = 2^22) fp64 and fp32: time per MVM, back-to-back."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "covariancefunctions.jl_amd"))
+import covgram as cg
+n = 1 << 22
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+for dt in (torch.float64, torch.float32):
+    T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n, dtype=dt))
+    a = torch.randn(n, dtype=T.dtype, device="cuda"); y = torch.empty_like(a)
+    for _ in range(10): T.mul_(y, a)
+    torch.cuda.synchronize(); ts = []
+    for rep in range(5):
+        e0.record()
+        for _ in range(50): T.mul_(y, a)
+        e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 50 * 1e3)
+    print(f"C5 {T.dtype}: median {np.median(ts):.1f} us  min {min(ts):.1f} us")
