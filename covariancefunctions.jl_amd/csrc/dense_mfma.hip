@@ -735,7 +735,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 // generic profiles / several right-hand sides (dense_mfma.hpp)
 // ------------------------------------------------------------------------------------------------------------------------
 #define CG_DECL(n) int launch_mfma_family_##n(const MfmaArgs&, bool query);
-CG_DECL(0) CG_DECL(2) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8)
+CG_DECL(0) CG_DECL(2) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(11) CG_DECL(12)
 #undef CG_DECL
 
 mfma_launch_fn mfma_launcher(int family) {
@@ -747,6 +747,8 @@ mfma_launch_fn mfma_launcher(int family) {
         case COVGRAM_MATERNP: return launch_mfma_family_6;
         case COVGRAM_DOT: return launch_mfma_family_7;
         case COVGRAM_EXPDOT: return launch_mfma_family_8;
+        case FAM_EXPR_ISO: return launch_mfma_family_11;          // Sum / Product / Power composites of the profiles above
+        case FAM_EXPR_DOT: return launch_mfma_family_12;
         default: return nullptr;
     }
 }
@@ -760,9 +762,37 @@ static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coord
 
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y) {
     if (ctx->dense_variant == 1 || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
-    if (hk.tu_family >= COVGRAM_NFAMILY || mfma_launcher(hk.tu_family) == nullptr) return false;
+    if (mfma_launcher(hk.tu_family) == nullptr) return false;
     if (hk.tu_family == COVGRAM_MATERNP && hk.k.p < 1) return false;          // MaternP(0) = Exp: not differentiable in s at 0
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
+    if (hk.tu_family >= COVGRAM_NFAMILY) {
+        // composite: every factor must be one of the smooth matrix-core profiles, and the relative errors of a product add up:
+        // the largest sum over a term's factors of (sensitivity x power / l^2) takes the place of the single profile's
+        if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
+        double worst = 0.0;
+        int fi = 0;
+        for (int t = 0; t < hk.nterms; ++t) {
+            double sum = 0.0;
+            for (int f = 0; f < hk.nfac[t]; ++f, ++fi) {
+                const KParams<double>& q = hk.fkp[fi];
+                double sens;
+                switch (hk.ffam[fi]) {
+                    case COVGRAM_EQ: case COVGRAM_RQ: sens = 0.5; break;
+                    case COVGRAM_CAUCHY: sens = 1.0; break;
+                    case COVGRAM_IMQ: sens = 0.5 / q.param; break;                 // param holds c^2
+                    case COVGRAM_MATERNP: if (q.p < 1) return false; sens = fabs(q.mp_d1) > 0.5 ? fabs(q.mp_d1) : 0.5; break;
+                    case COVGRAM_DOT: case COVGRAM_EXPDOT: sens = 0.0; break;
+                    default: return false;                                     // Exp, gammaExp, Matern(nu), asin: direct differences only
+                }
+                sum += sens * q.power * q.gamma2;
+            }
+            worst = std::max(worst, sum);
+        }
+        if (ctx->dense_variant == 2) return true;
+        if (!iso) return sqrt(X->max_norm2) * sqrt(Y->max_norm2) < 1e30;
+        const double Pn = centred_radius(X, Y) * sqrt(Y->max_cnorm2);          // natural units: every factor has its own 1 / l^2
+        return worst * Pn <= 0.5 * MFMA_GATE / 1.4426950408889634074;
+    }
     if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
     if (ctx->dense_variant == 2) return true;
     const double P = (iso ? centred_radius(X, Y) * sqrt(Y->max_cnorm2) : sqrt(X->max_norm2) * sqrt(Y->max_norm2)) /

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
                                                             int64_t tchunk, float alpha, float beta, int32_t final_store,
-                                                            const float* __restrict__ Cn, const KParams<float> kp) {
+                                                            const float* __restrict__ Cn, const typename ParamsOf<FAM, float>::type kp) {
     constexpr bool ISO = fam_is_iso<FAM>;
     constexpr int WPB = LDS ? 4 : 1;
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
@@ -107,6 +107,16 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D, 0, 0, 0);
+            if constexpr (fam_is_expr<FAM>) {                                       // composite: all 16 entries factor by factor
+                float sv[16], kv[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v];
+                expr_value_block<float, ISO, 16>(sv, kp, kv);
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv[v], acc[r][c][v]);
+            } else {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 float s = D[v];
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
                 if (kp.power != 1) kv = ipow(kv, kp.power);
 #pragma unroll
                 for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv, acc[r][c][v]);
+            }
             }
         }
     };
@@ -208,12 +219,14 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
 // FAM = FAM_EQFAST: the EQ form of dense_mfma.hip (exponent straight from the MFMA, norms in the weights); any other family:
 // the generic form above (the MFMA yields the profile argument s, the norms ride in a pseudo-coordinate, weights are a_j).
 constexpr int FAM_EQFAST = 1000;
+template <int FAM> struct SymParamsOf { using type = typename ParamsOf<FAM, float>::type; };
+template <> struct SymParamsOf<FAM_EQFAST> { using type = KParams<float>; };
 
 template <int FAM, int K2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const KParams<float> kp) {
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp) {
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
@@ -308,6 +321,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
+        if constexpr (fam_is_expr<FAM>) {                                           // composite: all 16 entries factor by factor
+            float sv[16], kv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v];
+            expr_value_block<float, ISO, 16>(sv, kp, kv);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[v] = kv[v];
+        } else {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);
@@ -318,6 +339,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (kp.power != 1) kv = ipow(kv, kp.power);
                 D[v] = kv;
             }
+        }
         }
         const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
@@ -411,7 +433,7 @@ template <int FAM, int K2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym_wide_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const KParams<float> kp) {
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp) {
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     constexpr int NW = 4;
@@ -507,6 +529,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f.v, D, 0, 0, 0);          \
             }                                                                                   \
             const float w = TW[t];                                                              \
+            if constexpr (fam_is_expr<FAM>) {                                                   \
+                float sv[16], kv[16];                                                           \
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v]; \
+                expr_value_block<float, ISO, 16>(sv, kp, kv);                                   \
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = kv[v];                    \
+            } else {                                                                            \
             _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                    \
                 if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);                        \
                 else {                                                                          \
@@ -516,6 +544,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     if (kp.power != 1) kv = ipow(kv, kp.power);                                 \
                     D[v] = kv;                                                                  \
                 }                                                                               \
+            }                                                                                   \
             }                                                                                   \
             const float wr = (J >= I0) ? w : 0.0f;                                              \
             float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;                                   \
@@ -605,10 +634,10 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
     if (a.lds)
         hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
                            a.PB, a.W, a.ntile, a.out, a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn,
-                           cast_params<float>(a.hk->kp));
+                           make_params<FAM, float>(*a.hk));
     else
         hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
-                           a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, cast_params<float>(a.hk->kp));
+                           a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
     return COVGRAM_OK;
 }
 
@@ -616,10 +645,10 @@ template <int FAM, int K2>
 static int mfma_sym_one(const MfmaArgs& a) {
     if constexpr (K2 <= 4)
         hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
-                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
+                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk));
     else
         hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
-                           a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, cast_params<float>(a.hk->kp));
+                           a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk));
     return COVGRAM_OK;
 }
 

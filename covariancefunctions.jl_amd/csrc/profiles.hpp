@@ -503,6 +503,45 @@ __device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& 
         v += p0; d1 += p1; d2 += p2;
     }
 }
+// N composite values at once, factor-outer, for the matrix-core tiles (a lane's 16 entries of a 32 x 32 tile): parameters and
+// family dispatch once per factor and tile.  Only the profiles that are smooth in s at 0 (the host admits no others here).
+template <typename T, bool ISO, int N>
+__device__ __forceinline__ void expr_value_block(const T (&s)[N], const ExprParams<T>& ep, T (&out)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = (T)0;
+    int fi = 0;
+    for (int t = 0; t < ep.nterms; ++t) {
+        T prod[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) prod[i] = ep.coef[t];
+        for (int f = 0; f < ep.nfac[t]; ++f, ++fi) {
+            const KParams<T>& q = ep.f[fi];
+            const T g2 = ISO ? q.gamma2 : (T)1;
+            const int pw = q.power;
+#define CG_EXPRV_CASE(F)                                                                                            \
+    case F:                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {                                                             \
+            T v = Phi<F, T, false>::eval(s[i] * g2, q);                                                             \
+            if (pw != 1) v = ipow(v, pw);                                                                           \
+            prod[i] *= v;                                                                                           \
+        }                                                                                                           \
+        break;
+            switch (ep.fam[fi]) {
+                CG_EXPRV_CASE(COVGRAM_EQ)
+                CG_EXPRV_CASE(COVGRAM_RQ)
+                CG_EXPRV_CASE(COVGRAM_CAUCHY)
+                CG_EXPRV_CASE(COVGRAM_IMQ)
+                CG_EXPRV_CASE(COVGRAM_MATERNP)
+                CG_EXPRV_CASE(COVGRAM_EXPDOT)
+                default:
+                    CG_EXPRV_CASE(COVGRAM_DOT)
+            }
+#undef CG_EXPRV_CASE
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] += prod[i];
+    }
+}
 // The composite jet for a block of BG column groups, factor-outer (the gradient counterpart of expr_accumulate_block):
 // parameters and family dispatch once per factor and block.
 template <typename T, bool ISO, int BG>
