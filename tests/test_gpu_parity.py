@@ -470,6 +470,41 @@ def test_plain_sums_run_term_by_term(cg, oracle, dtype):
                 cg.set_option("composite_termwise", 1)
 
 
+@pytest.mark.parametrize("d", [2, 5, 12])
+def test_product_kernels_on_the_matrix_cores(cg, oracle, d):
+    """Products / powers of smooth profiles (src/algebra.jl:28-63) as ONE composite on the generic matrix-core kernels (general,
+    LDS-shared for d > 8, symmetric), against the oracle and the direct-difference interpreter; a product with a profile that is
+    not smooth in s (Exp) stays on direct differences."""
+    o = oracle
+    rng = np.random.default_rng(7000 + d)
+    prods = [(cg.EQ() * cg.Lengthscale(cg.Cauchy(), 1.5), o.Composite(((o.Kernel(o.EQ), o.Kernel(o.CAUCHY, lengthscale=1.5)),), o.ISOTROPIC, 1.0)),
+             (1.7 * cg.Lengthscale(cg.MaternP(2), 1.4) * cg.RQ(1.5) ** 2,
+              o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=1.4), o.Kernel(o.RQ, param=1.5, power=2)),), o.ISOTROPIC, 1.7)),
+             (cg.Dot() ** 2 * cg.ExponentialDot(), o.Composite(((o.Kernel(o.DOT, power=2), o.Kernel(o.EXPDOT)),), o.DOTPRODUCT, 1.0))]
+    try:
+        for n, m in ((200, 333), (777, 777)):
+            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+            Y = X if n == m else (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+            a = rng.standard_normal(m).astype(np.float32); A3 = rng.standard_normal((m, 3)).astype(np.float32)
+            Xd = torch.from_numpy(X).cuda(); Yd = Xd if n == m else torch.from_numpy(Y).cuda()
+            for k, ko in prods:
+                G = cg.gramian(k, Xd) if n == m else cg.gramian(k, Xd, Yd)
+                ref = o.mul(None, ko, X, Y, a, dtype=np.float32); ref3 = o.mul(None, ko, X, Y, A3, dtype=np.float32)
+                got = {}
+                for variant, sym, lds in ((1, 0, -1), (2, 0, 0), (2, 0, 1), (2, 1, -1)):
+                    cg.set_option("dense_variant", variant); cg.set_option("mfma_sym", sym); cg.set_option("mfma_lds", lds)
+                    got[(variant, sym, lds)] = (G @ torch.from_numpy(a).cuda()).cpu().numpy()
+                    assert cg.get_info("last_dense_path") == (1 if variant == 1 else 2)
+                    assert cg.get_info("last_mfma_sym") == (1 if (sym == 1 and n == m) else 0)
+                    assert relerr(got[(variant, sym, lds)], ref) <= 1e-5, (d, n, variant, sym, lds, relerr(got[(variant, sym, lds)], ref))
+                    assert relerr((G @ torch.from_numpy(A3).cuda()).cpu().numpy(), ref3) <= 1e-5
+                assert np.array_equal(got[(2, 0, 0)], got[(2, 0, 1)])
+        cg.set_option("dense_variant", 0); cg.set_option("mfma_sym", -1); cg.set_option("mfma_lds", -1)
+        (cg.gramian(cg.EQ() * cg.Exp(), Xd) @ torch.from_numpy(a).cuda()); assert cg.get_info("last_dense_path") == 1
+    finally:
+        cg.set_option("dense_variant", 0); cg.set_option("mfma_sym", -1); cg.set_option("mfma_lds", -1)
+
+
 def test_composite_golden_and_toeplitz(cg, oracle):
     g = np.load(f"{GOLD}/composite.npz")
     for d in (1, 3, 8):
