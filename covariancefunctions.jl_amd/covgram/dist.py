@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 
 # The symmetric form pays from ~1e9 evaluated pairs per rank (tools/sym_shard_probe.py, n = 131072 on one GPU emulating rank r of
-# P: 653 vs 778 us per rank at P = 2, 351 vs 405 at P = 4, 197-206 vs 221 at P = 8; below that its 8-wave workgroups leave the
+# P: 636 vs 820 us per rank at P = 2, 333 vs 427 at P = 4, 173-199 vs 226 at P = 8; below that its 8-wave workgroups leave the
 # chip under-filled) — its all-reduce moves n scalars per rank where the all-gather moves n / P, a few microseconds apart at these sizes.
 SYM_MIN_PAIRS_PER_RANK = 1.0e9
 

@@ -662,10 +662,13 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
     const int64_t lpanels = panels > pfirst ? (panels - pfirst + pstride - 1) / pstride : 0;   // this call's panels
     const int64_t tileops = (panels * ntile / 2 + panels * 4) / pstride;         // (panel, tile) visits
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 8 ? 2 : 3) * 8;
+    // ~8 rounds of the resident workgroups, ~4 for one rank's share of a multi-GPU MVM (the list below puts the cut, shorter
+    // chunks last, so the last round balances); >= 64 tiles — shorter chunks do not amortise a workgroup's prologue (rows, row
+    // weights, first stage) —, >= 128 for a rank's share (tools/sym_tchunk_sweep.py, tools/sym_shard_probe.py: rank r of 8 at
+    // C2 size 170-185 us with 128-tile chunks, 183-201 with 64)
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 8 ? 2 : 3) * (pstride > 1 ? 4 : 8);
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
-    // >= 64 tiles: shorter chunks do not amortise a workgroup's prologue (rows, row weights, first stage) — tools/sym_tchunk_sweep.py
-    tchunk = std::max<int64_t>(64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
+    tchunk = std::max<int64_t>(pstride > 1 ? 128 : 64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
     void *Rp, *Sp;
     rc = ws_reserve(ctx, 1, (size_t)maxc * npad * sizeof(float), &Rp); if (rc) return rc;
@@ -676,13 +679,26 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     CG_REQUIRE(maxc <= 4096 && lpanels < ((int64_t)1 << 19), COVGRAM_EUNSUPPORTED, "dense_mfma_sym: work list out of range");
     const int64_t key[4] = {ntile, tchunk * 16 + tpp, pfirst, pstride};
     if (ctx->sym_map == nullptr || memcmp(ctx->sym_key, key, sizeof(key)) != 0) {
-        std::vector<int32_t> list;
+        // whole chunks first (chunk-major), then the cut ones (a panel's first chunk, the last chunk of the row): the short
+        // workgroups fill the last round instead of leaving most of the chip idle behind a few long ones
+        std::vector<int32_t> list, tail;
         for (int64_t c = 0; c < maxc; ++c)
             for (int64_t lp = 0; lp < lpanels; ++lp) {
                 const int64_t p8 = tpp * ((int64_t)pfirst + (int64_t)pstride * lp);   // the panel's first tile
                 if (p8 >= (c + 1) * tchunk) break;                 // panels are ascending: the rest start right of this chunk
-                if (std::max(c * tchunk, p8) < ntile) list.push_back((int32_t)((lp << 12) | c));
+                const int64_t t0 = std::max(c * tchunk, p8), t1 = std::min((c + 1) * tchunk, ntile);
+                if (t0 >= ntile) continue;
+                ((t1 - t0 == tchunk) ? list : tail).push_back((int32_t)((lp << 12) | c));
             }
+        std::sort(tail.begin(), tail.end(), [&](int32_t u, int32_t v) {   // longer cut chunks first
+            auto len = [&](int32_t w) {
+                const int64_t lp = w >> 12, c = w & 4095, p8 = tpp * ((int64_t)pfirst + (int64_t)pstride * lp);
+                return std::min((c + 1) * tchunk, ntile) - std::max(c * tchunk, p8);
+            };
+            const int64_t lu = len(u), lv = len(v);
+            return lu != lv ? lu > lv : u < v;
+        });
+        list.insert(list.end(), tail.begin(), tail.end());
         if (list.size() > ctx->sym_map_cap) {
             if (ctx->sym_map) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->sym_map); ctx->sym_map = nullptr; }
             ctx->sym_map_cap = std::max<size_t>(list.size(), 4096);

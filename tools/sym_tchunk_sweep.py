@@ -8,7 +8,7 @@ for n in [int(v) for v in sys.argv[1:]] or (40000, 49152, 65536, 90000):
     G = cg.gramian(cg.EQ(), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
     T = (n + 31) // 32
     out = []
-    for tc in (256, 192, 128, 96, 64, 48, 32, 0, 32):
+    for tc in (1024, 512, 256, 192, 128, 96, 64, 0):
         cg.set_option("mfma_sym", 1); cg.set_option("jsplit", 0 if tc == 0 else max(1, -(-T // tc)))
         for _ in range(3): G.mul_(y, a)
         torch.cuda.synchronize(); e0.record()
