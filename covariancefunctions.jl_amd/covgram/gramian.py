@@ -285,7 +285,11 @@ class Gramian(LazyOperator):
         return isinstance(self.k, (K.MercerKernel, K.MultiKernel)) and self.issymmetric()               # :135-137
 
     def _spec(self):
-        return K.require_device_spec(self.k)
+        # lowered once per Gramian: like the reference's Gramian{T, K, ...}, which holds an immutable kernel by value
+        sp = getattr(self, "_spec_cached", None)
+        if sp is None:
+            sp = self._spec_cached = K.require_device_spec(self.k)
+        return sp
 
     # -- products ---------------------------------------------------------------------------------
     def mul_(self, y, a, alpha=1.0, beta=0.0):
