@@ -545,24 +545,28 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 // ------------------------------------------------------------------------------------------------------------------------
 // b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order.
 // 64 rows per workgroup, the panel index strided over the 4 waves (as dense_reduce_kernel).
-__global__ __launch_bounds__(256) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
+__global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
                                                                     const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
                                                                     float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
                                                                     float beta, int32_t pfirst, int32_t pstride, int32_t use_e, int32_t tpp) {
+    // 64 rows per workgroup, the panel index strided over 16 waves (hundreds of panels per row: many independent loads in flight)
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     float s = 0.0f;
     if (i < n) {
         const int64_t pi = i / (32 * tpp);                                           // the row's panel (tpp row tiles: 256 or 128 rows)
         // local panels lp (global pfirst + pstride lp) up to the row's own panel
         const int64_t nlp = pi >= pfirst ? (pi - pfirst) / pstride + 1 : 0;
-        for (int64_t lp = part; lp < nlp; lp += 4) s += S[lp * npad + i];
+#pragma unroll 4
+        for (int64_t lp = part; lp < nlp; lp += 16) s += S[lp * npad + i];
     }
     red[part][lane] = s;
     __syncthreads();
     if (part != 0 || i >= n) return;
-    const float cs = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float cs = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cs += red[q][lane];                                  // fixed order
     const int64_t pi = i / (32 * tpp);
     const int64_t cfirst = (tpp * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
     float rs = 0.0f;
@@ -739,7 +743,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #undef CG_SYM_CASE
 #undef CG_SYMW_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
-    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d,
+    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, (const float*)X->dptr, n, d,
                        (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride,
                        fast ? 1 : 0, tpp);
     hipError_t e = hipGetLastError();
