@@ -49,7 +49,7 @@ namespace covgram {
 //   W[32 T + r]                = a_j * exp2(-|g y_j|^2 / 2)                     (0 for padding columns)
 __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
                                                         uint4* __restrict__ PB, float* __restrict__ W, int32_t K2, float g,
-                                                        const float* __restrict__ Cn) {
+                                                        const float* __restrict__ Cn, float* __restrict__ E0) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -63,14 +63,16 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     unsigned y1, y2, y3;
     split3(yt, y1, y2, y3);
     PB[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
-    if (mm == 0 && l < 32) {
-        float w = 0.0f;
+    if (mm == 0 && l < 32) {                                       // W[j] = a_j e_j (this MVM), E0[j] = e_j (kept with the fragments)
+        float w = 0.0f, ej = 0.0f;
         if (j < m) {
             float ny = 0.0f;
             for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
-            w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
+            ej = __builtin_amdgcn_exp2f(-0.5f * ny);
+            if (W) w = A[j] * ej;
         }
-        W[j] = w;
+        if (W) W[j] = w;
+        E0[j] = ej;
     }
 }
 
@@ -472,12 +474,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     float* W = (float*)Wp;
     if (Y->frag_cache == nullptr || Y->frag_bytes != fbytes || Y->frag_g != g || Y->frag_k2 != K2) {
         if (Y->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(Y->frag_cache); Y->frag_cache = nullptr; }
-        hipError_t me = hipMalloc(&Y->frag_cache, fbytes);
+        hipError_t me = hipMalloc(&Y->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));   // fragments + e_j (symmetric kernel)
         if (me != hipSuccess) { Y->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
         Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
-                           (uint4*)Y->frag_cache, W, K2, g, Cn);
+                           (uint4*)Y->frag_cache, W, K2, g, Cn, (float*)((char*)Y->frag_cache + fbytes));
     } else {
         hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, W,
                            ntile * 32, g, Cn);
@@ -634,24 +636,23 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     int rc;
     float* W;
     const uint4* PBu;
+    const float* E0 = nullptr;
     if (fast) {
-        void* Wp;
-        rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
-        if (rc) return rc;
-        W = (float*)Wp;
+        // the fragments AND e_j = exp2(-|x~_j|^2 / 2) are cached in the points handle; the kernel forms a_j e_j itself, so a
+        // steady-state MVM launches no pack kernel
         if (X->frag_cache == nullptr || X->frag_bytes != fbytes || X->frag_g != g || X->frag_k2 != K2) {
             if (X->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(X->frag_cache); X->frag_cache = nullptr; }
-            hipError_t me = hipMalloc(&X->frag_cache, fbytes);
+            hipError_t me = hipMalloc(&X->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));
             if (me != hipSuccess) { X->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
             X->frag_bytes = fbytes; X->frag_g = g; X->frag_k2 = K2;
             const int64_t pe = ntile * K2 * 64;
             hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                               (uint4*)X->frag_cache, W, K2, g, Cn);
-        } else {
-            hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a, W,
-                               ntile * 32, g, Cn);
+                               (uint4*)X->frag_cache, (float*)nullptr, K2, g, Cn, (float*)((char*)X->frag_cache + fbytes));
         }
         PBu = (const uint4*)X->frag_cache;
+        E0 = (const float*)((const char*)X->frag_cache + fbytes);
+        W = const_cast<float*>(a);                                 // the kernel multiplies by e_j itself
+        rc = COVGRAM_OK;
     } else {                                                       // generic fragments (norm pseudo-coordinate) + W = a, packed per MVM
         void* P;
         rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + 32 * sizeof(float)), &P);
@@ -719,10 +720,10 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
 #define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
-                                                  KParams<float>{}); break;
+                                                  KParams<float>{}, E0); break;
 #define CG_SYMW_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                    PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
-                                                   KParams<float>{}); break;
+                                                   KParams<float>{}, E0); break;
     if (fast) {
         switch (K2) {
             CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)

@@ -226,7 +226,12 @@ template <int FAM, int K2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp) {
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp,
+    const float* __restrict__ E0) {
+    // weights: W[j] (generic form: a_j, packed per MVM with the fragments) or, when E0 is given (EQ form), a_j * E0[j] with
+    // E0[j] = exp2(-|x~_j|^2 / 2) cached beside the fragments in the points handle (0 for padding) and W = a itself:
+    // no per-MVM pack kernel at all
+    auto wt = [&](int64_t j) { return E0 ? W[j < n ? j : n - 1] * E0[j] : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
             const float keep = ri < n ? 1.0f : 0.0f;
             if (ri >= n) ri = n - 1;
-            u[v] = W[ri] * keep;
+            u[v] = wt(ri) * keep;
         }
     }
     float acc[16];
@@ -306,7 +311,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    const float* __restrict__ wbase = W + T0 * 32;
     __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
     __shared__ float swA[ST][32], swB[ST][32];
     __shared__ float csA[NW][ST][64], csB[NW][ST][64];             // [wave][tile of the stage][half-wave, column]: column sums per half-wave
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
                 __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
-            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
+            gw = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
         }
 #define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
         _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
@@ -433,7 +437,12 @@ template <int FAM, int K2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym_wide_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp) {
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp,
+    const float* __restrict__ E0) {
+    // weights: W[j] (generic form: a_j, packed per MVM with the fragments) or, when E0 is given (EQ form), a_j * E0[j] with
+    // E0[j] = exp2(-|x~_j|^2 / 2) cached beside the fragments in the points handle (0 for padding) and W = a itself:
+    // no per-MVM pack kernel at all
+    auto wt = [&](int64_t j) { return E0 ? W[j < n ? j : n - 1] * E0[j] : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     constexpr int NW = 4;
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             int64_t ri = i0 + 8 * (v >> 2) + 4 * h + (v & 3);
             const float keep = ri < n ? 1.0f : 0.0f;
             if (ri >= n) ri = n - 1;
-            u[v] = W[ri] * keep;
+            u[v] = wt(ri) * keep;
         }
     }
     float acc[16];
@@ -503,7 +512,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    const float* __restrict__ wbase = W + T0 * 32;
     __shared__ uint4 tfA[K2][64], tfB[K2][64];
     __shared__ float twA[32], twB[32];
     __shared__ float csA[NW][64], csB[NW][64];
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int mm = wv + q * NW;                                                     \
                 if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
             }                                                                                   \
-            if (wv == 0) gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);                   \
+            if (wv == 0) gw = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);               \
         }
 #define CG_TILE2(ti_, TF, TW, CS)                                                               \
         {                                                                                       \
@@ -645,10 +653,10 @@ template <int FAM, int K2>
 static int mfma_sym_one(const MfmaArgs& a) {
     if constexpr (K2 <= 4)
         hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
-                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk));
+                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
     else
         hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
-                           a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk));
+                           a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
     return COVGRAM_OK;
 }
 
