@@ -5,12 +5,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one full MVM b = G a with the points, a and b resident in HBM.  For N > 1 the rows of G are
-sharded over the ranks (independent output rows), every rank runs the single-GPU HIP kernel on its shard and ONE
-RCCL all-gather completes b on every rank (covgram.dist); n stays 131072, so scaling is "strong".
+One "step" = one full MVM b = G a with the points, a and b resident in HBM.  gramian(EQ, x) is symmetric: on one GPU the
+matrix-core kernel evaluates its upper triangle once; for N > 1 every rank takes the cyclic 256-row panels p % N == rank of
+that triangle and ONE RCCL all-reduce completes b on every rank (covgram.dist; where the symmetric kernel does not apply the
+ranks shard rows and all-gather instead); n stays 131072, so scaling is "strong".
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (dense_mvm_kernel) priced against the FP32 vector peak it is actually bound by
+  roofline      the dominant kernel (the library reports which one ran) priced against the FP32 vector peak it is actually bound by
                 (the path is VALU/transcendental-bound; the HBM figures BASELINE.json's metric name asks
                 for are reported alongside as hbm_*), duration measured live with HIP events on the launch stream;
   cpu_baseline  the C restatement of src/gramian.jl:78-87 (oracle/, "port") timed on this host's cores on a bounded
