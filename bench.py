@@ -120,6 +120,11 @@ def main():
     def step():
         G.matmul(a, out=b)
 
+    # setup, not part of the W + K protocol: the first calls size the library's workspaces, pack the cached fragments, upload the
+    # symmetric kernel's workgroup list and (N > 1) open the RCCL channels; a short burst also brings the GPU out of its idle clocks
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
