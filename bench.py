@@ -249,8 +249,8 @@ def main():
                     "2.4 GHz (1.31e13/s); SQ counters show the VALU ~100% busy at the ~1.85 GHz the chip sustains "
                     "(profiles/r01_mfma_eq_counters.txt). 'hbm' does not bound this kernel.")
         elif dense_path == 2:
-            kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=4, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
-                     "1 v_fma_f32 per pair; 4 waves share each column tile through LDS)")
+            kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=8, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+                     "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)")
             ceiling = 1024 * 2.4e9 * 64 / 10.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (2 cyc) per 64 pairs per SIMD
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
                     "products), the VALU does 1 v_exp_f32 (8 issue cycles: quarter rate) + 1 v_fma_f32 (2) per 64 pairs per SIMD -> "
