@@ -448,7 +448,7 @@ static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : 
 template <int K2>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
                         float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
-    if (lds4 && K2 <= 2 && grid.x >= 256)   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms)
+    if (lds4 && K2 <= 2 && grid.x >= 1024)   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), dim3((grid.x + 7) / 8, grid.y), dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else if (lds4)   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (K2 <= 4 ? 2 : 1), 4, (K2 <= 4 ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);

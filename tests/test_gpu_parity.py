@@ -634,7 +634,7 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
     n and m, row blocks of 256 / 128 rows that end past n; checked on the first, last and some middle rows against the fp64
     oracle, and bit-for-bit against the one-wave-per-workgroup kernel."""
     rng = np.random.default_rng(400 + d)
-    n, m = 20011, 131072 - 37
+    n, m = (20011, 131072 - 37) if d != 3 else (65600 + 21, 33000 + 5)      # d = 3: >= 1024 row tiles -> eight waves per workgroup
     X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
     a = rng.standard_normal(m).astype(np.float32)
     G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.8), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
