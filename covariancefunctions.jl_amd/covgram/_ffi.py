@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
+# COVGRAM_LIB: another build of the SAME library (A/B of two builds in tools/); there is no other implementation to point it at
+LIB_PATH = os.environ.get("COVGRAM_LIB") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libcovgram.so"))
 
 # enums (include/covgram.h)
 EQ, EXP, RQ, GAMMAEXP, CAUCHY, IMQ, MATERNP, DOT, EXPDOT, MATERN, ASINDOT = range(11)
@@ -77,6 +78,8 @@ _KP = C.POINTER(covgram_kernel)
 # name -> (restype, argtypes): exactly the declarations of include/covgram.h
 PROTOTYPES = {
     "covgram_version": (C.c_int, []),
+    "covgram_sizeof_kernel": (C.c_int, []),
+    "covgram_sizeof_composite": (C.c_int, []),
     "covgram_last_error": (C.c_char_p, []),
     "covgram_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "covgram_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, _P]),

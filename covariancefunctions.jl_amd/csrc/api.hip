@@ -361,6 +361,8 @@ using namespace covgram;
 extern "C" {
 
 int covgram_version(void) { return COVGRAM_VERSION; }
+int covgram_sizeof_kernel(void) { return (int)sizeof(covgram_kernel); }
+int covgram_sizeof_composite(void) { return (int)sizeof(covgram_kernel_composite); }
 const char* covgram_last_error(void) { return g_err; }
 
 int covgram_device_count(int* count) {

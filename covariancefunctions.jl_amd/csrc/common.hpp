@@ -235,12 +235,15 @@ typedef int (*grad_launch_fn)(const GradArgs&, int dtype);
 grad_launch_fn grad_launcher(int family);
 
 // fp32 EQ on the matrix cores (dense_mfma.hip)
-// P = max|x~| max|y~| up to which the expanded exponent is used.  Its absolute error is a few fp32 roundings of O(P):
-// measured contribution to the MVM's 2-norm relative error ~4e-9 P (C2: P = 40, +0.7e-7; P = 125: 5e-7, tests), against
-// the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is ~1.7e-7 P per entry.
+// P = max(max|x~|, max|y~|)^2 (both radii about the column side's centre) up to which the expanded exponent is used.  Its
+// absolute error is a few fp32 roundings of O(P): measured contribution to the MVM's 2-norm relative error ~4e-9 P (C2:
+// P = 40, +0.7e-7; P = 125: 5e-7, tests), against the 1e-5 fp32 tolerance; the never-attained all-roundings-aligned bound is
+// ~1.7e-7 P per entry.  The bound is on EACH side, not on the product: the partial sums of |x~|^2 + |y~|^2 - 2 x~.y~ reach
+// the larger norm, and a far X cluster over a compact Y would otherwise pass.
 constexpr int MFMA_LDS_MIN_TILES = 64;
 constexpr int64_t MFMA_SYM_MIN_N = 24000;   // below: the general kernel is as fast (tools/mfma_sym_ab.py: 16384 loses, 24000 wins 7-16 %)
-constexpr double MFMA_GATE = 126.0;   // < 127: exp2 of the largest possible exponent |x~|max |y~|max must stay finite in fp32
+constexpr double MFMA_GATE = 126.0;
+double gate_radius2(const covgram_points* X, const covgram_points* Y);
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const float* a, float* y,

@@ -20,14 +20,19 @@
 // the 16 accumulators of a lane collect "row i, columns == lane (mod 32)" over all column tiles; the sum over the 32
 // lanes happens once per wave, at the end (5 butterfly steps).  RT row tiles per wave share every B fragment.
 //
-// Numerics.  This is NOT the reference's direct-difference r^2 (src/util.jl:40-47): the exponent x~.y~ - (|x~|^2+|y~|^2)/2
-// is formed from O(|x~||y~|) terms, so its absolute error is ~1e-7 |x~||y~| and the relative error of an entry
-// ~0.7e-7 |x~||y~|.  The path is therefore taken only when the host-side bound  max|x~| max|y~| <= MFMA_GATE (= 126:
-// measured contribution to the MVM's relative error ~4e-9 per unit of the bound, i.e. <= 5e-7 against the 1e-5 fp32
-// tolerance of BASELINE.json; common.hpp) holds — the point-set norms are computed once when the covgram_points handle
-// is created — and otherwise the exact direct-difference kernel runs.
-// (x~ is taken relative to the column set's own centre — common.hpp, covgram_points::center — so the bound does not depend on
-// where the cloud sits; 126 < 127 also keeps exp2 of the largest exponent finite.)
+// Numerics.  This is NOT the reference's direct-difference r^2 (src/util.jl:40-47): the exponent
+//     x~ . y~ - |x~|^2/2 - |y~|^2/2  =  -|x~ - y~|^2 / 2
+// is formed in the MFMA's fp32 accumulator from the split products plus the INTEGER parts of the two half-norms (two extra
+// K-slots); their fractions are fp32 factors in (1/2, 1] (dense_mfma.hpp: norm_split) — so every exponential is <= 4: it can
+// neither overflow nor lose a row or a column to an underflowing norm factor (round 1 kept e_i = exp2(-|x~_i|^2/2) and
+// a_j e_j whole, which flushed every row of an X cluster > ~16 scaled units from the column centre to 0), and the weights
+// stay within a factor 2 of the caller's a_j.  What remains is the cancellation: the partial sums reach max(|x~|^2, |y~|^2),
+// so the exponent carries an absolute error of a few fp32 roundings of that size.  The path is therefore taken only when BOTH
+// point sets lie within
+//     g^2 max_i |x_i - c|^2 <= MFMA_GATE  and  g^2 max_j |y_j - c|^2 <= MFMA_GATE      (c = the column side's centre)
+// (= 126: measured contribution to the MVM's relative error ~4e-9 per unit of the bound, i.e. <= 5e-7 against the 1e-5
+// fp32 tolerance of BASELINE.json; common.hpp) — the radii are computed once when the covgram_points handle is created —
+// and otherwise the exact direct-difference kernel runs.
 // Option "dense_variant": 0 = this rule, 1 = always direct differences, 2 = MFMA whenever the shape allows (tests).
 //
 // Kernels in this file and in dense_mfma.hpp (one path each, chosen on the host in covgram_mvm):
@@ -42,14 +47,15 @@
 
 namespace covgram {
 
-// B fragments of every column tile in MFMA lane order + the folded weights.  Lane (r, h) of MFMA mm of tile T holds, for
-// coordinate c = 2 mm + h of column j = 32 T + r, the eight K-slots  [y1, y2, y1, y3, y2, y1, y3, y2]  (16 bytes), which
-// meet the row side's  [x1, x1, x2, x1, x2, x3, x2, x3].
+// B fragments of every column tile in MFMA lane order + the fraction factors of the column norms (both depend on the points
+// and g only: cached in the points handle).  Lane (r, h) of MFMA mm of tile T holds, for coordinate c = 2 mm + h of column
+// j = 32 T + r, the eight K-slots  [y1, y2, y1, y3, y2, y1, y3, y2]  (16 bytes) of y~_c, which meet the row side's
+// [x1, x1, x2, x1, x2, x3, x2, x3]; the integer part k_j of -|y~_j|^2/2 sits in the idle coordinate c = d as [1, k_j, 0, ...]
+// (d odd) or replaces the last two slots of coordinate 0, [.., 1, k_j] (d even) — dense_mfma.hpp: norm_split.
 //   PB[(T * K2 + mm) * 64 + l] = that fragment (zero outside the point set / dimension)
-//   W[32 T + r]                = a_j * exp2(-|g y_j|^2 / 2)                     (0 for padding columns)
-__global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
-                                                        uint4* __restrict__ PB, float* __restrict__ W, int32_t K2, float g,
-                                                        const float* __restrict__ Cn, float* __restrict__ E0) {
+//   EF[32 T + r]               = exp2(f_j) in (1/2, 1]                          (0 for padding columns)
+__global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, uint4* __restrict__ PB,
+                                                        float* __restrict__ EF, int32_t K2, float g, const float* __restrict__ Cn) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -59,21 +65,34 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     const int64_t T = q / K2;
     const int64_t j = 32 * T + (l & 31);
     const int c = 2 * mm + (l >> 5);
-    const float yt = (j < m && c < d) ? g * (Y[j * (int64_t)d + c] - Cn[c]) : 0.0f;
-    unsigned y1, y2, y3;
-    split3(yt, y1, y2, y3);
-    PB[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
-    if (mm == 0 && l < 32) {                                       // W[j] = a_j e_j (this MVM), E0[j] = e_j (kept with the fragments)
-        float w = 0.0f, ej = 0.0f;
-        if (j < m) {
-            float ny = 0.0f;
-            for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
-            ej = __builtin_amdgcn_exp2f(-0.5f * ny);
-            if (W) w = A[j] * ej;
+    uint4 frag = make_uint4(0, 0, 0, 0);
+    const bool norm_lane = (d & 1) ? (c == d) : (c == 0);          // the lane that carries k_j (one per column)
+    if (j < m) {
+        if (c < d) {
+            const float yt = g * (Y[j * (int64_t)d + c] - Cn[c]);
+            unsigned y1, y2, y3;
+            split3(yt, y1, y2, y3);
+            frag = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
         }
-        if (W) W[j] = w;
-        E0[j] = ej;
+        if (norm_lane) {
+            double ny = 0.0;
+            for (int cc = 0; cc < d; ++cc) { const double yc = (double)(g * (Y[j * (int64_t)d + cc] - Cn[cc])); ny = __builtin_fma(yc, yc, ny); }
+            const NormSplit sp = norm_split(ny);
+            if (d & 1) frag = make_uint4(BF16_ONE | (sp.kbits << 16), 0, 0, 0);
+            else frag.w = BF16_ONE | (sp.kbits << 16);
+            EF[j] = sp.ef;
+        }
+    } else if (norm_lane) {
+        EF[j] = 0.0f;
     }
+    PB[e] = frag;
+}
+
+// the per-MVM part of the pack: W[j] = a_j * exp2(f_j) (the cached fraction factor, in (1/2, 1]), 0 for padding columns
+__global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restrict__ A, const float* __restrict__ EF, float* __restrict__ W,
+                                                          int64_t m, int64_t mpad) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < mpad) W[j] = j < m ? A[j] * EF[j] : 0.0f;
 }
 
 // LDS: 0 = every wave loads its own column tiles; 1 = stages of WPB tiles shared through LDS (K2 <= 4, RT = 2);
@@ -87,25 +106,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     // nothing shared explicitly): their fragment loads coalesce in the CU's vector L1 instead of each going to L2
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
     const int64_t i0 = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * (32 * RT);
-    // A fragments: lane (t, h) holds the split of x~[row][c = 2 mm + h]; the row norm from the same fp32 values
+    // A fragments: lane (t, h) holds the split of x~[row][c = 2 mm + h] (+ the integer part of the row's half-norm)
     Frag a[RT][K2];
-    float nx[RT];
+    float er[RT];                                                // exp2 of the fraction of the row's half-norm, in (1/2, 1]
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         int64_t row = i0 + 32 * r + t;
         if (row >= n) row = n - 1;                               // clamp: computed, never stored
-        const float* __restrict__ xr = X + row * (int64_t)d;
-        float part = 0.0f;
-#pragma unroll
-        for (int mm = 0; mm < K2; ++mm) {
-            const int c = 2 * mm + h;
-            const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
-            part = __builtin_fmaf(xt, xt, part);
-            unsigned x1, x2, x3;
-            split3(xt, x1, x2, x3);
-            a[r][mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-        }
-        nx[r] = part + __shfl_xor(part, 32);
+        er[r] = eq_row_fragments<K2>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
     }
 
     const int64_t T0 = (int64_t)blockIdx.y * tchunk;
@@ -119,13 +127,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     // Column tiles in pairs with two operand buffers (no register copies); the prefetch of a tile past the chunk is clamped
     // to the last tile (a harmless re-read) instead of branching.  Uniform base + 32-bit lane offset -> saddr loads.
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    const float* __restrict__ wbase = W + T0 * 32;
+    const float* __restrict__ wbase = W + T0 * 32;                // W[j] = a_j exp2(f_j), packed per MVM (0 for padding columns)
     const int nt = (int)(T1 - T0);
+    auto weight = [&](int tc) { return wbase[tc * 32 + t]; };
     auto load_tile = [&](int ti, Frag (&f)[K2], float& w) {
         const int tc = ti < nt ? ti : nt - 1;
 #pragma unroll
         for (int mm = 0; mm < K2; ++mm) f[mm].u = pbase[(tc * K2 + mm) * 64 + l];
-        w = wbase[tc * 32 + t];
+        w = weight(tc);
     };
     auto process = [&](const Frag (&f)[K2], float w) {
         f32x16 D[RT];
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
                 const int mm = wv + q * WPB;                                                    \
                 if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
             }                                                                                   \
-            if (wv == 0) gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);                   \
+            if (wv == 0) gw = ti_ < nt ? weight(tc_) : 0.0f;                                    \
         }
 #define CG_TILE2(TF, TW)                                                                        \
         {                                                                                       \
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
                 __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
-            gw = wbase[tc_ * 32 + t] * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
+            gw = ti_ < nt ? weight(tc_) : 0.0f;                    /* tiles past the chunk: weight 0 */ \
         }
 #define CG_STAGE(SF, SW)                                                                        \
         _Pragma("unroll 1") for (int k = 0; k < WPB; k += 2) {                                  \
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         }
         const int64_t i = i0 + 32 * r + t;
         if (((t >> 2) & 1) != h || i >= n) continue;
-        const float res = __builtin_amdgcn_exp2f(-0.5f * nx[r]) * tot;
+        const float res = er[r] * tot;
         if (final_store) {
             float v = alpha * res;
             if (beta != 0.0f) v = __builtin_fmaf(beta, out[i], v);
@@ -311,20 +320,6 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
     PB[e] = frag;
     if (mm == 0 && l < 32)
         for (int cr = 0; cr < NR; ++cr) W[(T * NR + cr) * 32 + l] = (j < m && c0 + cr < nrhs) ? A[j + (int64_t)(c0 + cr) * lda] : 0.0f;
-}
-
-// the per-MVM part of the pack when the fragments are cached: W[j] = a_j * exp2(-|g y_j|^2 / 2)
-__global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
-                                                          float* __restrict__ W, int64_t mpad, float g, const float* __restrict__ Cn) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= mpad) return;
-    float w = 0.0f;
-    if (j < m) {
-        float ny = 0.0f;
-        for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
-        w = A[j] * __builtin_amdgcn_exp2f(-0.5f * ny);
-    }
-    W[j] = w;
 }
 
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
@@ -422,13 +417,28 @@ static double centred_radius(const covgram_points* X, const covgram_points* Y) {
     return sqrt(X->max_cnorm2) + sqrt(s) * 1.000001;
 }
 
+// the larger of the two squared radii about the column side's centre: every partial sum of the cancellation
+// |x~|^2 + |y~|^2 - 2 x~.y~ (and of the EQ exponent) is bounded by it, so the absolute rounding error of s scales with it
+double gate_radius2(const covgram_points* X, const covgram_points* Y) {
+    const double rx = centred_radius(X, Y), ry = sqrt(Y->max_cnorm2);
+    const double r = rx > ry ? rx : ry;
+    return r * r;
+}
+
+static int eq_k2_for(int d) {   // MFMAs per tile of the EQ kernels (two coordinates each), from the compiled set
+    static const int ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int need = (d + 1) / 2;
+    for (int k : ks) if (k >= need) return k;
+    return -1;
+}
+
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
     if (ctx->dense_variant == 1) return false;
     if (hk.tu_family != COVGRAM_EQ || hk.k.power != 1 || X->dtype != COVGRAM_F32 || nrhs != 1) return false;
     if (X->d > 32 || Y->n == 0) return false;                   // beyond d = 32 the fragments leave one wave per SIMD
     if (ctx->dense_variant == 2) return true;
     const double g2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale);   // |x~|^2 = g2 |x|^2
-    return g2 * centred_radius(X, Y) * sqrt(Y->max_cnorm2) <= MFMA_GATE;
+    return g2 * gate_radius2(X, Y) <= MFMA_GATE;                 // BOTH sides: a far X cluster must not ride on a compact Y
 }
 
 // resident single-wave workgroups per CU of the kernel instance (register-limited), for the grid sizing below
@@ -443,19 +453,42 @@ static int mfma_blocks_per_cu() {
     return cached;
 }
 template <int K2>
-static int mfma_blocks(int rt) { return rt == 2 ? mfma_blocks_per_cu<K2, 2>() : mfma_blocks_per_cu<K2, 1>(); }
+static int mfma_blocks(int rt) {
+    if constexpr (K2 <= 8) { if (rt == 2) return mfma_blocks_per_cu<K2, 2>(); }
+    return mfma_blocks_per_cu<K2, 1>();
+}
 
 template <int K2>
-static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W, int64_t ntile,
-                        float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
+static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
+                        int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
+    constexpr bool NARROW = K2 <= MFMA_NARROW_MAXK2;
     if (lds4 && K2 <= 2 && grid.x >= 1024)   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), dim3((grid.x + 7) / 8, grid.y), dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else if (lds4)   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (K2 <= 4 ? 2 : 1), 4, (K2 <= 4 ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
-    else if (rt == 2)
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+    else if (rt == 2 && K2 <= 8)
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
     else
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+}
+
+// the column fragments and norm fraction factors of point set Y for (g, K2): packed once into the handle and reused by every
+// later MVM (they depend on the points and the lengthscale only; the kernels form the weights a_j EF[j] themselves)
+static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float g, const float* Cn, const uint4** PB, const float** EF) {
+    const int64_t m = Y->n, ntile = (m + 31) / 32;
+    const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
+    if (Y->frag_cache == nullptr || Y->frag_bytes != fbytes || Y->frag_g != g || Y->frag_k2 != K2) {
+        if (Y->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(Y->frag_cache); Y->frag_cache = nullptr; }
+        hipError_t me = hipMalloc(&Y->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));   // fragments + EF
+        if (me != hipSuccess) { Y->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
+        Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
+        const int64_t pe = ntile * K2 * 64;
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, Y->d,
+                           (uint4*)Y->frag_cache, (float*)((char*)Y->frag_cache + fbytes), K2, g, Cn);
+    }
+    *PB = (const uint4*)Y->frag_cache;
+    *EF = (const float*)((const char*)Y->frag_cache + fbytes);
+    return COVGRAM_OK;
 }
 
 // y <- alpha * scale * G a + beta * y for ONE right-hand side (device pointers)
@@ -463,42 +496,36 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
                 double alpha, double beta) {
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
-    const int D = pad_dim(d);
-    const int K2 = (D + 1) / 2;
+    const int K2 = eq_k2_for(d);
+    CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma: d = %d has no matrix-core instance", d);
     const int64_t ntile = (m + 31) / 32;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)Y->center;                    // both sides are taken relative to the column side's centre
-    // fragments: cached in the column point set's handle (they do not depend on the weights); weights: per MVM
-    const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
+    const uint4* PB;
+    const float* EF;
+    int rc = eq_fragments(ctx, Y, K2, g, Cn, &PB, &EF);
+    if (rc) return rc;
+    // the weights a_j exp2(f_j) of THIS right-hand side (the in-kernel product — two loads and a multiply per column tile in
+    // place of this 4 us launch — measured 3 % slower on C2 in round 2, as in round 1)
     void* Wp;
-    int rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
+    rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
     if (rc) return rc;
     float* W = (float*)Wp;
-    if (Y->frag_cache == nullptr || Y->frag_bytes != fbytes || Y->frag_g != g || Y->frag_k2 != K2) {
-        if (Y->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(Y->frag_cache); Y->frag_cache = nullptr; }
-        hipError_t me = hipMalloc(&Y->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));   // fragments + e_j (symmetric kernel)
-        if (me != hipSuccess) { Y->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
-        Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
-        const int64_t pe = ntile * K2 * 64;
-        hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
-                           (uint4*)Y->frag_cache, W, K2, g, Cn, (float*)((char*)Y->frag_cache + fbytes));
-    } else {
-        hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a, W,
-                           ntile * 32, g, Cn);
-    }
-    const uint4* PB = (const uint4*)Y->frag_cache;
+    hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, a, EF, W, m, ntile * 32);
     // split the column tiles so that the grid holds ~CUs * 128 waves (as the lane-per-row kernel, profiles/r01_quickbench_wg64.txt)
     // row tiles per wave: two share every B fragment while the state fits (d <= 8); option "rows_per_lane" = 1 / 2 forces it
-    const int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= 4 ? 2 : 1));
+    int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= MFMA_NARROW_MAXK2 ? 2 : 1));
+    if (K2 > 8) rt = 1;
     const int64_t rowtiles = (n + 32 * rt - 1) / (32 * rt);
     const int64_t npad = rowtiles * 32 * rt;
     // grid = a whole number (4) of rounds of resident waves: a fractional last round costs up to one round of idle SIMDs
     int nb = 16;
+#define CG_NB_CASE(K) case K: nb = mfma_blocks<K>(rt); break;
     switch (K2) {
-        case 1: nb = mfma_blocks<1>(rt); break; case 2: nb = mfma_blocks<2>(rt); break; case 3: nb = mfma_blocks<3>(rt); break;
-        case 4: nb = mfma_blocks<4>(rt); break; case 6: nb = mfma_blocks<6>(rt); break; case 8: nb = mfma_blocks<8>(rt); break;
-        case 12: nb = mfma_blocks<12>(rt); break; case 16: nb = mfma_blocks<16>(rt); break; default: break;
+        CG_NB_CASE(1) CG_NB_CASE(2) CG_NB_CASE(3) CG_NB_CASE(4) CG_NB_CASE(6) CG_NB_CASE(8) CG_NB_CASE(12) CG_NB_CASE(16)
+        default: break;
     }
+#undef CG_NB_CASE
     int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
     int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
     js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));     // >= 8 tiles (256 columns) per wave
@@ -509,9 +536,9 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
     const dim3 grid((unsigned)rowtiles, (unsigned)js);
     const int fs = js == 1 ? 1 : 0;
-    // long column chunks: four waves of a workgroup share every column tile through LDS (K2 <= 4 instances); short chunks
-    // would only pay its prologue and barriers (tools/mfma_lds_ab.py)
-    const bool lds4 = ((rt == 2 && K2 <= 4) || (rt == 1 && K2 > 4)) &&
+    // long column chunks: four waves of a workgroup share every column tile through LDS; short chunks would only pay its
+    // prologue and barriers (tools/mfma_lds_ab.py)
+    const bool lds4 = ((rt == 2 && K2 <= MFMA_NARROW_MAXK2) || (rt == 1 && K2 > MFMA_NARROW_MAXK2)) &&
                       (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
@@ -535,7 +562,8 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 // Symmetric Gramian (gramian(k, x): y IS x): every tile on or above the diagonal is evaluated ONCE and used twice,
 //     b_i += e_i sum_j (a_j e_j) E_ij          (row sums, as dense_mfma_eq_kernel)
 //     b_j += e_j sum_i (a_i e_i) E_ij          (column sums of the same exponentials, tiles strictly above the diagonal)
-// with E_ij = exp2(x~_i . x~_j), e_i = exp2(-|x~_i|^2 / 2): one v_exp_f32 and TWO v_fma_f32 per evaluated pair, i.e. 6 VALU
+// with E_ij = exp2(x~_i . x~_j + k_i + k_j) from the MFMA and e = exp2(f) in (1/2, 1] the fraction factors of the half-norms
+// (dense_mfma.hpp: norm_split): one v_exp_f32 and TWO v_fma_f32 per evaluated pair, i.e. 6 VALU
 // issue cycles per Gramian entry instead of 10, and half the MFMAs.  The reference evaluates all n^2 entries
 // (src/gramian.jl:78-87 does not look at issymmetric); the sums are the same numbers in a different order.
 //
@@ -547,12 +575,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 // S[p][j] (each (p, tile) exactly once); dense_mfma_sym_reduce_kernel adds R over the panel's chunks and S over the panels
 // p <= panel(j) in fixed order: deterministic, no float atomics.
 // ------------------------------------------------------------------------------------------------------------------------
-// b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order.
+// b_i = alpha (sum_{chunks c the panel of i visited} R[c][i] + e_i sum_{p <= panel(i)} S[p][i]) + beta b_i, fixed order
+// (EF = the fraction factors e_i the EQ form's column sums still lack; nullptr: generic form).
 // 64 rows per workgroup, the panel index strided over the 4 waves (as dense_reduce_kernel).
-__global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(const float* __restrict__ X, int64_t n, int32_t d, const float* __restrict__ R,
-                                                                    const float* __restrict__ S, int64_t npad, int64_t ntile, int32_t tchunk,
-                                                                    float g, const float* __restrict__ Cn, float* __restrict__ y, float alpha,
-                                                                    float beta, int32_t pfirst, int32_t pstride, int32_t use_e, int32_t tpp) {
+__global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(int64_t n, const float* __restrict__ R, const float* __restrict__ S, int64_t npad,
+                                                                    int64_t ntile, int32_t tchunk, const float* __restrict__ EF, float* __restrict__ y,
+                                                                    float alpha, float beta, int32_t pfirst, int32_t pstride, int32_t tpp) {
     // 64 rows per workgroup, the panel index strided over 16 waves (hundreds of panels per row: many independent loads in flight)
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -576,13 +604,7 @@ __global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(const float
     float rs = 0.0f;
     if (pi >= pfirst && (pi - pfirst) % pstride == 0)                                 // the row sums exist only where this rank owns the panel
         for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
-    float ei = 1.0f;                                                                 // EQ form: the column sums still lack e_i
-    if (use_e) {
-        float ni = 0.0f;
-        for (int c = 0; c < d; ++c) { const float xc = g * (X[i * (int64_t)d + c] - Cn[c]); ni = __builtin_fmaf(xc, xc, ni); }
-        ei = __builtin_amdgcn_exp2f(-0.5f * ni);
-    }
-    float v = alpha * __builtin_fmaf(ei, cs, rs);
+    float v = alpha * (EF ? __builtin_fmaf(EF[i], cs, rs) : cs + rs);
     if (beta != 0.0f) v = __builtin_fmaf(beta, y[i], v);
     y[i] = v;
 }
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(const float
 bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
     if (ctx->mfma_sym == 0 || X->dptr != Y->dptr || X->n != Y->n) return false;       // gramian(k, x): the same point set on both sides
     if (!mfma_eq_eligible(ctx, hk, X, Y, nrhs)) return false;
-    const int tpp = X->d > 8 ? 4 : 8;                                                // row tiles per panel (dense_mfma_sym_wide_kernel: 4)
+    const int tpp = eq_k2_for(X->d) > MFMA_NARROW_MAXK2 ? 4 : 8;                    // row tiles per panel (dense_mfma_sym_wide_kernel: 4)
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;   // column-sum slab <= 16 GiB of the 288
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
@@ -604,7 +626,7 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     if (!mfma_gen_eligible(ctx, hk, X, Y)) return false;
     const int k2 = mfma_k2_for(X->d + (hk.k.trait == COVGRAM_ISOTROPIC ? 1 : 0));
     if (k2 < 0) return false;
-    const int tpp = k2 > 4 ? 4 : 8;
+    const int tpp = k2 > MFMA_NARROW_MAXK2 ? 4 : 8;
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
     return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
@@ -626,45 +648,34 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     const bool iso = hku.k.trait == COVGRAM_ISOTROPIC;
     const int64_t n = X->n;
     const int d = X->d;
-    const int D = pad_dim(d);
-    const int K2 = fast ? (D + 1) / 2 : mfma_k2_for(d + (iso ? 1 : 0));
+    const int K2 = fast ? eq_k2_for(d) : mfma_k2_for(d + (iso ? 1 : 0));
+    CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: d = %d has no matrix-core instance", d);
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
-    const int tpp = K2 > 4 ? 4 : 8;                                  // row tiles per panel: 8 waves x 1 tile, or 4 x 1 for long fragments
+    const int tpp = K2 > MFMA_NARROW_MAXK2 ? 4 : 8;                  // row tiles per panel: 8 waves x 1 tile, or 4 x 1 for long fragments
     const int64_t ntile = (n + 31) / 32, panels = (ntile + tpp - 1) / tpp, npad = panels * 32 * tpp + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
-    const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
     int rc;
-    float* W;
+    const float* W;
     const uint4* PBu;
-    const float* E0 = nullptr;
+    const float* EF = nullptr;
     if (fast) {
-        // the fragments AND e_j = exp2(-|x~_j|^2 / 2) are cached in the points handle; the kernel forms a_j e_j itself, so a
+        // the fragments AND the fraction factors e_j are cached in the points handle; the kernel forms a_j e_j itself, so a
         // steady-state MVM launches no pack kernel
-        if (X->frag_cache == nullptr || X->frag_bytes != fbytes || X->frag_g != g || X->frag_k2 != K2) {
-            if (X->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(X->frag_cache); X->frag_cache = nullptr; }
-            hipError_t me = hipMalloc(&X->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));
-            if (me != hipSuccess) { X->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
-            X->frag_bytes = fbytes; X->frag_g = g; X->frag_k2 = K2;
-            const int64_t pe = ntile * K2 * 64;
-            hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                               (uint4*)X->frag_cache, (float*)nullptr, K2, g, Cn, (float*)((char*)X->frag_cache + fbytes));
-        }
-        PBu = (const uint4*)X->frag_cache;
-        E0 = (const float*)((const char*)X->frag_cache + fbytes);
-        W = const_cast<float*>(a);                                 // the kernel multiplies by e_j itself
-        rc = COVGRAM_OK;
+        rc = eq_fragments(ctx, X, K2, g, Cn, &PBu, &EF);
+        if (rc) return rc;
+        W = a;
     } else {                                                       // generic fragments (norm pseudo-coordinate) + W = a, packed per MVM
         void* P;
         rc = ws_reserve(ctx, 0, (size_t)ntile * ((size_t)K2 * 64 * sizeof(uint4) + 32 * sizeof(float)), &P);
         if (rc) return rc;
         uint4* PB = (uint4*)P;
-        W = (float*)(PB + ntile * K2 * 64);
+        float* Wg = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                           n, 1, 0, PB, W, K2, 1, (float)hku.kp.gamma, iso ? 1 : 0, Cn);
-        PBu = PB;
+                           n, 1, 0, PB, Wg, K2, 1, (float)hku.kp.gamma, iso ? 1 : 0, Cn);
+        PBu = PB; W = Wg;
     }
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
     const int64_t lpanels = panels > pfirst ? (panels - pfirst + pstride - 1) / pstride : 0;   // this call's panels
@@ -722,10 +733,10 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
 #define CG_SYM_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
-                                                  KParams<float>{}, E0); break;
+                                                  KParams<float>{}, EF); break;
 #define CG_SYMW_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                    PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
-                                                   KParams<float>{}, E0); break;
+                                                   KParams<float>{}, EF); break;
     if (fast) {
         switch (K2) {
             CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
@@ -746,9 +757,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #undef CG_SYM_CASE
 #undef CG_SYMW_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
-    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, (const float*)X->dptr, n, d,
-                       (const float*)Rp, (const float*)Sp, npad, ntile, (int)tchunk, g, Cn, y, (float)alpha_eff, (float)beta, pfirst, pstride,
-                       fast ? 1 : 0, tpp);
+    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, n, (const float*)Rp,
+                       (const float*)Sp, npad, ntile, (int)tchunk, EF, y, (float)alpha_eff, (float)beta, pfirst, pstride, tpp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
@@ -813,12 +823,12 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
         }
         if (ctx->dense_variant == 2) return true;
         if (!iso) return sqrt(X->max_norm2) * sqrt(Y->max_norm2) < 1e30;
-        const double Pn = centred_radius(X, Y) * sqrt(Y->max_cnorm2);          // natural units: every factor has its own 1 / l^2
+        const double Pn = gate_radius2(X, Y);                                  // natural units: every factor has its own 1 / l^2
         return worst * Pn <= 0.5 * MFMA_GATE / 1.4426950408889634074;
     }
     if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
     if (ctx->dense_variant == 2) return true;
-    const double P = (iso ? centred_radius(X, Y) * sqrt(Y->max_cnorm2) : sqrt(X->max_norm2) * sqrt(Y->max_norm2)) /
+    const double P = (iso ? gate_radius2(X, Y) : sqrt(X->max_norm2) * sqrt(Y->max_norm2)) /
                      (hk.k.lengthscale * hk.k.lengthscale);
     if (!(P < 1e30)) return false;
     if (!iso) return true;                                                     // x.y itself: no cancellation to gate

@@ -37,6 +37,55 @@ union Frag {
 
 
 constexpr unsigned BF16_ONE = 0x3F80u;
+// EQ kernels up to this many MFMAs per tile (d <= 8) keep two row tiles per wave, share staged column tiles through LDS and
+// use the 8-wave symmetric panels; longer fragments take the one-tile-per-stage forms
+constexpr int MFMA_NARROW_MAXK2 = 4;
+
+// ---- the norms of the fp32 EQ kernels (dense_mfma.hip) ------------------------------------------------------------------
+// The exponent of an entry is  x~.y~ - |x~|^2/2 - |y~|^2/2 = -|x~ - y~|^2/2.  Each half-norm is split into an INTEGER and
+// a fraction,  -|x~|^2/2 = k + f  with k = ceil(.) <= 0 and f in (-1, 0]:  the integers (exact in bf16 up to 256; the gate
+// keeps them <= 63) ride through the MFMA in two K-slots, [k_i] x [1] and [1] x [k_j], so the matrix cores deliver
+//     x~.y~ + k_i + k_j  =  -|x~ - y~|^2/2 - f_i - f_j   (<= 2),
+// and the fractions are fp32 factors exp2(f) in (1/2, 1] — on the row side applied once per row, on the column side folded
+// into the weight a_j exp2(f_j).  Nothing can overflow (every exponential is <= 4), no row or column is lost to an
+// underflowing norm factor (round 1 kept exp2(-|x~|^2/2) whole: 2^-160 for a point 18 scaled units out), and the weights
+// stay within a factor 2 of the caller's a_j over the whole fp32 range.
+// Where the two slots live: d odd — in the idle coordinate c = d of the last MFMA (nothing is displaced); d even — in place
+// of the two smallest split products (x2 y3, x3 y2 ~ 2^-24 |x_0 y_0|) of coordinate 0, so K2 stays d / 2.
+struct NormSplit { unsigned kbits; float ef; };
+__device__ __forceinline__ NormSplit norm_split(double n2) {       // n2 = |x~|^2 (fp64 sum of squares of the fp32 coordinates)
+    const double hn = -0.5 * n2;
+    const double k = __builtin_ceil(hn);
+    NormSplit s;
+    s.kbits = bf16_bits((float)k);
+    s.ef = __builtin_amdgcn_exp2f((float)(hn - k));
+    return s;
+}
+
+// A fragments of one row for the EQ kernels: lane (t, h) holds the split of x~[row][c = 2 mm + h]; returns exp2(f_i)
+template <int K2>
+__device__ __forceinline__ float eq_row_fragments(const float* __restrict__ xr, const float* __restrict__ Cn, int d, float g, int h,
+                                                  Frag (&a)[K2]) {
+    double part = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < K2; ++mm) {
+        const int c = 2 * mm + h;
+        const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
+        part = __builtin_fma((double)xt, (double)xt, part);
+        unsigned x1, x2, x3;
+        split3(xt, x1, x2, x3);
+        a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+    }
+    const NormSplit s = norm_split(part + __shfl_xor(part, 32));
+    if (d & 1) {                                                   // idle coordinate c = d: slots [k_i, 1, 0, ...]
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm)
+            if (2 * mm + h == d) a[mm].u = make_uint4(s.kbits | (BF16_ONE << 16), 0, 0, 0);
+    } else if (h == 0) {                                           // coordinate 0: [x1, x1, x2, x1, x2, x3, k_i, 1]
+        a[0].u.w = s.kbits | (BF16_ONE << 16);
+    }
+    return s.ef;
+}
 
 // EQ and MaternP take the dense path's FOLDED parameter block here too (log2(e) and sqrt(2p+1) in the coordinate pre-scale,
 // rescaled tables: exp2 of the MFMA result, no multiplications in front) — the host passes make_host_kernel(.., for_gradient = false)
@@ -227,11 +276,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
     int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp,
-    const float* __restrict__ E0) {
-    // weights: W[j] (generic form: a_j, packed per MVM with the fragments) or, when E0 is given (EQ form), a_j * E0[j] with
-    // E0[j] = exp2(-|x~_j|^2 / 2) cached beside the fragments in the points handle (0 for padding) and W = a itself:
-    // no per-MVM pack kernel at all
-    auto wt = [&](int64_t j) { return E0 ? W[j < n ? j : n - 1] * E0[j] : W[j]; };
+    const float* __restrict__ EF) {
+    // weights: W[j], padded with zeros by the per-MVM pack (generic form), or, when EF is given (EQ form), a_j * EF[j] with
+    // EF[j] = exp2(f_j) the fraction factor of the point's half-norm, cached beside the fragments in the points handle (0 for
+    // padding), and W = the caller's a itself: no per-MVM pack kernel at all
+    // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
+    auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
@@ -259,7 +309,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t I0 = NW * p + wv;                                // this wave's row tile
     const int64_t i0 = I0 * 32;
     Frag a[K2];
-    float nx;
+    float er = 1.0f;                                               // EQ form: exp2 of the fraction of the row's half-norm
     float u[16];                                                   // a_i e_i of the 16 rows this lane's accumulators belong to
     {
         int64_t row = i0 + t;
@@ -267,16 +317,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float* __restrict__ xr = X + row * (int64_t)d;
         float part = 0.0f;
         if constexpr (FAST) {
-#pragma unroll
-            for (int mm = 0; mm < K2; ++mm) {
-                const int c = 2 * mm + h;
-                const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
-                part = __builtin_fmaf(xt, xt, part);
-                unsigned x1, x2, x3;
-                split3(xt, x1, x2, x3);
-                a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-            }
-            nx = part + __shfl_xor(part, 32);
+            er = eq_row_fragments<K2>(xr, Cn, d, g, h, a);
         } else {
             const float gg = kp.gamma;
             if constexpr (ISO)
@@ -296,7 +337,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 a[mm].u = f;
             }
-            nx = 0.0f;
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {                             // MFMA 32x32 output: register v of half h is row 8 (v / 4) + 4 h + v % 4
@@ -426,7 +466,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const int64_t i = i0 + t;
     if (((t >> 2) & 1) != h || i >= n) return;
-    R[cabs * npad + i] = FAST ? __builtin_amdgcn_exp2f(-0.5f * nx) * tot : tot;
+    R[cabs * npad + i] = FAST ? er * tot : tot;
 }
 
 
@@ -438,11 +478,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
     int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp,
-    const float* __restrict__ E0) {
-    // weights: W[j] (generic form: a_j, packed per MVM with the fragments) or, when E0 is given (EQ form), a_j * E0[j] with
-    // E0[j] = exp2(-|x~_j|^2 / 2) cached beside the fragments in the points handle (0 for padding) and W = a itself:
-    // no per-MVM pack kernel at all
-    auto wt = [&](int64_t j) { return E0 ? W[j < n ? j : n - 1] * E0[j] : W[j]; };
+    const float* __restrict__ EF) {
+    // weights: W[j], padded with zeros by the per-MVM pack (generic form), or, when EF is given (EQ form), a_j * EF[j] with
+    // EF[j] = exp2(f_j) the fraction factor of the point's half-norm, cached beside the fragments in the points handle (0 for
+    // padding), and W = the caller's a itself: no per-MVM pack kernel at all
+    // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
+    auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST);
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     constexpr int NW = 4;
@@ -460,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int64_t I0 = NW * p + wv;
     const int64_t i0 = I0 * 32;
     Frag a[K2];
-    float nx;
+    float er = 1.0f;                                               // EQ form: exp2 of the fraction of the row's half-norm
     float u[16];
     {
         int64_t row = i0 + t;
@@ -468,16 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* __restrict__ xr = X + row * (int64_t)d;
         float part = 0.0f;
         if constexpr (FAST) {
-#pragma unroll
-            for (int mm = 0; mm < K2; ++mm) {
-                const int c = 2 * mm + h;
-                const float xt = (c < d) ? g * (xr[c] - Cn[c]) : 0.0f;
-                part = __builtin_fmaf(xt, xt, part);
-                unsigned x1, x2, x3;
-                split3(xt, x1, x2, x3);
-                a[mm].u = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-            }
-            nx = part + __shfl_xor(part, 32);
+            er = eq_row_fragments<K2>(xr, Cn, d, g, h, a);
         } else {
             const float gg = kp.gamma;
             if constexpr (ISO)
@@ -497,7 +529,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 a[mm].u = f;
             }
-            nx = 0.0f;
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
@@ -606,7 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     const int64_t i = i0 + t;
     if (((t >> 2) & 1) != h || i >= n) return;
-    R[cabs * npad + i] = FAST ? __builtin_amdgcn_exp2f(-0.5f * nx) * tot : tot;
+    R[cabs * npad + i] = FAST ? er * tot : tot;
 }
 
 struct MfmaArgs {
@@ -651,7 +682,7 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
 
 template <int FAM, int K2>
 static int mfma_sym_one(const MfmaArgs& a) {
-    if constexpr (K2 <= 4)
+    if constexpr (K2 <= MFMA_NARROW_MAXK2)
         hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
                            (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
     else

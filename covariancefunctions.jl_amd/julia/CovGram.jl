@@ -1,39 +1,78 @@
-# CovGram.jl — the reference-side binding a maintainer would add: `ccall` stubs for libcovgram.so and the
-# `mul!` methods that route the hot path of CovarianceFunctions.jl (v0.3.5) to the MI355X engine.
+# CovGram.jl — the reference-side binding a maintainer would add: `ccall` stubs for libcovgram.so and the methods that route
+# the hot path of CovarianceFunctions.jl (v0.3.5) — `gramian` dispatch, `mul!`, `Matrix` — to the MI355X engine.
 #
-# WRITTEN BLIND: Julia is not installed in the build image, so this file has never been executed.  All logic
-# lives in the C library; this shim is declarative (struct mirror, kernel lowering, ccall).  The executed and
-# tested host mirror is the Python package next to it (covgram/).
+# WRITTEN BLIND: Julia is not installed in the build image, so this file has never been executed.  All logic lives in the C
+# library; this shim is declarative (struct mirrors, kernel lowering, ccall).  What CAN be checked without Julia is checked:
+# tests/test_host.py::test_julia_shim_mirrors_the_header parses the `struct` blocks and the `ccall` argument-type tuples below
+# and compares them with include/covgram.h (tests/abi_layout.c compiles the header and prints sizeof / offsetof of every
+# field), so a drift between this file and the header fails the CPU test suite.  At load time the module additionally
+# asserts sizeof(CKernel) / sizeof(CComposite) against the library's own covgram_sizeof_*().
+# The executed and tested host mirror is the Python package next to it (covgram/).
 #
 # Usage:   using CovarianceFunctions, CovGram
+#          CovGram.enable!()                    # from here on the methods below take the device path where input_trait allows
 #          G = gramian(EQ(), X)                 # unchanged, lazy, O(1)
-#          CovGram.enable!()                    # from here on mul!(b, G, a) runs on the GPU when input_trait allows
+#          mul!(b, G, a)                        # covgram_mvm
+#          T = gramian(Exp(), range(-1, 1, length = 2^22))     # DeviceToeplitz (covgram_toeplitz_*)
+#
+# One context = one device + one stream (include/covgram.h: covgram_ctx_create(ctx, device_id, stream)); a multi-GPU job is
+# one Julia process per GPU (MPI.jl), each with its own context — the library holds no multi-device state.
 module CovGram
 
 using LinearAlgebra
 using CovarianceFunctions
-using CovarianceFunctions: Gramian, GradientKernel, IsotropicInput, DotProductInput, GenericInput, input_trait,
-                           EQ, RQ, Exp, γExp, Cauchy, InverseMultiQuadratic, MaternP, Dot, ExponentialDot,
-                           Lengthscale, Power, Product, Constant
+using CovarianceFunctions: Gramian, GradientKernel, ValueGradientKernel, IsotropicInput, DotProductInput, StationaryInput,
+                           GenericInput, input_trait, EQ, RQ, Exp, γExp, Cauchy, InverseMultiQuadratic, MaternP, Dot,
+                           ExponentialDot, Lengthscale, Power, Product, Sum, Constant, SeparableProduct, LazyGrid, FiniteBasis
+import CovarianceFunctions: gramian
 import BlockFactorizations
 
 const libcovgram = get(ENV, "COVGRAM_LIB", joinpath(@__DIR__, "..", "lib", "libcovgram.so"))
 
-# mirrors `covgram_kernel` of include/covgram.h (field order and types are ABI)
+# ---- struct mirrors of include/covgram.h (field order and types are ABI; checked by tests/test_host.py) ------------------
+const COMPOSITE_MAX_TERMS = 8        # COVGRAM_COMPOSITE_MAX_TERMS
+const COMPOSITE_MAX_FACTORS = 8      # COVGRAM_COMPOSITE_MAX_FACTORS
+
+# mirrors `covgram_kernel`
 struct CKernel
-    family::Int32; trait::Int32; p::Int32; power::Int32
-    param::Float64; lengthscale::Float64; scale::Float64
+    family::Int32
+    trait::Int32
+    p::Int32
+    power::Int32
+    param::Float64
+    lengthscale::Float64
+    scale::Float64
 end
+
+# mirrors `covgram_kernel_composite`: k = head.scale * sum_t prod_f factors; every entry point accepts a pointer to its first
+# member (`head`, family = 101) in place of a CKernel
+struct CComposite
+    head::CKernel
+    nterms::Int32
+    nfactors::NTuple{8, Int32}
+    factors::NTuple{8, CKernel}
+end
+
 const F_EQ, F_EXP, F_RQ, F_GAMMAEXP, F_CAUCHY, F_IMQ, F_MATERNP, F_DOT, F_EXPDOT = Int32.(0:8)
+const F_CONSTANT, F_COMPOSITE = Int32(100), Int32(101)
 const ISO, DOTP = Int32(1), Int32(2)
 const HOST, DEVICE = Int32(0), Int32(1)
 dtype_code(::Type{Float32}) = Int32(0); dtype_code(::Type{Float64}) = Int32(1)
+const DevFloat = Union{Float32, Float64}
+
+function __init__()
+    isfile(libcovgram) || return          # enable!() reports the missing library
+    sk = ccall((:covgram_sizeof_kernel, libcovgram), Cint, ())
+    sc = ccall((:covgram_sizeof_composite, libcovgram), Cint, ())
+    (sk == sizeof(CKernel) && sc == sizeof(CComposite)) ||
+        error("CovGram.jl and libcovgram.so disagree on the ABI: covgram_kernel $(sizeof(CKernel)) vs $sk bytes, covgram_kernel_composite $(sizeof(CComposite)) vs $sc")
+end
 
 check(rc) = rc == 0 ? nothing :
     (msg = unsafe_string(ccall((:covgram_last_error, libcovgram), Cstring, ()));
      rc == -1 ? throw(DimensionMismatch(msg)) : error("libcovgram status $rc: $msg"))
 
-# lowering: the same closed set `covgram.kernels.device_spec` handles; anything else -> nothing (GenericInput path)
+# ---- lowering: the same closed set `covgram.kernels.device_spec` handles; anything else -> nothing (GenericInput path) ----
 lower(k; scale = 1.0, power = 1, l = 1.0) = nothing
 lower(::EQ; kw...)            = ckernel(F_EQ, ISO; kw...)
 lower(::Exp; kw...)           = ckernel(F_EXP, ISO; kw...)
@@ -55,18 +94,55 @@ end
 ckernel(f, t; p = 0, param = 0.0, scale = 1.0, power = 1, l = 1.0) =
     (t == DOTP && l != 1.0) ? nothing : CKernel(f, t, Int32(p), Int32(power), Float64(param), Float64(l), Float64(scale))
 
-# context: one per process/device, default (null) stream
+# Sum / Product / Power with a common trait (src/algebra.jl:5-63, src/properties.jl:47-63) -> CComposite, or nothing.
+# A term is a Product (or a single kernel); each of its non-Constant factors must lower to a CKernel of the common trait.
+# (covgram/kernels.py::device_spec is the executed version of this flattening, including the merge of like factors.)
+const NOKERNEL = CKernel(F_CONSTANT, Int32(0), Int32(0), Int32(1), 0.0, 1.0, 0.0)
+function lower_composite(k)
+    terms = k isa Sum ? collect(k.args) : [k]
+    length(terms) ≤ COMPOSITE_MAX_TERMS || return nothing
+    nfac = zeros(Int32, COMPOSITE_MAX_TERMS); facs = CKernel[]; trait = Int32(0)
+    for (t, term) in enumerate(terms)
+        parts = term isa Product ? collect(term.args) : [term]
+        for part in parts
+            f = part isa Constant ? CKernel(F_CONSTANT, Int32(0), Int32(0), Int32(1), 0.0, 1.0, Float64(part.c)) : lower(part)
+            f === nothing && return nothing
+            if f.family != F_CONSTANT
+                trait == 0 && (trait = f.trait)
+                trait == f.trait || return nothing                       # mixed traits: GenericInput (src/properties.jl:47-63)
+            end
+            push!(facs, f); nfac[t] += 1
+        end
+    end
+    (trait != 0 && length(facs) ≤ COMPOSITE_MAX_FACTORS) || return nothing
+    while length(facs) < COMPOSITE_MAX_FACTORS; push!(facs, NOKERNEL); end
+    CComposite(CKernel(F_COMPOSITE, trait, Int32(0), Int32(1), 0.0, 1.0, 1.0), Int32(length(terms)), Tuple(nfac), Tuple(facs))
+end
+# what the entry points take: Ref{CKernel}, or Ref{CComposite} (same address as its head)
+device_kernel(k) = (s = lower(k); s === nothing ? lower_composite(k) : s)
+device_kernel_for(k) = ENABLED[] && input_trait(k) isa Union{IsotropicInput, DotProductInput} ? device_kernel(k) : nothing
+kref(s::CKernel) = Ref(s)
+kref(s::CComposite) = Ref(s)
+
+# ---- context: one per process = one device + its default stream ---------------------------------------------------------
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+const DEVICE_ID = Ref{Cint}(0)           # set before the first call (e.g. from the MPI local rank): one process per GPU
 function ctx()
     if CTX[] == C_NULL
-        check(ccall((:covgram_ctx_create, libcovgram), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}), CTX, 0, C_NULL))
+        check(ccall((:covgram_ctx_create, libcovgram), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}), CTX, DEVICE_ID[], C_NULL))
     end
     CTX[]
 end
 
-# device-resident copy of a point set, cached per Gramian input so Krylov solvers upload x once
+# ---- device-resident copy of a point set ---------------------------------------------------------------------------------
+# Cached per (input object, element type) so Krylov solvers upload x once.  The library's contract for a handle is "unchanged
+# while the handle lives" (include/covgram.h: covgram_points_create), whereas the reference's lazy Gramian follows in-place
+# updates of x; the cache therefore keeps a fingerprint (length, dimension, a hash of ≤ 4096 strided scalars) and re-uploads
+# when it changes; `CovGram.refresh!(x)` forces it after an update the sample might miss.  Keys are weak: the Points
+# finalizer runs (and frees the HBM copy) once x itself is garbage.
 mutable struct Points
     handle::Ptr{Cvoid}
+    fingerprint::UInt
     function Points(x::AbstractVector, ::Type{T}) where {T}
         d = length(x[1]); n = length(x)
         X = Matrix{T}(undef, d, n)                      # d×n column-major == point-major, as gramian.jl:2,154-155
@@ -74,65 +150,100 @@ mutable struct Points
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:covgram_points_create, libcovgram), Cint,
                     (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Int32, Int32, Int32), ctx(), h, X, n, d, dtype_code(T), HOST))
-        p = new(h[]); finalizer(q -> ccall((:covgram_points_destroy, libcovgram), Cint, (Ptr{Cvoid},), q.handle), p); p
+        p = new(h[], fingerprint(x))
+        finalizer(q -> ccall((:covgram_points_destroy, libcovgram), Cint, (Ptr{Cvoid},), q.handle), p)
+        p
     end
 end
-const POINTS = IdDict{Any, Points}()
-points(x, T) = get!(() -> Points(x, T), POINTS, x)
+function fingerprint(x::AbstractVector)
+    n = length(x); n == 0 && return UInt(0)
+    d = length(x[1]); h = hash((n, d))
+    for j in 1:max(1, n ÷ 1024):n
+        xj = x[j]
+        for c in 1:max(1, d ÷ 4):d; h = hash(xj[c], h); end
+    end
+    h
+end
+const POINTS = WeakKeyDict{Any, Dict{DataType, Points}}()
+function points(x, ::Type{T}) where {T}
+    per = get!(() -> Dict{DataType, Points}(), POINTS, x)
+    p = get(per, T, nothing)
+    if p === nothing || p.fingerprint != fingerprint(x)
+        p = Points(x, T); per[T] = p                   # the old handle is freed by its finalizer
+    end
+    p
+end
+refresh!(x) = (delete!(POINTS, x); nothing)
 
 const ENABLED = Ref(false)
-enable!() = (ENABLED[] = true); disable!() = (ENABLED[] = false)
+function enable!()
+    isfile(libcovgram) || error("$libcovgram not found: build it with `make -C covariancefunctions.jl_amd -j8`; there is no CPU fallback inside the library")
+    ENABLED[] = true
+end
+disable!() = (ENABLED[] = false)
 
 # --- src/gramian.jl:78-87 / 89-99 --------------------------------------------------------------------------------
-function device_mul!(y::StridedVecOrMat{T}, G::Gramian{T}, a::StridedVecOrMat{T}, α, β, spec::CKernel) where {T <: Union{Float32, Float64}}
+function device_mul!(y::StridedVecOrMat{T}, G::Gramian, a::StridedVecOrMat{T}, α, β, spec) where {T <: DevFloat}
     n, m = size(G)
     size(a, 1) == m && size(y, 1) == n && size(y, 2) == size(a, 2) || throw(DimensionMismatch("mul!: size mismatch"))
     X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
     check(ccall((:covgram_mvm, libcovgram), Cint,
-                (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
-                ctx(), spec, X.handle, Y.handle, a, stride(a, 2) == 0 ? m : max(stride(a, 2), m), y, max(stride(y, 2), n),
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
+                ctx(), kref(spec), X.handle, Y.handle, a, stride(a, 2) == 0 ? m : max(stride(a, 2), m), y, max(stride(y, 2), n),
                 size(a, 2), Float64(α), Float64(β), HOST))
     return y
 end
 
-function LinearAlgebra.mul!(y::StridedVector{T}, G::Gramian{T}, a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: Union{Float32, Float64}}
-    spec = ENABLED[] && input_trait(G.k) isa Union{IsotropicInput, DotProductInput} ? lower(G.k) : nothing
+function LinearAlgebra.mul!(y::StridedVector{T}, G::Gramian{T}, a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    spec = device_kernel_for(G.k)
     spec === nothing ? invoke(mul!, Tuple{AbstractVector, Gramian, AbstractVector, Real, Real}, y, G, a, α, β) :
                        device_mul!(y, G, a, α, β, spec)
 end
-function LinearAlgebra.mul!(Y::StridedMatrix{T}, G::Gramian{T}, A::StridedMatrix{T}, α::Real = 1, β::Real = 0) where {T <: Union{Float32, Float64}}
-    spec = ENABLED[] && input_trait(G.k) isa Union{IsotropicInput, DotProductInput} ? lower(G.k) : nothing
+function LinearAlgebra.mul!(Y::StridedMatrix{T}, G::Gramian{T}, A::StridedMatrix{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    spec = device_kernel_for(G.k)
     spec === nothing ? invoke(mul!, Tuple{AbstractMatrix, Gramian, AbstractMatrix, Real, Real}, Y, G, A, α, β) :
                        device_mul!(Y, G, A, α, β, spec)
 end
 
-# --- src/gramian.jl:241-257 with src/gradient.jl:86-115: flat point-major block vectors ---------------------------
-function device_gradmul!(y::StridedVector{T}, G::Gramian, a::StridedVector{T}, α, β, spec::CKernel) where {T}
+# --- src/gramian.jl:102-114: Matrix(G) -> covgram_matrix (HBM-write-bound tile instantiation, copied back) ----------------
+function Base.Matrix(G::Gramian{T}) where {T <: DevFloat}
+    spec = device_kernel_for(G.k)
+    spec === nothing && return invoke(Matrix, Tuple{Gramian}, G)
+    n, m = size(G)
+    M = Matrix{T}(undef, n, m)
     X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
-    check(ccall((:covgram_grad_mvm, libcovgram), Cint,
-                (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
-                ctx(), spec, X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+    check(ccall((:covgram_matrix, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32),
+                ctx(), kref(spec), X.handle, Y.handle, M, n, HOST))
+    return M
+end
+
+# --- src/gramian.jl:241-257 with src/gradient.jl:86-115: flat point-major block vectors ---------------------------
+function device_blockmul!(sym::Symbol, y::StridedVector{T}, G::Gramian, a::StridedVector{T}, α, β, spec) where {T}
+    X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
+    if sym === :grad
+        check(ccall((:covgram_grad_mvm, libcovgram), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
+                    ctx(), kref(spec), X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+    else   # src/gradient.jl:400-474 (ValueGradientKernel), block mul! :319-351: blocks of d+1, value component first
+        check(ccall((:covgram_valgrad_mvm, libcovgram), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
+                    ctx(), kref(spec), X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+    end
     return y
 end
 function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:GradientKernel}},
-                            a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: Union{Float32, Float64}}
+                            a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
     G = B.A
-    spec = ENABLED[] && input_trait(G.k) isa Union{IsotropicInput, DotProductInput} ? lower(G.k.k) : nothing
+    spec = device_kernel_for(G.k.k)
     spec === nothing ? invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β) :
-                       device_gradmul!(y, G, a, α, β, spec)
+                       device_blockmul!(:grad, y, G, a, α, β, spec)
 end
-
-# --- src/gradient.jl:400-474 (ValueGradientKernel), block mul! :319-351: blocks of d+1, value component first ----
-function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:CovarianceFunctions.ValueGradientKernel}},
-                            a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: Union{Float32, Float64}}
+function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:ValueGradientKernel}},
+                            a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
     G = B.A
-    spec = ENABLED[] && input_trait(G.k) isa Union{IsotropicInput, DotProductInput} ? lower(G.k.k) : nothing
-    spec === nothing && return invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β)
-    X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
-    check(ccall((:covgram_valgrad_mvm, libcovgram), Cint,
-                (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
-                ctx(), spec, X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
-    return y
+    spec = device_kernel_for(G.k.k)
+    spec === nothing ? invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β) :
+                       device_blockmul!(:valgrad, y, G, a, α, β, spec)
 end
 
 # --- multi-GPU symmetric form (one Julia process per GPU, e.g. under MPI.jl; x and a replicated) -----------------------
@@ -141,39 +252,31 @@ end
 # ranks is G * a.  `covgram_mvm_sym_supported` tells whether the symmetric matrix-core kernel serves (k, x) — it depends on k
 # and x only, so all ranks take the same branch; otherwise shard rows and all-gather (covgram_mvm on X[lo:hi] × X).
 function sym_partial!(part::Ptr{Cvoid}, G::Gramian, a::Ptr{Cvoid}, rank::Integer, world::Integer)
-    spec = lower(G.k); X = points(G.x, Float32)
+    spec = device_kernel(G.k); spec === nothing && return false
+    X = points(G.x, Float32)
     ok = Ref{Int32}(0)
-    check(ccall((:covgram_mvm_sym_supported, libcovgram), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ref{Int32}), ctx(), spec, X.handle, ok))
+    check(ccall((:covgram_mvm_sym_supported, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}), ctx(), kref(spec), X.handle, ok))
     ok[] == 1 || return false
-    check(ccall((:covgram_mvm_sym_partial, libcovgram), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32),
-                ctx(), spec, X.handle, a, part, Int32(rank), Int32(world)))
+    check(ccall((:covgram_mvm_sym_partial, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32),
+                ctx(), kref(spec), X.handle, a, part, Int32(rank), Int32(world)))
     return true
 end
 
-# --- Sum / Product / Power with a common trait (src/algebra.jl:5-63, src/properties.jl:47-63) ---------------------
-# mirrors `covgram_kernel_composite`: k = head.scale * sum_t prod_f factors; every entry point above accepts a pointer to
-# its first member (`head`, family = 101) in place of a CKernel.  Lowering = flatten the Sum/Product tree to a sum of
-# products of `lower`-able leaves (covgram/kernels.py::device_spec is the executed version of this), e.g.
-#     k = 1.5 * Lengthscale(MaternP(2), 0.7) + 0.5 * EQ()   ->   nterms = 2, nfactors = (1, 1, 0, 0),
-#         factors = (CKernel(F_MATERNP, ISO, 2, 1, 0.0, 0.7, 1.5), CKernel(F_EQ, ISO, 0, 1, 0.0, 1.0, 0.5), ...)
-struct CComposite
-    head::CKernel                       # family = 101 (COVGRAM_COMPOSITE), trait = common trait, power = 1, lengthscale = 1
-    nterms::Int32
-    nfactors::NTuple{4, Int32}
-    factors::NTuple{6, CKernel}         # family 100 (COVGRAM_CONSTANT) = a bare constant factor
+# --- Toeplitz (src/gramian.jl:167-189): the handle caches the plans and the spectrum of the circulant embedding ----------
+mutable struct DeviceToeplitz{T} <: AbstractMatrix{T}
+    handle::Ptr{Cvoid}
+    n::Int
+    m::Int
+    vc::Vector{T}
+    vr::Union{Nothing, Vector{T}}
+    circulant::Bool
 end
-# ccall signature: replace `Ref{CKernel}` by `Ref{CComposite}` (same address as its head).
-
-# --- Toeplitz (src/gramian.jl:167-189): handle caches the plan and spectrum -------------------------------------
-mutable struct DeviceToeplitz{T}
-    handle::Ptr{Cvoid}; n::Int; m::Int
-end
-function DeviceToeplitz(vc::Vector{T}, vr::Union{Nothing, Vector{T}} = nothing; circulant = false) where {T}
+function DeviceToeplitz(vc::Vector{T}, vr::Union{Nothing, Vector{T}} = nothing; circulant = false) where {T <: DevFloat}
     h = Ref{Ptr{Cvoid}}(C_NULL); n = length(vc); m = vr === nothing ? n : length(vr)
     check(ccall((:covgram_toeplitz_create, libcovgram), Cint,
                 (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Int32, Int32),
                 ctx(), h, vc, vr === nothing ? C_NULL : vr, n, m, dtype_code(T), HOST, circulant ? 1 : 0))
-    t = DeviceToeplitz{T}(h[], n, m)
+    t = DeviceToeplitz{T}(h[], n, m, vc, vr, circulant)
     finalizer(q -> ccall((:covgram_toeplitz_destroy, libcovgram), Cint, (Ptr{Cvoid},), q.handle), t); t
 end
 function LinearAlgebra.mul!(y::StridedVector{T}, A::DeviceToeplitz{T}, a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T}
@@ -181,5 +284,80 @@ function LinearAlgebra.mul!(y::StridedVector{T}, A::DeviceToeplitz{T}, a::Stride
                 A.handle, a, y, Float64(α), Float64(β), HOST)); y
 end
 Base.size(A::DeviceToeplitz) = (A.n, A.m)
+function Base.getindex(A::DeviceToeplitz, i::Integer, j::Integer)   # T[i,j] = vc[i-j+1] (i ≥ j), vr[j-i+1] (i < j)
+    A.circulant && return A.vc[mod(i - j, A.n) + 1]
+    i ≥ j ? A.vc[i - j + 1] : (A.vr === nothing ? A.vc[j - i + 1] : A.vr[j - i + 1])
+end
+LinearAlgebra.issymmetric(A::DeviceToeplitz) = A.vr === nothing && !A.circulant
+
+# gramian(k, x::StepRangeLen, y::StepRangeLen, trait): same three cases as src/gramian.jl:172-183; floating-point ranges only
+# (more specific than the reference's method, which stays the fallback)
+function gramian(k, x::StepRangeLen{T}, y::StepRangeLen{T}, t::Union{IsotropicInput, StationaryInput}) where {T <: DevFloat}
+    ENABLED[] || return invoke(gramian, Tuple{Any, StepRangeLen, StepRangeLen, Union{IsotropicInput, StationaryInput}}, k, x, y, t)
+    if x === y
+        DeviceToeplitz(T.(k.(x[1], x)))                                   # SymmetricToeplitz(k1), src/gramian.jl:174-175
+    elseif x.step == y.step
+        DeviceToeplitz(T.(k.(x, y[1])), T.(k.(x[1], y)))                  # Toeplitz(k1, k2), :177-179
+    else
+        Gramian(k, x, y)                                                  # :181
+    end
+end
+# periodic boundary conditions: Circulant(k1), src/gramian.jl:186-189
+function gramian(k::CovarianceFunctions.StationaryKernel, x::StepRangeLen{T}, p::CovarianceFunctions.PeriodicInput) where {T <: DevFloat}
+    ENABLED[] || return invoke(gramian, Tuple{CovarianceFunctions.StationaryKernel, StepRangeLen, CovarianceFunctions.PeriodicInput}, k, x, p)
+    DeviceToeplitz(T.(k.(x[1], x)); circulant = true)
+end
+
+# --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, one strided-batched GEMM per mode ----------
+struct DeviceKronecker{T} <: AbstractMatrix{T}
+    factors::Vector{Matrix{T}}          # F_1 ⊗ F_2 ⊗ … ⊗ F_q in the reference's order (kronecker(G_1, …, G_q))
+end
+Base.size(K::DeviceKronecker) = (prod(size(F, 1) for F in K.factors), prod(size(F, 2) for F in K.factors))
+function Base.getindex(K::DeviceKronecker, i::Integer, j::Integer)
+    v = one(eltype(K)); i -= 1; j -= 1
+    for F in reverse(K.factors)                                           # the LAST factor's index varies fastest
+        r, c = size(F); v *= F[i % r + 1, j % c + 1]; i ÷= r; j ÷= c
+    end
+    v
+end
+function LinearAlgebra.mul!(y::StridedVector{T}, K::DeviceKronecker{T}, a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    q = length(K.factors)
+    ptrs = Ptr{Cvoid}[pointer(F) for F in K.factors]
+    rows = Int64[size(F, 1) for F in K.factors]; cols = Int64[size(F, 2) for F in K.factors]
+    GC.@preserve K check(ccall((:covgram_kron_mvm, libcovgram), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
+        ctx(), ptrs, rows, cols, rows, Int32(q), dtype_code(T), a, y, Float64(α), Float64(β), HOST))
+    y
+end
+function gramian(k::SeparableProduct, X::LazyGrid{T}, Y::LazyGrid{T}) where {T <: DevFloat}
+    ENABLED[] || return invoke(gramian, Tuple{SeparableProduct, LazyGrid, LazyGrid}, k, X, Y)
+    length(X.args) == length(Y.args) || throw(DimensionMismatch("length(X.args) = $(length(X.args)) ≠ $(length(Y.args)) = length(Y.args)"))
+    length(k.args) == length(X.args) || throw(DimensionMismatch("SeparableProduct needs d = $(length(X.args)) kernels but has r = $(length(k.args))"))
+    DeviceKronecker{T}([Matrix{T}(Matrix(gramian(ki, xi, yi))) for (ki, xi, yi) in zip(k.args, X.args, Y.args)])
+end
+
+# --- low rank (src/mercer.jl:53-70, src/lazy_linear_algebra.jl:78-85): U (V' a), vector or matrix right-hand sides -------
+struct DeviceLowRank{T} <: AbstractMatrix{T}
+    U::Matrix{T}
+    V::Matrix{T}
+end
+Base.size(L::DeviceLowRank) = (size(L.U, 1), size(L.V, 1))
+Base.getindex(L::DeviceLowRank, i::Integer, j::Integer) = dot(view(L.U, i, :), view(L.V, j, :))
+function LinearAlgebra.mul!(y::StridedVecOrMat{T}, L::DeviceLowRank{T}, a::StridedVecOrMat{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    n, m = size(L); r = size(L.U, 2)
+    size(a, 1) == m && size(y, 1) == n && size(y, 2) == size(a, 2) || throw(DimensionMismatch("mul!: size mismatch"))
+    check(ccall((:covgram_lowrank_mvm, libcovgram), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
+                ctx(), L.U, n, L.V, m, n, m, r, dtype_code(T), a, max(stride(a, 2), m), y, max(stride(y, 2), n), Int32(size(a, 2)),
+                Float64(α), Float64(β), HOST))
+    y
+end
+function gramian(k::FiniteBasis{T}, x::AbstractVector, y::AbstractVector) where {T <: DevFloat}
+    r = length(k.basis)
+    (ENABLED[] && length(x) > r && length(y) > r) || return invoke(gramian, Tuple{FiniteBasis, AbstractVector, AbstractVector}, k, x, y)
+    U = CovarianceFunctions.basis(k, x)
+    V = x === y ? U : CovarianceFunctions.basis(k, y)
+    DeviceLowRank{T}(U, V)
+end
 
 end # module

@@ -116,6 +116,10 @@ typedef struct covgram_points covgram_points;     /* device-resident point set (
 typedef struct covgram_toeplitz covgram_toeplitz; /* cached circulant spectrum + plans */
 
 int covgram_version(void);
+/* sizeof() of the two structs that cross the ABI by pointer, as THIS build of the library sees them: a binding asserts its
+ * own mirror against these at load time (julia/CovGram.jl does; tests/abi_layout.c checks every field offset). */
+int covgram_sizeof_kernel(void);
+int covgram_sizeof_composite(void);
 const char* covgram_last_error(void);
 int covgram_device_count(int* count);
 

@@ -774,7 +774,7 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
 
 
 def test_eq_matrix_core_gate(cg, oracle):
-    """The expanded exponent is only used while max|x~| max|y~| <= 126, x~ = (x - c) / l relative to the set's own centre c
+    """The expanded exponent is only used while max(max|x~|, max|y~|)^2 <= 126, x~ = (x - c) / l relative to the column set's own centre c
     (a sample mean: here, with n <= 1024, the mean of all points): wide or short-lengthscale data falls back to direct differences (and stays accurate), a translation
     changes nothing; fp64 and the profiles that are not smooth in s never take it."""
     rng = np.random.default_rng(5)
@@ -824,6 +824,138 @@ def test_eq_matrix_core_gate(cg, oracle):
     (cg.gramian(cg.InverseMultiQuadratic(0.01), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 1   # 1/c^2 sensitivity
     (cg.gramian(cg.RQ(1.0), torch.from_numpy(X0).cuda()) @ ad); assert cg.get_info("last_dense_path") == 2
     (cg.gramian(cg.EQ(), torch.from_numpy(X0).cuda()) @ torch.randn(n, 3, device="cuda")); assert cg.get_info("last_dense_path") == 2
+
+
+def rowwise_err(b, ref, absref, L=None):
+    """max_i |b_i - ref_i| / sum_j |k_ij a_j|: the row-wise bound — a norm-wise check cannot see a
+    row whose entries are all tiny (a test point far from the training cloud).
+    With L_i = -ln max_j k_ij given, row i's error is divided by max(1, L_i / 10): exp(-r^2/2) has relative condition number
+    r^2/2 = L, so ANY fp32 evaluation of r^2 — the reference's direct differences (src/util.jl:40-47) included — carries a
+    relative error ~ L * few * 2^-24 in such an entry (L = 35: ~1e-5); rows with a neighbour within r^2/2 <= 10 keep 1e-5."""
+    b = np.asarray(b, dtype=np.float64)
+    e = np.abs(b - ref) / absref
+    if L is not None:
+        e = e / np.maximum(1.0, L / 10.0)
+    return float(np.max(e))
+
+
+def eq_row_logs(X, Y):
+    """L_i = min_j |x_i - y_j|^2 / 2 = -ln max_j k_ij for the EQ kernel (fp64)."""
+    X = X.astype(np.float64); Y = Y.astype(np.float64)
+    d2 = (X * X).sum(1)[:, None] + (Y * Y).sum(1)[None, :] - 2.0 * X @ Y.T
+    return np.maximum(d2.min(1), 0.0) / 2.0
+
+
+SQRT_LOG2E = 1.2011224087864498      # x~ = SQRT_LOG2E * x / l: the scaled units of the matrix-core gate
+
+
+@pytest.mark.parametrize("d", [2, 3, 8])
+def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
+    """round 1's gate bounded only the PRODUCT max|x~| max|y~| <= 126 while the kernel kept
+    e_i = exp2(-|x~_i|^2/2) and a_j e_j as separate fp32 factors, so a test cluster ~16 scaled units from a compact training
+    cluster passed the gate and lost every row to an underflowing e_i.  Now the integer parts of the half-norms ride through the
+    MFMA (every exponential is <= 4), their fractions are factors in (1/2, 1] (dense_mfma.hpp: norm_split), and the gate bounds
+    EACH radius.  Reference behaviour: direct differences never lose these rows
+    (src/util.jl:40-47, src/stationary.jl:42).  Checked norm-wise (<= 1e-5), ROW-wise (|b_i - ref_i| <= 1e-5 max(1, L_i / 10) sum_j |k_ij a_j|,
+    L_i = -ln max_j k_ij: see rowwise_err)
+    and for finiteness, on the library's own choice (dense_variant 0) and with the matrix cores forced where the gate admits them."""
+    rng = np.random.default_rng(4200 + d)
+    ko = oracle.Kernel(oracle.EQ)
+    k = cg.EQ()
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+    def ball(n, radius):          # points in a d-ball of the given radius (scaled units), some ON the sphere
+        u = unit(rng.standard_normal((n, d))) * radius * rng.random((n, 1)) ** (1.0 / d)
+        u[:4] = unit(rng.standard_normal((4, d))) * radius
+        return u
+
+    e1 = np.zeros(d); e1[0] = 1.0
+    cases = []
+    # (name, X~, Y~, expected path under dense_variant 0: 1 direct differences, 2 matrix cores)
+    for off, ry in ((14.0, 7.0), (16.0, 7.0), (18.0, 5.0), (17.5, 6.9)):
+        # X: a cluster of radius 1 at `off` scaled units from the Y ball's centre — round 1: product <= 126 passed, rows = 0
+        cases.append((f"far X cluster {off}/{ry}", ball(300, 1.0) + off * e1, ball(700, ry), 1))
+    # one far outlier row against a tight Y, inside the gate (|x~| = 10.5 -> 110 <= 126) and outside it (15)
+    Xo = ball(257, 3.0); Xo[5] = 10.5 * unit(rng.standard_normal(d)); cases.append(("outlier row 10.5", Xo, ball(600, 3.0), 2))
+    Xo = ball(257, 3.0); Xo[5] = 15.0 * unit(rng.standard_normal(d)); cases.append(("outlier row 15", Xo, ball(600, 3.0), 1))
+    # the mirror: far columns (their weights a_j e_j used to underflow), tight rows
+    Yo = ball(600, 3.0); Yo[7] = 10.5 * unit(rng.standard_normal(d)); Yo[300] = -10.5 * unit(rng.standard_normal(d))
+    cases.append(("outlier columns 10.5", ball(257, 3.0), Yo, 2))
+    # both sets wide and aligned: x~ . y~ reaches ~120 (round 1: exp2(120) * tiny weights)
+    cases.append(("wide aligned", ball(400, 9.8), ball(500, 9.8), 2))
+    # a compact X well inside a wide Y and vice versa
+    cases.append(("compact in wide", ball(300, 2.0) + 5.0 * e1, ball(800, 9.8), 2))
+    try:
+        for name, Xs, Ys, path in cases:
+            X = (Xs / SQRT_LOG2E + 3.0).astype(np.float32); Y = (Ys / SQRT_LOG2E + 3.0).astype(np.float32)   # a common offset changes nothing
+            a = rng.standard_normal(len(Y)).astype(np.float32)
+            ref = oracle.mul(None, ko, X, Y, a, dtype=np.float32)
+            absref = oracle.mul(None, ko, X, Y, np.abs(a), dtype=np.float32)
+            assert np.all(absref > 0)
+            L = eq_row_logs(X, Y)
+            G = cg.gramian(k, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()); ad = torch.from_numpy(a).cuda()
+            cg.set_option("dense_variant", 0)
+            b = (G @ ad).cpu().numpy()
+            assert cg.get_info("last_dense_path") == path, (name, d, cg.get_info("last_dense_path"))
+            assert np.isfinite(b).all(), (name, d)
+            assert relerr(b, ref) <= 1e-5, (name, d, relerr(b, ref))
+            assert rowwise_err(b, ref, absref, L) <= 1e-5, (name, d, rowwise_err(b, ref, absref, L), L.max())
+            print(f"band d={d} {name}: path {path} norm-wise {relerr(b, ref):.2e} row-wise {rowwise_err(b, ref, absref):.2e} scaled {rowwise_err(b, ref, absref, L):.2e} Lmax {L.max():.1f}")
+            if path == 2:      # where the gate admits the matrix cores: every variant of that kernel
+                for rpl, lds in ((1, 0), (2, 0), (2, 1), (1, 1)):
+                    cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds)
+                    b2 = (G @ ad).cpu().numpy()
+                    assert cg.get_info("last_dense_path") == 2
+                    assert np.isfinite(b2).all() and relerr(b2, ref) <= 1e-5 and rowwise_err(b2, ref, absref, L) <= 1e-5, \
+                        (name, d, rpl, lds, relerr(b2, ref), rowwise_err(b2, ref, absref, L))
+                cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1)
+            else:              # forced past the gate the kernel must still be finite and lose no row (it is merely less accurate)
+                cg.set_option("dense_variant", 2)
+                b2 = (G @ ad).cpu().numpy()
+                assert cg.get_info("last_dense_path") == 2 and np.isfinite(b2).all()
+                assert np.all(b2[np.abs(ref) > 1e-30 * np.abs(ref).max()] != 0), (name, d)
+                print(f"   forced past the gate: row-wise {rowwise_err(b2, ref, absref):.2e}")
+                assert rowwise_err(b2, ref, absref) <= 2e-4, (name, d, rowwise_err(b2, ref, absref))
+            # the product is linear in a over the whole fp32 range (the weights stay within a factor 2 of a_j; round 1's a_j e_j
+            # went denormal below |a| ~ 2^-62): scaling a by a power of two scales b (up to the flush of terms < 2^-126)
+            cg.set_option("dense_variant", 0)
+            for sc in (2.0 ** -60, 2.0 ** 60):
+                bs = (G @ (ad * sc)).cpu().numpy().astype(np.float64) / sc
+                ok = (absref * sc > 1e-30) & (absref * sc < 1e30)      # rows whose scaled result fp32 can hold at all
+                assert ok.sum() >= len(ok) // 2 or "far X" in name
+                assert np.isfinite(bs).all() and (not ok.any() or rowwise_err(bs[ok], b.astype(np.float64)[ok], absref[ok]) <= 1e-6), (name, d, sc)
+    finally:
+        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1)
+
+
+@pytest.mark.parametrize("d", [3, 8, 12])
+def test_symmetric_matrix_core_kernels_far_outliers_rowwise(cg, oracle, d):
+    """gramian(k, x) with a few points far from the cloud (|x~ - c| up to 10.5 scaled units, inside the gate): their rows AND
+    their columns must survive on the symmetric and on the general matrix-core kernel — norm-wise, row-wise, finite; EQ and RQ."""
+    rng = np.random.default_rng(4300 + d)
+    n = 1500
+    Xs = rng.standard_normal((n, d)); Xs *= 2.5 / np.sqrt(d)
+    for i, r in ((3, 10.5), (700, 10.0), (1499, 9.0)):
+        v = rng.standard_normal(d); Xs[i] = r * v / np.linalg.norm(v)
+    Xs[701] = Xs[700] * 1.01                                   # a neighbour for one of the outliers
+    X = (Xs / SQRT_LOG2E - 7.0).astype(np.float32)
+    a = rng.standard_normal(n).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+    try:
+        for k, ko in ((cg.EQ(), oracle.Kernel(oracle.EQ)), (cg.RQ(2.0), oracle.Kernel(oracle.RQ, param=2.0))):
+            ref = oracle.mul(None, ko, X, X, a, dtype=np.float32)
+            absref = oracle.mul(None, ko, X, X, np.abs(a), dtype=np.float32)
+            G = cg.gramian(k, Xd)
+            for sym in (0, 1):
+                cg.set_option("mfma_sym", sym)
+                b = (G @ ad).cpu().numpy()
+                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == sym
+                assert np.isfinite(b).all()
+                assert relerr(b, ref) <= 1e-5 and rowwise_err(b, ref, absref) <= 1e-5, (type(k).__name__, d, sym, relerr(b, ref), rowwise_err(b, ref, absref))
+    finally:
+        cg.set_option("mfma_sym", -1)
 
 
 @pytest.mark.parametrize("d", [1, 3, 4, 8, 16, 31])
