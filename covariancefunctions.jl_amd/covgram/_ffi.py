@@ -105,7 +105,7 @@ PROTOTYPES = {
     "covgram_toeplitz_destroy": (C.c_int, [_P]),
     "covgram_kron_mvm": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _I32, _I32,
                                    _P, _P, _D, _D, _I32]),
-    "covgram_lowrank_mvm": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P, _P, _D, _D, _I32]),
+    "covgram_lowrank_mvm": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_debug_kernel_params": (C.c_int, [_KP, _I32, _I32, C.POINTER(_D)]),
 }
 

@@ -578,23 +578,25 @@ class LazyMatrixProduct(LazyOperator):
 
     def mul_(self, y, a, alpha=1.0, beta=0.0):
         a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
-        if a.dim() != 1:
-            for c in range(a.shape[1]):
-                yc = y[:, c].contiguous()
-                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
-                y[:, c] = yc
-            return y
-        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
-            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
         n, m = self.shape
         r = self.U.shape[1]
-        a_c = a.contiguous()
-        y_c = y if y.is_contiguous() else y.contiguous()
+        nrhs = 1 if a.dim() == 1 else a.shape[1]
+        if y.shape[0] != n or y.dtype != self.dtype or (a.dim() == 2 and tuple(y.shape) != (n, nrhs)):
+            raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
+        # matrix right-hand sides go down in ONE call (column-major m x p / n x p): from 8 columns on both products run on the
+        # matrix cores (csrc/lowrank.hip)
+        a_c = a.contiguous() if a.dim() == 1 else a.t().contiguous()
+        if a.dim() == 1:
+            y_c = y if y.is_contiguous() else y.contiguous()
+        else:
+            y_c = y.t().contiguous() if beta != 0 else torch.empty((nrhs, n), dtype=self.dtype, device=self.device)
         ctx = get_ctx(self.device).bind_stream()
         _ffi.check(_ffi.lib().covgram_lowrank_mvm(ctx, _ffi._P(self._Ucm.data_ptr()), n, _ffi._P(self._Vcm.data_ptr()), m, n, m, r,
-                                                  _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()), _ffi._P(y_c.data_ptr()),
+                                                  _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()), m, _ffi._P(y_c.data_ptr()), n, nrhs,
                                                   float(alpha), float(beta), _ffi.DEVICE))
-        if y_c is not y:
+        if a.dim() == 2:
+            y.copy_(y_c.t())
+        elif y_c is not y:
             y.copy_(y_c)
         return y
 

@@ -385,7 +385,8 @@ int covgram_ctx_create(covgram_ctx** out, int device_id, void* hip_stream) {
         return COVGRAM_ENODEVICE;
     }
     CG_REQUIRE(device_id >= 0 && device_id < count, COVGRAM_EINVAL, "device_id %d out of range [0,%d)", device_id, count);
-    CG_CHECK_HIP(hipSetDevice(device_id));
+    ::covgram::DeviceGuard _cg_dev(device_id);
+    CG_REQUIRE(_cg_dev.ok(), COVGRAM_EHIP, "hipSetDevice(%d) failed", device_id);
     hipDeviceProp_t prop;
     CG_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -404,7 +405,7 @@ int covgram_ctx_create(covgram_ctx** out, int device_id, void* hip_stream) {
 int covgram_ctx_destroy(covgram_ctx* ctx) {
     if (!ctx) return COVGRAM_OK;
     CG_REQUIRE(ctx->live_handles == 0, COVGRAM_EINVAL, "ctx destroyed with %d live handles", ctx->live_handles);
-    (void)hipSetDevice(ctx->device);
+    ::covgram::DeviceGuard _cg_dev(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx_blas_destroy(ctx);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
@@ -483,7 +484,7 @@ int covgram_points_create(covgram_ctx* ctx, covgram_points** out, const void* x,
     CG_REQUIRE(n >= 0 && d >= 1, COVGRAM_EINVAL, "points: need n >= 0 and d >= 1 (got n=%lld d=%d)", (long long)n, d);
     CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
     CG_REQUIRE(x != nullptr || n == 0, COVGRAM_EINVAL, "points pointer is NULL");
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     covgram_points* p = new covgram_points();
     p->ctx = ctx; p->n = n; p->d = d; p->dtype = dtype;
     if (loc == COVGRAM_DEVICE) { p->dptr = const_cast<void*>(x); p->owns = false; }
@@ -522,9 +523,13 @@ int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t co
 
 int covgram_points_destroy(covgram_points* p) {
     if (!p) return COVGRAM_OK;
-    if (p->frag_cache) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->frag_cache); }
-    if (p->owns && p->dptr) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->dptr); }
-    if (p->owns_center && p->center_buf) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->center_buf); }
+    {
+        ::covgram::DeviceGuard _cg_dev(p->ctx->device);            // (a finalizer may call this from any thread state)
+        if (p->frag_cache || (p->owns && p->dptr) || (p->owns_center && p->center_buf)) (void)hipStreamSynchronize(p->ctx->stream);
+        if (p->frag_cache) (void)hipFree(p->frag_cache);
+        if (p->owns && p->dptr) (void)hipFree(p->dptr);
+        if (p->owns_center && p->center_buf) (void)hipFree(p->center_buf);
+    }
     p->ctx->live_handles--;
     delete p;
     return COVGRAM_OK;
@@ -687,7 +692,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const bool wide = X->d > kDims[kNumDims - 1];
     const int D = wide ? ((X->d + 31) / 32) * 32 : pad_dim(X->d);
     dense_launch_fn launch = wide ? dense_wide_launcher(hk.tu_family) : dense_launcher(hk.tu_family);
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     if (n == 0) return COVGRAM_OK;
 
     // host staging ---------------------------------------------------------------------------------
@@ -714,10 +719,19 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
 
     // isotropic kernels work relative to the column side's centre (common.hpp: covgram_points::center)
     const void* Cn = (hk.k.trait == COVGRAM_ISOTROPIC) ? Y->center : nullptr;
-    bool mfma = m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
+    // Gramian(Dot(), x, y) = X Y' (src/gramian.jl:23,150-151): the reference goes entry by entry through the generic loop; the
+    // product is X (Y' a), two O((n + m) d) streaming passes (lowrank.hip).  dense_variant = 1 / 2 keep the entry-by-entry kernels.
+    const bool dotfac = m > 0 && hk.tu_family == COVGRAM_DOT && hk.k.power == 1 && ctx->dense_variant == 0 &&
+                        (size_t)X->d * (size_t)nrhs * ts <= 65536;
+    if (dotfac) {
+        rc = mvm_dot_factored(ctx, hk, X, Y, a_dev, lda_d, y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
+        ctx->last_dense_path = 4;
+    }
+    bool mfma = !dotfac && m > 0 && mfma_eq_eligible(ctx, hk, X, Y, nrhs);
     const bool sym = mfma && mfma_eq_sym_eligible(ctx, hk, X, Y, nrhs);
     ctx->last_mfma_sym = sym ? 1 : 0;
-    if (sym) { rc = mvm_eq_mfma_sym(ctx, hk, X, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
+    if (dotfac) mfma = true;                                     // (handled: skip the kernels below)
+    else if (sym) { rc = mvm_eq_mfma_sym(ctx, hk, X, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
         mfma = true;
@@ -728,7 +742,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             rc = mvm_mfma_gen(ctx, k, X, Y, (const float*)a_dev, lda_d, (float*)y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
         }
     }
-    if (m > 0) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
+    if (m > 0 && !dotfac) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NRpad = (nr == 1) ? 1 : 4;
@@ -810,7 +824,7 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
     HostKernel hk;
     rc = make_host_kernel(k, dtype, true, &hk);   // gamma = 1/l, unfolded EQ
     if (rc) return rc;
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     if (n == 0 || m == 0) return COVGRAM_OK;
     void* o = out;
     int64_t ld = ldo;
@@ -877,7 +891,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
                       (hk.tu_family >= COVGRAM_NFAMILY && ctx->grad_keep_r < 0 && d >= 8);
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(hk.tu_family);
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     if (n == 0) return COVGRAM_OK;
 
     const void* a_dev = a;
@@ -1026,7 +1040,7 @@ int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const cov
     int rc = covgram_mvm_sym_supported(ctx, k, X, &ok);
     if (rc) return rc;
     if (!ok) { set_error("symmetric matrix-core kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     HostKernel hk;
     rc = make_host_kernel(k, X->dtype, false, &hk);
     if (rc) return rc;

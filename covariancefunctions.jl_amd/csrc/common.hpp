@@ -35,6 +35,26 @@ void set_error(const char* fmt, ...);
         }                                        \
     } while (0)
 
+// Every entry point runs on its ctx's device and leaves the CALLER's current device as it found it (a process that holds
+// tensors on several GPUs must not have its current device changed behind its back, also not from a destroy call that a
+// garbage collector runs at an arbitrary time).
+struct DeviceGuard {
+    int prev = -1;
+    bool good = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) { good = hipSetDevice(dev) == hipSuccess; prev = cur; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    bool ok() const { return good; }
+};
+#define CG_DEVICE(ctx)                                                                             \
+    ::covgram::DeviceGuard _cg_dev((ctx)->device);                                                 \
+    CG_REQUIRE(_cg_dev.ok(), COVGRAM_EHIP, "hipSetDevice(%d) failed", (ctx)->device)
+
 // ---------------------------------------------------------------------------------------------
 // Device-side kernel parameters (passed by value in the kernarg segment -> scalar loads).
 // The host fills the double version from covgram_kernel; kernels receive the T version.
@@ -141,7 +161,7 @@ struct covgram_ctx {
     bool own_stream = false;
     covgram::Workspace ws[5];  // 0: packed tile stream, 1: split-J partials, 2/3: host staging (device copies of a / y), 4: wide-gradient slices
     // options
-    int64_t dense_variant = 0;   // 0 auto (fp32 EQ on the matrix cores when the norm bound allows), 1 direct differences, 2 MFMA whenever the shape allows
+    int64_t dense_variant = 0;   // 0 auto (fp32 EQ on the matrix cores when the norm bound allows; Dot() as X (Y' a)), 1 direct differences / entry by entry, 2 MFMA whenever the shape allows
     int64_t rows_per_lane = 0;   // 0 = auto
     int64_t jsplit = 0;          // 0 = auto
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
@@ -154,7 +174,7 @@ struct covgram_ctx {
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
-    int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix-core EQ, 3 wide rows
+    int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix cores, 3 wide rows, 4 factored dot product X (Y' a)
     int32_t* sym_map = nullptr;  // symmetric kernel: device list of its (local panel, chunk) workgroups, keyed by sym_key
     size_t sym_map_cap = 0, sym_map_len = 0;
     int64_t sym_key[4] = {-1, -1, -1, -1};
@@ -256,6 +276,10 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);
+
+// Gramian(Dot(), x, y) = X Y' as two streaming passes over the point sets (lowrank.hip)
+int mvm_dot_factored(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, const void* a, int64_t lda, void* y,
+                     int64_t ldy, int32_t nrhs, double alpha, double beta);
 
 void ctx_blas_destroy(covgram_ctx* ctx);
 

@@ -574,7 +574,7 @@ extern "C" {
 
 int covgram_toeplitz_destroy(covgram_toeplitz* T) {
     if (!T) return COVGRAM_OK;
-    (void)hipSetDevice(T->ctx->device);
+    ::covgram::DeviceGuard _cg_dev(T->ctx->device);
     (void)hipStreamSynchronize(T->ctx->stream);
     if (T->fwd) rocfft_plan_destroy(T->fwd);
     if (T->inv) rocfft_plan_destroy(T->inv);
@@ -597,7 +597,7 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
     if (!vr) m = n;
     CG_REQUIRE(m >= 1, COVGRAM_EINVAL, "toeplitz: m must be >= 1");
     CG_REQUIRE(!(circulant && vr), COVGRAM_EINVAL, "circulant takes a first column only");
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     const size_t ts = dtype_size(dtype);
     if (g_rocfft_users++ == 0) rocfft_setup();
     covgram_toeplitz* T = new covgram_toeplitz();
@@ -701,7 +701,7 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
 int covgram_toeplitz_mvm(covgram_toeplitz* T, const void* a, void* y, double alpha, double beta, int32_t loc) {
     CG_REQUIRE(T && a && y, COVGRAM_EINVAL, "NULL argument");
     covgram_ctx* ctx = T->ctx;
-    CG_CHECK_HIP(hipSetDevice(ctx->device));
+    CG_DEVICE(ctx);
     const size_t ts = dtype_size(T->dtype);
     const int64_t n = T->n, m = T->m, N = T->N, NC = N / 2 + 1;
     const void* a_dev = a; void* y_dev = y;

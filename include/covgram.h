@@ -130,7 +130,8 @@ int covgram_ctx_destroy(covgram_ctx* ctx);
 int covgram_ctx_set_stream(covgram_ctx* ctx, void* hip_stream);
 int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 /* tuning / A-B knobs: "dense_variant" (0 = auto: fp32 EQ runs on the matrix cores when the norm bound of dense_mfma.hip
- * holds, 1 = always the direct-difference kernel, 2 = matrix cores whenever the shape allows), "rows_per_lane", "jsplit",
+ * holds and the plain dot-product Gramian is applied as X (Y' a), 1 = always the entry-by-entry direct kernel, 2 = matrix
+ * cores whenever the shape allows), "rows_per_lane", "jsplit",
  * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused", "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
@@ -138,7 +139,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
- * 2 matrix-core EQ, 3 wide rows), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
+ * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
  * MVM ran the symmetric upper-triangle kernel), "num_cus". */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
@@ -205,10 +206,12 @@ int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t
                      const int64_t* lds, int32_t q, int32_t dtype, const void* a, void* y, double alpha,
                      double beta, int32_t loc);
 
-/* y <- alpha * U (V' a) + beta * y;  U: n×r (ldu), V: m×r (ldv), column-major. */
-int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void* V, int64_t ldv, int64_t n,
-                        int64_t m, int64_t r, int32_t dtype, const void* a, void* y, double alpha, double beta,
-                        int32_t loc);
+/* Y <- alpha * U (V' A) + beta * Y;  U: n×r (ldu), V: m×r (ldv), A: m×nrhs (lda >= m), Y: n×nrhs (ldy >= n), column-major.
+ * nrhs >= 8: both tall-skinny products run on the matrix cores in the data's own precision (v_mfma_f32_32x32x2_f32 /
+ * v_mfma_f64_16x16x4_f64); fewer right-hand sides: streaming GEMV kernels, one pair per column. */
+int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void* V, int64_t ldv, int64_t n, int64_t m,
+                        int64_t r, int32_t dtype, const void* a, int64_t lda, void* y, int64_t ldy, int32_t nrhs,
+                        double alpha, double beta, int32_t loc);
 
 /* Test hook: the double-precision parameter block handed to the device kernels for `k`
  * (out45[0..8] = gamma, gamma^2, scale, param, c0, 2p+1, Taylor bound, d1, d2; then the MaternP tables

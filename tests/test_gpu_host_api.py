@@ -139,7 +139,7 @@ def test_host_pointer_toeplitz_kron_lowrank(cg, oracle, ctx):
     U = rng.standard_normal((n, r)); V = rng.standard_normal((m, r))
     Uc = np.asfortranarray(U); Vc = np.asfortranarray(V)
     a = rng.standard_normal(m); y = rng.standard_normal(n); y0 = y.copy()
-    f.check(lib.covgram_lowrank_mvm(ctx, P(Uc), n, P(Vc), m, n, m, r, f.F64, P(a), P(y), 2.0, 0.25, f.HOST))
+    f.check(lib.covgram_lowrank_mvm(ctx, P(Uc), n, P(Vc), m, n, m, r, f.F64, P(a), m, P(y), n, 1, 2.0, 0.25, f.HOST))
     assert relerr(y, oracle.lowrank_mul(y0, U, V, a, 2.0, 0.25)) <= 1e-12
 
 

@@ -254,6 +254,87 @@ def test_lowrank_finite_basis(cg, oracle):
     assert relerr((G2 @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.lowrank_mul(None, Un, Vn, av)) <= 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_lowrank_matrix_rhs_on_the_matrix_cores(cg, oracle, dtype):
+    """LazyMatrixProduct(U, V') with a matrix right-hand side (src/lazy_linear_algebra.jl:78-85): from 8 columns on both
+    tall-skinny products run on the matrix cores in the data's own precision (csrc/lowrank.hip); fewer columns take the GEMV
+    pair per column.  Ragged n / m / r / p (tiles end past every edge), U is V and U is not V, alpha / beta, NaN in y with
+    beta = 0, and the raw C ABI with padded leading dimensions."""
+    from covgram import _ffi as f
+    import ctypes as C
+    rng = np.random.default_rng(61)
+    dt = npdt(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    for (n, m, r, p) in ((1000, 777, 5, 8), (4099, 3001, 33, 12), (2500, 2500, 64, 40), (1031, 999, 130, 70), (300, 311, 200, 9), (5000, 40000, 17, 3)):
+        U = rng.standard_normal((n, r)).astype(dt); V = U if n == m else rng.standard_normal((m, r)).astype(dt)
+        A = rng.standard_normal((m, p)).astype(dt); Y0 = rng.standard_normal((n, p)).astype(dt)
+        Ud = torch.from_numpy(U).cuda(); Vd = Ud if V is U else torch.from_numpy(V).cuda()
+        L = cg.LazyMatrixProduct(Ud, Vd)
+        Yd = torch.from_numpy(Y0.copy()).cuda()
+        out = cg.mul_(Yd, L, torch.from_numpy(A).cuda(), 1.7, -0.4)
+        assert out is Yd
+        ref = oracle.lowrank_mul(Y0, U, V, A, 1.7, -0.4)
+        for c in range(p):
+            assert relerr(Yd.cpu().numpy()[:, c], ref[:, c]) <= tol, (n, m, r, p, c, relerr(Yd.cpu().numpy()[:, c], ref[:, c]))
+        Yn = torch.full((n, p), float("nan"), dtype=dtype, device="cuda")
+        cg.mul_(Yn, L, torch.from_numpy(A).cuda(), 1.0, 0.0)
+        assert relerr(Yn.cpu().numpy(), oracle.lowrank_mul(None, U, V, A)) <= tol
+        assert relerr((L @ torch.from_numpy(A).cuda()).cpu().numpy(), oracle.lowrank_mul(None, U, V, A)) <= tol
+    # raw ABI, host pointers, leading dimensions larger than the matrices
+    n, m, r, p, ldu, ldv, lda, ldy = 700, 520, 19, 11, 704, 528, 523, 777
+    U = np.zeros((r, ldu), dt); V = np.zeros((r, ldv), dt); A = np.zeros((p, lda), dt); Y = np.full((p, ldy), 7.0, dt)     # column-major storage
+    U[:, :n] = rng.standard_normal((r, n)); V[:, :m] = rng.standard_normal((r, m)); A[:, :m] = rng.standard_normal((p, m)); Y[:, :n] = rng.standard_normal((p, n))
+    Y0 = Y.copy()
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    ctx = cg.get_ctx().bind_stream()
+    f.check(f.lib().covgram_lowrank_mvm(ctx, P(U), ldu, P(V), ldv, n, m, r, f.F32 if dtype == torch.float32 else f.F64, P(A), lda, P(Y), ldy, p, -0.8, 0.3, f.HOST))
+    ref = oracle.lowrank_mul(Y0[:, :n].T, U[:, :n].T, V[:, :m].T, A[:, :m].T, -0.8, 0.3)
+    assert relerr(Y[:, :n].T, ref) <= tol
+    assert np.all(Y[:, n:] == 7.0)                                  # the padding rows of y are not touched
+    with pytest.raises(f.DimensionMismatch):
+        f.check(f.lib().covgram_lowrank_mvm(ctx, P(U), ldu, P(V), ldv, n, m, r, f.F32 if dtype == torch.float32 else f.F64, P(A), m - 1, P(Y), ldy, p, 1.0, 0.0, f.HOST))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d", [1, 3, 17, 70])
+def test_dot_gramian_is_applied_as_x_yt_a(cg, oracle, dtype, d):
+    """Gramian(Dot(), x, y) (src/gramian.jl:23,150-151; src/mercer.jl:6-9) is X Y': the library applies it as X (Y' a) — two
+    streaming passes instead of the reference's O(n m d) entry loop — for vectors and matrices, alpha / beta, a scaled kernel;
+    dense_variant = 1 keeps the entry-by-entry kernel and both agree with the oracle.  Dot()^2 is not a product of thin factors."""
+    rng = np.random.default_rng(70 + d)
+    dt = npdt(dtype)
+    tol = TOL[dtype]
+    n, m = 1300, 2111
+    X = rng.standard_normal((n, d)).astype(dt); Y = rng.standard_normal((m, d)).astype(dt)
+    Xd = torch.from_numpy(X).cuda(); Yd = torch.from_numpy(Y).cuda()
+    try:
+        for k, ko in ((cg.Dot(), oracle.Kernel(oracle.DOT)), (2.5 * cg.Dot(), oracle.Kernel(oracle.DOT, scale=2.5))):
+            G = cg.gramian(k, Xd, Yd)
+            for p in (1, 3, 9):
+                a = rng.standard_normal((m, p) if p > 1 else m).astype(dt); y0 = rng.standard_normal((n, p) if p > 1 else n).astype(dt)
+                ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, dt)
+                got = {}
+                for variant in (0, 1):
+                    cg.set_option("dense_variant", variant)
+                    yd = torch.from_numpy(y0.copy()).cuda()
+                    cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
+                    assert cg.get_info("last_dense_path") == (4 if variant == 0 else (1 if d <= 64 else 3)), (variant, d, cg.get_info("last_dense_path"))
+                    got[variant] = yd.cpu().numpy()
+                    assert relerr(got[variant], ref) <= tol, (variant, d, p, relerr(got[variant], ref))
+                cg.set_option("dense_variant", 0)
+                yn = torch.full(y0.shape, float("nan"), dtype=dtype, device="cuda")
+                cg.mul_(yn, G, torch.from_numpy(a).cuda(), 1.0, 0.0)
+                assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, Y, a, 1.0, 0.0, dt)) <= tol
+        # gramian(x, y) == Gramian(Dot(), x, y) and the symmetric case
+        G1 = cg.gramian(Xd, Yd); a = rng.standard_normal(m).astype(dt)
+        assert relerr((G1 @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.DOT), X, Y, a, dtype=dt)) <= tol
+        assert cg.get_info("last_dense_path") == 4
+        G2 = cg.gramian(cg.Dot() ** 2, Xd, Yd); (G2 @ torch.from_numpy(a).cuda())
+        assert cg.get_info("last_dense_path") != 4
+    finally:
+        cg.set_option("dense_variant", 0)
+
+
 def test_errors_and_traits(cg):
     x = torch.randn(10, 3, device="cuda", dtype=torch.float64)
     with pytest.raises(cg.DimensionMismatch):
