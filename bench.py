@@ -1,8 +1,8 @@
-#!/usr/bin/env python3
 """bench.py — the contract benchmark: Gramian MVMs/s for the dense EQ kernel, n = 131072, d = 3, fp32
 (BASELINE.json metric / configs[1]) on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python3 bench.py [--gpus N] [--steps K] [--warmup W]          (run it as `python3 bench.py`, also after `rocprofv3 ... --`:
+                                                                     the file has no shebang, so nothing re-execs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one full MVM b = G a with the points, a and b resident in HBM.  The contract run follows SURVEY.md §8d: y == x,
@@ -16,7 +16,10 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                 (the path is VALU/transcendental-bound; the HBM figures BASELINE.json's metric name asks
                 for are reported alongside as hbm_*), duration measured live with HIP events on the launch stream;
   cpu_baseline  the C restatement of src/gramian.jl:78-87 (oracle/, "port") timed on this host's cores on a bounded
-                row slice (rank 0, N = 1 only).
+                row slice (rank 0, N = 1 only) — BEFORE the first GPU call, so that the compiler it may spawn is never a
+                child of a process that has initialised the GPU;
+  configs       (N = 1) the other BASELINE.json configs at their stated sizes — C1, one rank's share of C3 (row shard and symmetric
+                partial), C4, C5 — each with ms per MVM, rel-err against the oracle and its own roofline.
 """
 from __future__ import annotations
 
@@ -50,13 +53,17 @@ def cpu_baseline(X: np.ndarray, a: np.ndarray, budget_s: float = 12.0):
     import ctypes
     import c_oracle
     out_dir = None
+    # under a profiler (rocprofv3 preloads its library into every child) nothing is spawned: the prebuilt object is loaded in-process
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
     try:   # rebuild for this host's ISA; fall back to the prebuilt portable object
+        if profiled:
+            raise RuntimeError("profiler preload detected")
         out_dir = tempfile.mkdtemp(prefix="covgram_oracle_")
         c_oracle.build(march="native", out=out_dir)
         lib = ctypes.CDLL(os.path.join(out_dir, "libcovgram_cpubaseline.so"))
         flags = "-O3 -march=native -fopenmp -ffast-math"
     except Exception:
-        lib = c_oracle._load("libcovgram_cpubaseline.so")
+        lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "build", "libcovgram_cpubaseline.so"))
         flags = "-O3 -march=x86-64-v3 -fopenmp -ffast-math (prebuilt)"
     threads = c_oracle.num_threads(lib)
     n = X.shape[0]
@@ -81,12 +88,117 @@ def cpu_baseline(X: np.ndarray, a: np.ndarray, budget_s: float = 12.0):
     }
 
 
+def _timed(fn, warm=5, reps=20, after_warm=None):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    if after_warm is not None:
+        after_warm()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def _rel(b, ref):
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(b - ref) / np.linalg.norm(ref))
+
+
+def other_configs(cg, dev):
+    """BASELINE.json configs[0], [2], [3], [4] at their stated sizes on this one GPU: ms per MVM (host wall over back-to-back calls,
+    inputs resident), rel-err against the oracle (checker, outside the timed loops) and the roofline SURVEY.md §8d assigns."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import covgram_oracle as o
+    import c_oracle
+    out = {}
+    # C1: MaternP(2), d=3, n=4096, fp64 (the reference's CPU-runnable case, here through the device path)
+    n, d = 4096, 3
+    rng = np.random.default_rng(0xC0F + 0)
+    Xh = rng.standard_normal((n, d)); ah = rng.standard_normal(n)
+    G = cg.gramian(cg.MaternP(2), torch.from_numpy(Xh).to(dev)); a = torch.from_numpy(ah).to(dev); y = torch.empty_like(a)
+    ms = _timed(lambda: G.mul_(y, a))
+    fl = float(n) * n * (3 * d + 3)
+    out["C1"] = {"what": "MaternP(2) dense Gramian mul!, d=3 n=4096 fp64", "ms": ms, "mvm_per_s": 1e3 / ms,
+                 "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), Xh, Xh, ah)),
+                 "roofline": {"bound": "valu_fp64", "achieved": fl / (ms * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) * 1e-12 / 78.6,
+                              "note": "1.7e7 pairs: launch-bound (three launches), not a roofline case"}}
+    # C3: EQ, d=8, n=524288, fp32 — what ONE of the 8 ranks computes (the 8-GPU run itself is the driver's)
+    n, d, world = 524288, 8, 8
+    rng = np.random.default_rng(0xC0F + 2)
+    Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+    X = torch.from_numpy(Xh).to(dev); a = torch.from_numpy(ah).to(dev)
+    per = n // world
+    G = cg.gramian(cg.EQ(), X[:per], X); y = torch.empty(per, dtype=torch.float32, device=dev)
+    cg.set_option("time_kernels", 1)
+    ms = _timed(lambda: G.mul_(y, a), warm=3, reps=10, after_warm=cg.kernel_time)
+    kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
+    rows = np.sort(np.random.default_rng(2).choice(per, 256, replace=False))
+    ref = c_oracle.mvm(o.Kernel(o.EQ), Xh[rows].astype(np.float64), Xh.astype(np.float64), ah.astype(np.float64))
+    fl = float(per) * n * (3 * d + 3)
+    kavg = kms / max(kl, 1)
+    out["C3_shard"] = {"what": "EQ dense Gramian mul!, d=8 n=524288 fp32: one rank's row shard of the 8-GPU config (65536 rows x 524288 columns, all entries)",
+                       "ms": ms, "kernel_avg_ms": kavg, "pairs_per_s": float(per) * n / (ms * 1e-3), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
+                       "checked_rows": len(rows),
+                       "roofline": {"bound": "valu", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": fl / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
+                                    "note": "frac = the reference's 3d+3 = 27 flops per pair against the FP32 VECTOR peak (SURVEY.md \u00a78d(i)); 24 of them run on the "
+                                            "matrix pipe here, so it can exceed 1 — the utilisation figure is issue_roofline_frac (v_exp_f32 8 + v_fma_f32 4 + MFMA hold 2 "
+                                            "cycles per 64 pairs per SIMD at 2.4 GHz)",
+                                    "issue_roofline_frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0))}}
+    Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n, dtype=torch.float32, device=dev)
+    if Gf.sym_partial_supported():
+        cg.set_option("time_kernels", 1)
+        ms = _timed(lambda: Gf.sym_partial_(part, a, 3, world), warm=3, reps=10, after_warm=cg.kernel_time)
+        kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
+        kavg = kms / max(kl, 1)
+        ev = float(n) * (n + 32) / 2 / world
+        out["C3_sym_partial"] = {"what": "the same config in the symmetric form: rank 3 of 8's cyclic panels of the upper triangle (covgram_mvm_sym_partial); "
+                                         "an all-reduce of the 8 partials completes b", "ms": ms, "kernel_avg_ms": kavg, "evaluated_pairs_per_s": ev / (ms * 1e-3),
+                                 "roofline": {"bound": "valu", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
+                                              "issue_roofline_frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0))}}
+    del G, Gf, X, a, y, part
+    # C4: GradientKernel(EQ), d=32, n=16384, fp64
+    n, d = 16384, 32
+    rng = np.random.default_rng(0xC0F + 3)
+    Xh = rng.standard_normal((n, d)); ah = rng.standard_normal(n * d)
+    K = cg.gramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(Xh).to(dev)); a = torch.from_numpy(ah).to(dev); y = torch.empty_like(a)
+    cg.set_option("time_kernels", 1)
+    ms = _timed(lambda: K.mul_(y, a), warm=3, reps=10, after_warm=cg.kernel_time)
+    kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
+    kavg = kms / max(kl, 1) if kl else ms
+    rows = np.sort(np.random.default_rng(3).choice(n, 128, replace=False))
+    ref = c_oracle.grad_mvm(o.Kernel(o.EQ), Xh[rows], Xh, ah)
+    fl = float(n) * n * (10 * d + 12)
+    out["C4"] = {"what": "GradientKernel(EQ) mul!, d=32 n=16384 fp64", "ms": ms, "kernel_avg_ms": kavg, "mvm_per_s": 1e3 / ms,
+                 "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy().reshape(n, d)[rows].reshape(-1), ref), "checked_rows": len(rows),
+                 "roofline": {"bound": "valu_fp64", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (kavg * 1e-3) * 1e-12 / 78.6,
+                              "algorithmic_flops": fl}}
+    del K, a, y
+    # C5: Exponential on range(-1, 1, 2^22), fp64: Toeplitz MVM through the circulant embedding N = 2^23
+    n = 1 << 22
+    T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n))
+    ah = np.random.default_rng(0xC0F + 4).standard_normal(n)
+    a = torch.from_numpy(ah).to(dev); y = torch.empty_like(a)
+    ms = _timed(lambda: T.mul_(y, a), warm=5, reps=20)
+    ref = o.toeplitz_mul(None, T.vc.cpu().numpy(), None, ah)
+    by = 112.0 * n
+    out["C5"] = {"what": "Exponential on range(-1,1,2^22): SymmetricToeplitz mul!, fp64, cached spectrum", "ms": ms, "mvm_per_s": 1e3 / ms,
+                 "rel_err_vs_numpy_fft": _rel(y.cpu().numpy(), ref),
+                 "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) * 1e-9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
+                              "algorithmic_bytes": by, "note": "112 n bytes = the ideal single-pass traffic of SURVEY.md §8d; ms is the whole call (all its kernels)"}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C4 / C5 block (N = 1)")
     args = ap.parse_args()
 
     # RCCL prints its version banner and warnings on fd 1; keep the contract's ONE JSON line clean by routing every other
@@ -98,6 +210,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    rng = np.random.default_rng(SEED)                       # identical on every rank: replicated inputs
+    Xh = rng.standard_normal((N_POINTS, DIM)).astype(np.float32)
+    ah = rng.standard_normal(N_POINTS).astype(np.float32)
+
+    # the CPU baseline first: no GPU call has been made yet (torch.cuda is not initialised until set_device below)
+    cpu_line = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            cpu_line = cpu_baseline(Xh, ah)
+        except Exception as e:   # the baseline is reporting only; never fail the GPU measurement for it
+            cpu_line = {"value": None, "unit": "MVM/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
     if world > 1 or os.environ.get("COVGRAM_FORCE_COLLECTIVE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
@@ -109,9 +234,6 @@ def main():
 
     import covgram as cg
 
-    rng = np.random.default_rng(SEED)                       # identical on every rank: replicated inputs
-    Xh = rng.standard_normal((N_POINTS, DIM)).astype(np.float32)
-    ah = rng.standard_normal(N_POINTS).astype(np.float32)
     X = torch.from_numpy(Xh).to(dev)
     a = torch.from_numpy(ah).to(dev)
 
@@ -157,6 +279,24 @@ def main():
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
     else:
         kern_avg_ms = kernel_ms / max(launches, 1)
+
+    # sustained shader clock under THIS kernel: a few launches of its clock-stamping diagnostic build (same loop, s_memtime /
+    # s_memrealtime around the column loop of every workgroup; MI355X_MICROARCH.md DVFS item 6), untimed, right after the run
+    clock_ghz = None
+    if dense_path == 2 and not sym_path:
+        cg.set_option("mfma_stamp", 1)
+        ks = []
+        for _ in range(5):
+            step()
+            ks.append(cg.get_info("last_clock_khz"))
+        cg.set_option("mfma_stamp", 0)
+        ks = [k for k in ks if k > 0]
+        if ks:
+            clock_ghz = float(np.median(ks)) * 1e-6
+    if world > 1:
+        t = torch.tensor([clock_ghz or 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        clock_ghz = float(t[0]) or None
 
     # parity spot check outside the timed region: 1024 random rows against the fp64 oracle (tests/ hold the full suite)
     rel_err = None
@@ -220,50 +360,58 @@ def main():
         kern_s = kern_avg_ms * 1e-3
         achieved_tflops = flops_launch / kern_s * 1e-12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", ("r01_dense_mfma_sym_pmc.json" if sym_path else "r01_dense_mfma_pmc.json") if dense_path == 2
-                           else "r01_dense_pmc.json")
-        if os.path.exists(pmc):
+        pmc = None
+        for rnd in ("r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
+            cand = os.path.join(ROOT, "profiles", f"{rnd}_" + (("dense_mfma_sym_pmc.json" if sym_path else "dense_mfma_pmc.json") if dense_path == 2
+                                                               else "dense_pmc.json"))
+            if os.path.exists(cand):
+                pmc = cand
+                break
+        if pmc:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # which kernel ran (the library picks the matrix-core EQ path when its norm bound holds)
+        # Issue pricing (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost'): per wave-instruction and SIMD v_exp_f32 8 cycles,
+        # v_fma_f32 4, and each v_mfma_f32_32x32x16_bf16 holds the SIMD's vector issue for 8 of its 32 cycles; costs add.
         evaluated_pairs = float(n_local) * m
+        k2 = (d + 1) // 2                                            # MFMAs per 32x32 tile (two coordinates each)
+        mfma_hold = 8.0 * k2 / 16.0                                  # per 64 pairs: k2 MFMAs serve 1024 pairs
         if dense_path == 2 and sym_path:
             # gramian(k, x) on one GPU: tiles on / above the diagonal are evaluated once and feed row AND column sums
             evaluated_pairs = float(n) * (n + 32) / 2 / world       # per rank: cyclic panels of the triangle
             # this algorithm's own work: per evaluated pair the reference's 3d+3 flops + the second weighted sum
             flops_launch = evaluated_pairs * (3 * d + 3 + 2)
             achieved_tflops = flops_launch / kern_s * 1e-12
-            kname = ("covgram::dense_mfma_eq_sym_kernel<K2=2> (upper triangle only: bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+            kname = ("covgram::dense_mfma_sym_kernel<EQ, K2=2> (upper triangle only: bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
                      "2 v_fma_f32 per EVALUATED pair, each evaluated pair serves the entries (i,j) and (j,i); 8 waves share each column "
                      "tile through LDS)")
-            ceiling = 1024 * 2.4e9 * 64 / 12.0     # evaluated pairs/s: 1 v_exp_f32 (8 cyc) + 2 v_fma_f32 (2 cyc each) per 64 pairs per SIMD
+            cycles64 = 8.0 + 2 * 4.0 + mfma_hold
             note = ("FP32 VALU + transcendental issue bound. The Gramian of one point set is symmetric: every 32x32 tile on or above the "
                     "diagonal is evaluated once (distance on the bf16 matrix pipe, three-way split) and used for the row sums and — "
                     "strictly above the diagonal — for the column sums, so one MVM costs n(n+32)/2 exponentials instead of n^2 "
                     "(the reference evaluates all n^2, src/gramian.jl:78-87). 'achieved' counts THIS algorithm's flops: evaluated pairs x "
                     "(3d+3 of SURVEY.md \u00a78d + 2 for the second weighted sum) over the measured kernel time; 'reference_algorithm_tflops' "
-                    "is the reference's n^2 x (3d+3) over the same time (what the caller gets). 'issue_roofline_frac' prices the executed VALU stream: "
-                    "evaluated pairs/s against 1 v_exp_f32 (8 issue cycles) + 2 v_fma_f32 (2 each) per 64 evaluated pairs per SIMD at "
-                    "2.4 GHz (1.31e13/s); SQ counters show the VALU ~100% busy at the ~1.85 GHz the chip sustains "
-                    "(profiles/r01_mfma_eq_counters.txt). 'hbm' does not bound this kernel.")
+                    "is the reference's n^2 x (3d+3) over the same time (what the caller gets). 'hbm' does not bound this kernel.")
         elif dense_path == 2:
             kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=8, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
                      "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)")
-            ceiling = 1024 * 2.4e9 * 64 / 10.0     # 1 v_exp_f32 (8 cyc) + 1 v_fma_f32 (2 cyc) per 64 pairs per SIMD
+            cycles64 = 8.0 + 4.0 + mfma_hold
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
-                    "products), the VALU does 1 v_exp_f32 (8 issue cycles: quarter rate) + 1 v_fma_f32 (2) per 64 pairs per SIMD -> "
-                    "ceiling 1.57e13 pairs/s at the 2.4 GHz peak clock (issue_roofline_frac); rocprof SQ counters show the VALU "
-                    "~100% busy at the ~1.85 GHz the chip sustains under this load (profiles/r01_mfma_eq_counters.txt), i.e. "
-                    "~1.2e13 pairs/s at the sustained clock. 'achieved' uses the reference's algorithmic 3d+3 flops per "
-                    "pair (SURVEY.md \u00a78d), not the instructions executed. 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
+                    "products), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' / 'frac' use the reference's algorithmic "
+                    "3d+3 flops per pair against the FP32 vector peak (SURVEY.md \u00a78d(i)) — most of those flops now run on the matrix "
+                    "pipe, so 'frac' is a throughput ratio, not a utilisation; the utilisation figures are 'issue_roofline_frac' "
+                    "(2.4 GHz peak clock) and 'issue_roofline_frac_at_sustained_clock' (the clock measured in this run with the "
+                    "kernel's stamping build): the VALU issue stream priced with the guide's costs (v_exp_f32 8 + v_fma_f32 4 + MFMA "
+                    "hold 1 cycle per 64 pairs per SIMD). 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
         else:
             kname = "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>"
-            ceiling = 7.15e12
+            cycles64 = 23.2                                           # measured packed body, profiles/r01_microbench_valu_rates.txt
             note = ("FP32 VALU + transcendental issue bound (12 flop + 1 v_exp_f32 per pair, O(n) bytes for O(n^2) work); "
-                    "'mfma'/'hbm' do not bound this kernel (SURVEY.md §8d, DESIGN.md §4). Issue-slot ceiling with the measured "
-                    "costs (7 plain VALU at 2 cyc + 1 v_exp_f32 at 8 cyc per 64 pairs per SIMD, 2.4 GHz) = 7.15e12 pairs/s.")
+                    "'mfma'/'hbm' do not bound this kernel (SURVEY.md §8d, DESIGN.md §4).")
+        ceiling = 1024 * 2.4e9 * 64 / cycles64                        # evaluated pairs/s at the 2.4 GHz peak clock
+        ceiling_sustained = 1024 * clock_ghz * 1e9 * 64 / cycles64 if clock_ghz else None
         line = {
             "metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (+ achieved HBM GB/s in roofline.hbm_*)",
             "value": mvms, "unit": "MVM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,22 +431,28 @@ def main():
                 "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": "recorded rocprofv3 --pmc pass of this kernel (profiles/, FETCH_SIZE doubled per the guide), not measured in this run",
                 "kernel_avg_ms": kern_avg_ms, "launches": int(launches),
                 "algorithmic_flops_per_launch": flops_launch,
                 "note": note,
                 "reference_algorithm_tflops": float(n_local) * m * (3 * d + 3) / kern_s * 1e-12,
                 "issue_roofline_frac": (evaluated_pairs / kern_s) / ceiling,
+                "issue_cycles_per_64_pairs_per_simd": cycles64,
+                "sustained_clock_ghz": clock_ghz,
+                "issue_roofline_frac_at_sustained_clock": (evaluated_pairs / kern_s) / ceiling_sustained if ceiling_sustained else None,
                 "evaluated_pairs_per_launch": evaluated_pairs,
                 "hbm_algorithmic_bytes_per_launch": bytes_launch,
                 "hbm_achieved_GBps": bytes_launch / kern_s * 1e-9,
                 "hbm_frac": bytes_launch / kern_s * 1e-9 / HBM_PEAK_GBPS,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        if world == 1 and not args.no_configs:
             try:
-                line["cpu_baseline"] = cpu_baseline(Xh, ah)
-            except Exception as e:   # the baseline is reporting only; never fail the GPU measurement for it
-                line["cpu_baseline"] = {"value": None, "unit": "MVM/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+                line["configs"] = other_configs(cg, dev)
+            except Exception as e:   # reporting only: the contract line above stands on its own
+                line["configs"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if dist.is_initialized():

@@ -35,6 +35,34 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def _host_staged(group) -> bool:
+    """gloo has no device collectives for every op: with that backend the ONE collective of the MVM is staged through host
+    memory (two processes sharing a GPU in the tests, or a box without RCCL); under "nccl" (= RCCL) tensors go as they are."""
+    try:
+        return dist.get_backend(group) == "gloo"
+    except Exception:
+        return False
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather_into(target: torch.Tensor, shard: torch.Tensor, group) -> None:
+    if shard.is_cuda and _host_staged(group):
+        hs = shard.cpu()
+        ht = torch.empty(target.shape, dtype=target.dtype)
+        dist.all_gather_into_tensor(ht, hs, group=group)
+        target.copy_(ht)
+    else:
+        dist.all_gather_into_tensor(target, shard, group=group)
+
+
 class ShardedGramian:
     """Row shard of gramian(k, x, y) owned by this rank + the all-gather that completes b.
 
@@ -116,7 +144,7 @@ class ShardedGramian:
             else:
                 res = out
             self.sym_partial(res, a, self.rank, self.world)
-            dist.all_reduce(res, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce_sum(res, self.group)
             if out is not None and res is not out:
                 out.copy_(res)
                 return out
@@ -126,7 +154,7 @@ class ShardedGramian:
             self._local_into(shard[:rows], a)
         exact = (self.per * self.world == self.n)
         target = out if (exact and out is not None and out.is_contiguous()) else full
-        dist.all_gather_into_tensor(target, shard, group=self.group)       # the ONLY collective of the MVM
+        _all_gather_into(target, shard, self.group)                        # the ONLY collective of the MVM
         if target is out:
             return out
         b = full[: self.n * self.block]

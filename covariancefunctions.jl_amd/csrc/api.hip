@@ -410,6 +410,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     ctx_blas_destroy(ctx);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
     if (ctx->sym_map) (void)hipFree(ctx->sym_map);
+    if (ctx->stamp_buf) (void)hipFree(ctx->stamp_buf);
     for (auto& t : ctx->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -441,6 +442,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
+    else if (!strcmp(key, "mfma_stamp")) ctx->mfma_stamp = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
@@ -453,6 +455,22 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
+    else if (!strcmp(key, "last_clock_khz")) {
+        // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none
+        *value = 0;
+        if (ctx->stamp_count > 0 && ctx->stamp_buf) {
+            CG_DEVICE(ctx);
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<unsigned long long> h(ctx->stamp_count * 4);
+            CG_CHECK_HIP(hipMemcpy(h.data(), ctx->stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<double> khz;
+            for (size_t w = 0; w < ctx->stamp_count; ++w) {
+                const double dc = (double)(h[4 * w + 2] - h[4 * w]), dr = (double)(h[4 * w + 3] - h[4 * w + 1]);
+                if (h[4 * w + 3] > h[4 * w + 1] && dr >= 100.0) khz.push_back(dc / dr * 1.0e5);   // >= 1 us of work
+            }
+            if (!khz.empty()) { std::nth_element(khz.begin(), khz.begin() + khz.size() / 2, khz.end()); *value = (int64_t)khz[khz.size() / 2]; }
+        }
+    }
     else { set_error("unknown info key '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
 }

@@ -170,6 +170,9 @@ struct covgram_ctx {
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t mfma_sym = -1;       // matrix-core EQ path on gramian(k, x): evaluate the upper triangle once (-1 auto, 0 never, 1 always)
     int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
+    int64_t mfma_stamp = 0;      // 1: the general matrix-core EQ kernel runs its clock-stamping diagnostic build (info key "last_clock_khz")
+    void* stamp_buf = nullptr;   // [workgroup][4]: s_memtime / s_memrealtime before and after the column loop
+    size_t stamp_cap = 0, stamp_count = 0;
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use

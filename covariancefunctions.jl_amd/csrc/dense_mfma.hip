@@ -97,11 +97,15 @@ __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restric
 
 // LDS: 0 = every wave loads its own column tiles; 1 = stages of WPB tiles shared through LDS (K2 <= 4, RT = 2);
 //      2 = ONE tile per stage, its K2 fragment slices fetched by the WPB waves in turn (K2 > 4, RT = 1)
-template <int K2, int RT, int WPB = 1, int LDS = 0>
+// STAMP = 1: the diagnostic build of the SAME loop that reads the shader clock (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) around the column loop of every workgroup — clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md,
+// DVFS give-back item 6).  The stamps go to a buffer of their own; no product launch ever runs this instantiation.
+template <int K2, int RT, int WPB = 1, int LDS = 0, int STAMP = 0>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS == 1 ? (K2 <= 2 ? 4 : 3) : 1, LDS == 1 ? (K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
-                                                           float alpha, float beta, int32_t final_store, const float* __restrict__ Cn) {
+                                                           float alpha, float beta, int32_t final_store, const float* __restrict__ Cn,
+                                                           unsigned long long* __restrict__ stamps) {
     // WPB waves per workgroup take consecutive row tiles and walk the SAME column tiles at the same pace (no barrier,
     // nothing shared explicitly): their fragment loads coalesce in the CU's vector L1 instead of each going to L2
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         er[r] = eq_row_fragments<K2>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
     }
 
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if constexpr (STAMP) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int64_t T0 = (int64_t)blockIdx.y * tchunk;
     const int64_t T1 = (T0 + tchunk < ntile) ? (T0 + tchunk) : ntile;
     float acc[RT][16];
@@ -261,6 +267,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     }
     }
 
+    if constexpr (STAMP) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* o = stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = st_c0; o[1] = st_r0; o[2] = c1; o[3] = r1;
+        }
+    }
     // lane (t, h) owns output row t of each row tile iff bit 2 of t equals h; its register is v = (t & 3) + 4 (t >> 3)
     const int vsel = (t & 3) + 4 * (t >> 3);
 #pragma unroll
@@ -460,16 +473,25 @@ static int mfma_blocks(int rt) {
 
 template <int K2>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
-                        int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn) {
+                        int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn,
+                        unsigned long long* stamps, dim3* launched) {
     constexpr bool NARROW = K2 <= MFMA_NARROW_MAXK2;
-    if (lds4 && K2 <= 2 && grid.x >= 1024)   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), dim3((grid.x + 7) / 8, grid.y), dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
-    else if (lds4)   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), dim3((grid.x + 3) / 4, grid.y), dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
-    else if (rt == 2 && K2 <= 8)
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
-    else
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn);
+    unsigned long long* const ns = nullptr;
+    if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
+        *launched = dim3((grid.x + 7) / 8, grid.y);
+        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+    } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
+        *launched = dim3((grid.x + 3) / 4, grid.y);
+        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+    } else if (rt == 2 && K2 <= 8) {
+        *launched = grid;
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+    } else {
+        *launched = grid;
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+    }
 }
 
 // the column fragments and norm fraction factors of point set Y for (g, K2): packed once into the handle and reused by every
@@ -540,16 +562,31 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // prologue and barriers (tools/mfma_lds_ab.py)
     const bool lds4 = ((rt == 2 && K2 <= MFMA_NARROW_MAXK2) || (rt == 1 && K2 > MFMA_NARROW_MAXK2)) &&
                       (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
+    // option "mfma_stamp": the clock-stamping diagnostic build of the two LDS-shared instances (C2's and C3's kernels)
+    unsigned long long* stamps = nullptr;
+    ctx->stamp_count = 0;
+    if (ctx->mfma_stamp && lds4 && (K2 == 2 || K2 == 4)) {
+        const size_t need = (size_t)rowtiles * js * 4 * sizeof(unsigned long long);
+        if (need > ctx->stamp_cap) {
+            if (ctx->stamp_buf) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->stamp_buf); ctx->stamp_buf = nullptr; ctx->stamp_cap = 0; }
+            CG_CHECK_HIP(hipMalloc(&ctx->stamp_buf, need));
+            ctx->stamp_cap = need;
+        }
+        CG_CHECK_HIP(hipMemsetAsync(ctx->stamp_buf, 0, need, ctx->stream));
+        stamps = (unsigned long long*)ctx->stamp_buf;
+    }
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
     ctx->last_mfma_lds = lds4 ? 1 : 0;
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn); break;
+    dim3 launched;
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
     }
 #undef CG_MFMA_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+    if (stamps) ctx->stamp_count = (size_t)launched.x * launched.y;
     if (js > 1)
         hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
                            (int)js, y, n, n, 1, (float)alpha_eff, (float)beta);

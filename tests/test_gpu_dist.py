@@ -1,0 +1,122 @@
+"""Two REAL processes on the device path: world_size 2 over gloo, both ranks on GPU 0, the DEFAULT local
+factory (the HIP kernels through the C ABI), device tensors staged through host memory for the one collective (covgram.dist) —
+row shards + all-gather and symmetric partials + all-reduce, against the fp64 oracle.  Plus bench.py's RCCL path at world = 1
+(COVGRAM_FORCE_COLLECTIVE=1): init_process_group("nccl"), the all-gather / all-reduce really issued on one rank.
+The 8-GPU run itself is the driver's; this proves the multi-process logic with real kernels, not a CPU stand-in."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import covgram as cg
+    import covgram_oracle as o
+    dev = torch.device("cuda", 0)                       # both ranks share the one GPU of the box
+    res = {}
+    try:
+        rng = np.random.default_rng(2024)               # same seed on every rank: replicated inputs
+        # (1) fp32 EQ, d = 3: row shards + all-gather (general matrix-core kernel), ragged n (shards of 15001 / 15000 rows)
+        n, d = 30001, 3
+        Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+        X = torch.from_numpy(Xh).to(dev); a = torch.from_numpy(ah).to(dev)
+        rows = np.random.default_rng(1).choice(n, 256, replace=False)
+        ref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32)
+        G = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+        b = G @ a
+        res["gather"] = (G.lo, G.hi, float(np.linalg.norm(b.cpu().numpy()[rows] - ref) / np.linalg.norm(ref)), cg.get_info("last_dense_path"))
+        # (2) the symmetric form: cyclic panels of the upper triangle per rank + ONE all-reduce
+        Gs = cg.ShardedGramian(cg.EQ(), X, symmetric=True)
+        assert Gs.sym_partial is not None
+        bs = Gs @ a
+        res["reduce"] = (float(np.linalg.norm(bs.cpu().numpy()[rows] - ref) / np.linalg.norm(ref)), cg.get_info("last_mfma_sym"))
+        # (3) fp64 MaternP(2), two point sets, matrix right-hand side (direct-difference kernel), and the gradient blocks
+        m, p = 2111, 3
+        Yh = rng.standard_normal((m, d)); Ah = rng.standard_normal((m, p)); X64 = rng.standard_normal((3001, d))
+        Gm = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X64).to(dev), torch.from_numpy(Yh).to(dev))
+        B = Gm @ torch.from_numpy(Ah).to(dev)
+        refm = o.mul(None, o.Kernel(o.MATERNP, p=2), X64, Yh, Ah)
+        res["matrix"] = float(np.linalg.norm(B.cpu().numpy() - refm) / np.linalg.norm(refm))
+        Xg = rng.standard_normal((333, 5)); ag = rng.standard_normal(333 * 5)
+        Gg = cg.ShardedGramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(Xg).to(dev))
+        bg = Gg @ torch.from_numpy(ag).to(dev)
+        refg = o.grad_mul(None, o.Kernel(o.EQ), Xg, Xg, ag)
+        res["grad"] = float(np.linalg.norm(bg.cpu().numpy() - refg) / np.linalg.norm(refg))
+        # (4) CG on the sharded operator: every rank must reach the same solution
+        S = cg.ShardedGramian(cg.MaternP(1), torch.from_numpy(X64[:800]).to(dev))
+        Aop = cg.LazyMatrixSum(S, 0.5 * torch.ones(800, dtype=torch.float64, device=dev))
+        xs, info = cg.cg(Aop, torch.from_numpy(Ah[:800, 0].copy()).to(dev), reltol=1e-10, maxiter=400)
+        Mh = o.matrix(o.Kernel(o.MATERNP, p=1), X64[:800]) + 0.5 * np.eye(800)
+        res["cg"] = xs.cpu().numpy()
+        res["cg_err"] = float(np.linalg.norm(res["cg"] - np.linalg.solve(Mh, Ah[:800, 0])) / np.linalg.norm(res["cg"]))
+        res["cg_converged"] = bool(info["converged"])
+        res["ok"] = True
+    except Exception as e:      # report instead of hanging the other rank in a collective
+        import traceback
+        res["ok"] = False; res["error"] = traceback.format_exc()
+    q.put((rank, res))
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def test_two_processes_share_a_gpu_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")                       # fresh children: a process that touched the GPU is never re-exec'ed
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(2):
+        rank, res = q.get(timeout=600)
+        out[rank] = res
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert out[r]["ok"], out[r].get("error")
+    assert (out[0]["gather"][0], out[0]["gather"][1]) == (0, 15001) and (out[1]["gather"][0], out[1]["gather"][1]) == (15001, 30001)
+    for r in (0, 1):
+        assert out[r]["gather"][2] <= 1e-5 and out[r]["gather"][3] == 2, out[r]["gather"]       # the matrix-core kernel ran in each rank
+        assert out[r]["reduce"][0] <= 1e-5 and out[r]["reduce"][1] == 1, out[r]["reduce"]         # the symmetric kernel ran in each rank
+        assert out[r]["matrix"] <= 1e-12 and out[r]["grad"] <= 1e-12, (out[r]["matrix"], out[r]["grad"])
+    assert out[0]["cg_converged"] and out[0]["cg_err"] <= 1e-8, out[0]["cg_err"]
+    assert np.array_equal(out[0]["cg"], out[1]["cg"])                                             # replicated vectors stay bit-identical
+
+
+def test_bench_runs_its_rccl_collectives_at_world_one():
+    """bench.py with COVGRAM_FORCE_COLLECTIVE=1: backend "nccl" (= RCCL), world = 1, the all-gather of the contract run and the
+    all-reduce of the symmetric variant are issued for real; the line must parse and both results must match the oracle."""
+    env = dict(os.environ, COVGRAM_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["unit"] == "MVM/s" and line["value"] > 50
+    assert line["rel_err_vs_fp64_oracle"] <= 1e-5
+    assert line["symmetric_variant"]["rel_err_vs_fp64_oracle"] <= 1e-5
+    assert "row-shard" in line["config"]["parallelism"] or "1 GPU" in line["config"]["parallelism"]
