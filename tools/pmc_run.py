@@ -1,4 +1,5 @@
-"""Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).  usage: pmc_run.py dense|grad|toeplitz [K]"""
+"""Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).
+usage: pmc_run.py dense|densegen|shard8|grad|toeplitz [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -9,6 +10,17 @@ if which == "dense":
     n = 131072
     X = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
     G = cg.gramian(cg.EQ(), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(K): G.mul_(y, a)
+elif which == "densegen":
+    n = 131072
+    X = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    cg.set_option("mfma_sym", 0)
+    G = cg.gramian(cg.EQ(), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(K): G.mul_(y, a)
+elif which == "shard8":
+    n, per = 524288, 65536
+    X = torch.from_numpy(np.random.default_rng(0xC0F + 2).standard_normal((n, 8)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    G = cg.gramian(cg.EQ(), X[:per], X); y = torch.empty(per, dtype=torch.float32, device="cuda")
     for _ in range(K): G.mul_(y, a)
 elif which == "grad":
     n, d = 16384, 32
