@@ -23,7 +23,7 @@ from .gramian import (Gramian, BlockGramian, SymmetricToeplitz, Toeplitz, Circul
                       SeparableGramian, LazyMatrixProduct, LazyMatrixSum, ScaledOperator, LinearMapBlockGramian, CosineBlockGramian, PointJacobianBlockGramian, Fill, LazyOperator, LazyGrid, StepRangeLen,
                       srange, gramian, mul_, get_ctx, set_option, get_info, kernel_time)
 from .dist import ShardedGramian, shard_bounds
-from .solve import cg, solve, toeplitz_solve
+from .solve import cg, solve, toeplitz_solve, durbin, levinson, trench
 from .factorize import cholesky, factorize, diagonal, CholeskyFactor, PivotedCholesky
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -134,3 +134,63 @@ def toeplitz_solve(T, b: torch.Tensor, reltol: float = 1e-12, maxiter: Optional[
     def precond(r):
         return torch.fft.irfft(torch.fft.rfft(r) * inv, n)
     return cg(T, b, reltol=reltol, maxiter=maxiter if maxiter is not None else 10 * n, precond=precond)
+
+
+# ---- the reference's direct Toeplitz solvers on the device (src/toeplitz.jl:12-111; csrc/toeplitz_direct.hip) ---------------
+def _unit_diagonal(r_or_T, dtype=None):
+    """(r, r0): r = first column without its leading entry, scaled to a unit diagonal; a SymmetricToeplitz operator T gives
+    r = T.vc[1:] / T.vc[0] and r0 = T.vc[0] (src/toeplitz.jl:40-46,100-111 — the reference tests `r_0 == 1` where it means
+    `r_0 != 1`; the normalisation is done right here, as in the oracle)."""
+    from .gramian import get_ctx
+    if hasattr(r_or_T, "vc"):
+        if getattr(r_or_T, "vr", None) is not None:
+            raise NotImplementedError("direct Toeplitz solvers: symmetric Toeplitz expected")
+        vc = r_or_T.vc
+        return (vc[1:] / vc[0]).contiguous(), float(vc[0])
+    r = torch.as_tensor(r_or_T)
+    if not r.is_cuda:
+        r = r.to(get_ctx().device)
+    if dtype is not None:
+        r = r.to(dtype)
+    return r.contiguous(), 1.0
+
+
+def durbin(r: torch.Tensor) -> torch.Tensor:
+    """durbin(r): y = K \\ (-r), K = SymmetricToeplitz([1, r[1:end-1]]) (src/toeplitz.jl:12-27)."""
+    from . import _ffi
+    from .gramian import get_ctx, _dtype_code
+    r, _ = _unit_diagonal(r)
+    y = torch.empty_like(r)
+    ctx = get_ctx(r.device).bind_stream()
+    _ffi.check(_ffi.lib().covgram_toeplitz_durbin(ctx, _ffi._P(r.data_ptr()), r.shape[0], _ffi._P(y.data_ptr()), _dtype_code(r.dtype), _ffi.DEVICE))
+    return y
+
+
+def levinson(r_or_T, b: torch.Tensor) -> torch.Tensor:
+    """levinson(r, b) = SymmetricToeplitz([1; r]) \\ b, or levinson(T, b) = T \\ b (src/toeplitz.jl:75-111): the O(n²) chain of
+    n - 1 dependent steps on one workgroup.  For large n `toeplitz_solve` (PCG over the FFT MVM) is the faster path."""
+    from . import _ffi
+    from .gramian import get_ctx, _dtype_code
+    r, r0 = _unit_diagonal(r_or_T, b.dtype if torch.is_tensor(b) else None)
+    b = torch.as_tensor(b).to(device=r.device, dtype=r.dtype).contiguous()
+    n = b.shape[0]
+    if r.shape[0] != n - 1:
+        raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: length(b) = {n} ≠ {r.shape[0] + 1} = length(r) + 1")
+    x = torch.empty_like(b)
+    ctx = get_ctx(r.device).bind_stream()
+    _ffi.check(_ffi.lib().covgram_toeplitz_levinson(ctx, _ffi._P(r.data_ptr()), _ffi._P(b.data_ptr()), n, _ffi._P(x.data_ptr()), _dtype_code(r.dtype), _ffi.DEVICE))
+    return x / r0 if r0 != 1.0 else x
+
+
+def trench(r_or_T) -> torch.Tensor:
+    """trench(r) = inv(SymmetricToeplitz([1; r])), or trench(T) = inv(T) (src/toeplitz.jl:29-71), as a full symmetric matrix."""
+    from . import _ffi
+    from .gramian import get_ctx, _dtype_code
+    r, r0 = _unit_diagonal(r_or_T)
+    n = r.shape[0] + 1
+    Bt = torch.empty((n, n), dtype=r.dtype, device=r.device)       # column-major n x n == the transpose of a C-contiguous tensor
+    ctx = get_ctx(r.device).bind_stream()
+    _ffi.check(_ffi.lib().covgram_toeplitz_trench(ctx, _ffi._P(r.data_ptr()) if n > 1 else _ffi._P(Bt.data_ptr()), n, _ffi._P(Bt.data_ptr()), n,
+                                                  _dtype_code(r.dtype), _ffi.DEVICE))
+    B = Bt.t()
+    return B / r0 if r0 != 1.0 else B

@@ -308,6 +308,29 @@ function gramian(k::CovarianceFunctions.StationaryKernel, x::StepRangeLen{T}, p:
     DeviceToeplitz(T.(k.(x[1], x)); circulant = true)
 end
 
+# --- direct Toeplitz solvers (src/toeplitz.jl:12-111): the O(n²) chains on one workgroup of the device --------------------
+# unit-diagonal forms, as the reference's vector methods; `levinson(T, b)` / `trench(T)` normalise by T.vc[1] (the reference's
+# `r_0 == 1` test is inverted, src/toeplitz.jl:40-42,103-105; done right here)
+function device_durbin(r::Vector{T}) where {T <: DevFloat}
+    y = similar(r)
+    check(ccall((:covgram_toeplitz_durbin, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int32),
+                ctx(), r, length(r), y, dtype_code(T), HOST)); y
+end
+function device_levinson(r::Vector{T}, b::Vector{T}) where {T <: DevFloat}
+    length(b) == length(r) + 1 || throw(DimensionMismatch("length(b) = $(length(b)) ≠ $(length(r) + 1) = length(r) + 1"))
+    x = similar(b)
+    check(ccall((:covgram_toeplitz_levinson, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int32),
+                ctx(), r, b, length(b), x, dtype_code(T), HOST)); x
+end
+function device_trench(r::Vector{T}) where {T <: DevFloat}
+    n = length(r) + 1; B = Matrix{T}(undef, n, n)
+    check(ccall((:covgram_toeplitz_trench, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Int32),
+                ctx(), r, n, B, n, dtype_code(T), HOST)); Symmetric(B)
+end
+device_levinson(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = device_levinson(A.vc[2:end] ./ A.vc[1], b) ./ A.vc[1]
+device_trench(A::DeviceToeplitz) = Symmetric(parent(device_trench(A.vc[2:end] ./ A.vc[1])) ./ A.vc[1])
+LinearAlgebra.:\(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = issymmetric(A) ? device_levinson(A, b) : error("only symmetric Toeplitz solves are served")
+
 # --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, one strided-batched GEMM per mode ----------
 struct DeviceKronecker{T} <: AbstractMatrix{T}
     factors::Vector{Matrix{T}}          # F_1 ⊗ F_2 ⊗ … ⊗ F_q in the reference's order (kronecker(G_1, …, G_q))

@@ -16,6 +16,7 @@
  *   covgram_valgrad_mvm    the same  blockmul! with the ValueGradientKernel element                       src/gradient.jl:319-351, 400-474
  *   covgram_toeplitz_*     replaces  mul!(y, ::SymmetricToeplitz/Toeplitz/Circulant, a, α, β) of ToeplitzMatrices 0.7.1 as
  *                          constructed by gramian(k, x::StepRangeLen, y::StepRangeLen)            src/gramian.jl:167-189
+ *   covgram_toeplitz_durbin / _levinson / _trench  replace durbin! / levinson! / trench!             src/toeplitz.jl:12-111
  *   covgram_kron_mvm       replaces  mul!(y, ::KroneckerProduct, a) of KroneckerProducts 1.1.1 as constructed at
  *                                                                                                 src/algebra.jl:91-95, src/separable.jl:33-42
  *   covgram_lowrank_mvm    replaces  mul!(y, L::LazyMatrixProduct(U, V'), a, α, β)                src/lazy_linear_algebra.jl:78-85
@@ -202,6 +203,17 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
                             int64_t m, int32_t dtype, int32_t loc, int32_t circulant);
 int covgram_toeplitz_mvm(covgram_toeplitz* T, const void* a, void* y, double alpha, double beta, int32_t loc);
 int covgram_toeplitz_destroy(covgram_toeplitz* T);
+
+/* Direct solvers of src/toeplitz.jl for the symmetric positive definite Toeplitz matrix K = SymmetricToeplitz([1; r])
+ * (UNIT diagonal; r = the first column without its leading 1 — callers with T.vc[0] = r_0 != 1 pass vc[1:] / r_0 and scale the
+ * result by 1 / r_0, src/toeplitz.jl:100-111 with its inverted `r_0 == 1` test put right):
+ *   covgram_toeplitz_durbin    replaces durbin!(y, r)        src/toeplitz.jl:12-27    y = K_n \ (-r), K_n = SymmetricToeplitz([1, r[1:n-1]]), n = length(r)
+ *   covgram_toeplitz_levinson  replaces levinson!(x, r, b)   src/toeplitz.jl:75-98    x = K \ b, n = length(b) = length(r) + 1
+ *   covgram_toeplitz_trench    replaces trench!(B, r)        src/toeplitz.jl:52-71    B = inv(K), n x n column-major (ldb), BOTH triangles filled
+ * Durbin / Levinson are chains of n - 1 dependent steps: one workgroup walks them (O(n^2 / 1024) thread steps). */
+int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y, int32_t dtype, int32_t loc);
+int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, int64_t n, void* x, int32_t dtype, int32_t loc);
+int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B, int64_t ldb, int32_t dtype, int32_t loc);
 
 /* y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) a + beta * y, standard Kronecker order (F_1 = slowest index).
  * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc). */

@@ -1141,6 +1141,47 @@ def test_toeplitz_solve_pcg_vs_levinson(cg, oracle, n):
     assert info["converged"] and relerr(x.cpu().numpy(), oracle.levinson_toeplitz(vc, b)) <= 1e-8, info
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 32, 257, 2049])
+def test_toeplitz_direct_solvers_durbin_levinson_trench(cg, oracle, n):
+    """src/toeplitz.jl:12-111 on the device (csrc/toeplitz_direct.hip) against the oracle's restatement and against dense
+    algebra, as test/toeplitz.jl:7-42 does: durbin(r) = inv(K) (-r), levinson(r, b) = inv(K) b, trench(r) = inv(K); EQ / Exponential
+    Gramians on a grid (positive definite), unit and non-unit diagonals, fp64 and fp32."""
+    rng = np.random.default_rng(800 + n)
+    xs = np.linspace(-1.0, 1.0, n + 1)
+    for fam, tolf in ((lambda t: np.exp(-np.abs(t)), 1.0), (lambda t: np.exp(-0.5 * (3.0 * t) ** 2) + 1e-3 * (t == 0), 100.0)):
+        vc = fam(xs - xs[0])                                         # first column of the (n+1) x (n+1) Toeplitz Gramian, vc[0] = 1 (+ jitter)
+        r = vc[1:] / vc[0]
+        K = oracle.toeplitz_dense(vc / vc[0]) if hasattr(oracle, "toeplitz_dense") else np.array([[vc[abs(i - j)] / vc[0] for j in range(n + 1)] for i in range(n + 1)])
+        b = rng.standard_normal(n + 1)
+        rd = torch.from_numpy(r).cuda()
+        # Durbin: K_n \ (-r) with K_n the leading n x n block
+        y = cg.durbin(rd).cpu().numpy()
+        assert relerr(y, oracle.durbin(r)) <= 1e-9 * tolf, ("durbin", n, relerr(y, oracle.durbin(r)))
+        assert relerr(K[:n, :n] @ y, -r) <= 1e-9 * tolf
+        # Levinson, vector form and operator form (non-unit diagonal: T = 2.5 K)
+        x = cg.levinson(rd, torch.from_numpy(b).cuda()).cpu().numpy()
+        assert relerr(x, oracle.levinson(r, b)) <= 1e-9 * tolf, ("levinson", n, relerr(x, oracle.levinson(r, b)))
+        assert relerr(K @ x, b) <= 1e-8 * tolf
+        T = cg.SymmetricToeplitz(torch.from_numpy(2.5 * vc).cuda())
+        xT = cg.levinson(T, torch.from_numpy(b).cuda()).cpu().numpy()
+        assert relerr(xT, oracle.levinson_toeplitz(2.5 * vc, b)) <= 1e-9 * tolf
+        # Trench: the full symmetric inverse
+        if n <= 257:
+            Bi = cg.trench(rd).cpu().numpy()
+            assert relerr(Bi, oracle.trench(r)) <= 1e-9 * tolf, ("trench", n, relerr(Bi, oracle.trench(r)))
+            assert np.array_equal(Bi, Bi.T)
+            assert relerr(Bi @ K, np.eye(n + 1)) <= 1e-7 * tolf
+            BT = cg.trench(T).cpu().numpy()
+            assert relerr(BT @ (2.5 * vc[0] * K), np.eye(n + 1)) <= 1e-7 * tolf
+    # fp32: the same chains in single precision (Exponential: well conditioned)
+    vc32 = np.exp(-np.abs(xs - xs[0])).astype(np.float32)
+    x32 = cg.levinson(torch.from_numpy(vc32[1:]).cuda(), torch.from_numpy(b.astype(np.float32)).cuda()).cpu().numpy()
+    # (the grid Gramian's condition number grows like n^2: single precision keeps ~ 7 - 2 log10(n) digits)
+    assert relerr(x32, oracle.levinson(vc32[1:].astype(np.float64), b.astype(np.float32))) <= max(1e-5, 1e-6 * (n + 1) ** 2)
+    with pytest.raises(cg._ffi.DimensionMismatch):
+        cg.levinson(rd, torch.zeros(n + 3, dtype=torch.float64, device="cuda"))
+
+
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 65536), (torch.float64, 250000), (torch.float64, 1000000), (torch.float64, 3000001),
                                      (torch.float32, 250000), (torch.float32, 4000000)])
 def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
