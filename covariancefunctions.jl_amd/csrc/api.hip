@@ -439,6 +439,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
+    else if (!strcmp(key, "grad_expand")) ctx->grad_expand = value;
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
@@ -454,6 +455,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
+    else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
         // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none
@@ -994,8 +996,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     } else {
         void* P;
         // + 1 prefetch-only record; the value weights A0[0..m] of the value-gradient variant follow the stream
-        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * (2 * D + vg) * ts, &P); if (rc) return rc;
+        // expanded form (grad_mvm.hpp): fp64 isotropic simple profiles whose pre-scaled clouds lie within the radius gate
+        const bool expd = iso && dtype == COVGRAM_F64 && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 &&
+                          (ctx->grad_expand == 1 || (ctx->grad_expand < 0 && hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
+        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * (2 * D + vg + (expd ? 2 : 0)) * ts, &P); if (rc) return rc;
         void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * 2 * D * ts) : nullptr;
+        void* Ex = expd ? (void*)((char*)P + (size_t)(m + 1) * (2 * D + vg) * ts) : nullptr;
         const int64_t pe = (m + 1) * (int64_t)D;
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1003,6 +1009,9 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn);
+        if (expd)
+            hipLaunchKernelGGL(grad_pack_extra_kernel<double>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, d,
+                               (const double*)a_dev, hk.kp.gamma, vg, (const double*)Cn, (double*)Ex);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
@@ -1012,6 +1021,8 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         ga.vg = vg; ga.A0 = A0; ga.alpha0 = alpha0;
+        ga.expd = expd ? 1 : 0; ga.Ex = Ex;
+        ctx->last_grad_expand = ga.expd;
         ga.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma;
         ga.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
         if (jsplit == 1) ga.out = y_dev;

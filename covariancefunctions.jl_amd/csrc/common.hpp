@@ -165,6 +165,7 @@ struct covgram_ctx {
     int64_t rows_per_lane = 0;   // 0 = auto
     int64_t jsplit = 0;          // 0 = auto
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
+    int64_t grad_expand = -1;    // fp64 isotropic gradient Gramians in the expanded form (4 fma per dimension and pair): -1 inside the radius gate, 0 never, 1 always
     int64_t grad_keep_r = -1;    // -1 auto
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
@@ -182,6 +183,7 @@ struct covgram_ctx {
     size_t sym_map_cap = 0, sym_map_len = 0;
     int64_t sym_key[4] = {-1, -1, -1, -1};
     int64_t last_mfma_sym = 0;   // the last dense MVM ran the symmetric (upper-triangle) matrix-core kernel
+    int64_t last_grad_expand = 0; // the last lane-per-row gradient MVM ran the expanded form
     int64_t last_mfma_lds = 0;   // the last matrix-core EQ MVM shared its column tiles through LDS
     // optional HIP-event bracketing of the dominant kernel of each MVM (bench.py's live roofline measurement)
     int64_t time_kernels = 0;
@@ -250,6 +252,8 @@ struct GradArgs {
     int32_t vg = 0;                        // 1: ValueGradientKernel blocks of d+1 (out slab rows D+1)
     const void* A0 = nullptr;              // vg: value weights of the columns, m+1 entries
     double alpha0 = 0, vg_c = 0, vg_b = 0; // vg: scale of the value row, c2 and b0 coupling coefficients
+    int32_t expd = 0;                      // 1: expanded form (fp64 isotropic): Ex holds (|y'_j|^2, y'_j . a_j) per column, m + 1 entries
+    const void* Ex = nullptr;
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;
@@ -266,6 +270,7 @@ grad_launch_fn grad_launcher(int family);
 constexpr int MFMA_LDS_MIN_TILES = 64;
 constexpr int64_t MFMA_SYM_MIN_N = 24000;   // below: the general kernel is as fast (tools/mfma_sym_ab.py: 16384 loses, 24000 wins 7-16 %)
 constexpr double MFMA_GATE = 126.0;
+constexpr double GRAD_EXPAND_GATE = 1000.0;   // gamma^2 R^2 up to which the fp64 gradient kernel expands |x - y|^2 (abs. error ~1e-16 R^2; grad_mvm.hpp)
 double gate_radius2(const covgram_points* X, const covgram_points* Y);
 int points_max_norm2(covgram_points* p);
 bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);

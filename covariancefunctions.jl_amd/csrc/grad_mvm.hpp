@@ -13,6 +13,15 @@
 // so the host folds -2 gamma^2 * scale into alpha.  Grid = (row blocks) × (J splits) with a
 // deterministic second-pass reduction, as in dense_mvm.hpp.
 //
+// Expanded form (EXPD; fp64 isotropic Gramians inside a radius gate).  The reference's block needs r = x_i - y_j twice: 6 fp64
+// VALU instructions per dimension and pair (sub + 2 fma in each sweep).  With the norms |x'_i|^2, |y'_j|^2 and the column scalar
+// y'_j . a_j known (one pass per point set / per MVM), the same block is
+//     s = |x'|^2 + |y'|^2 - 2 x'.y',   t = x'.a_j - y'_j.a_j,   b_i += k1 a_j - c2 y'_j   (+ x'_i * sum_j c2_j once per row):
+// 4 fma per dimension and pair, a third fewer instructions on a kernel that is fp64-VALU bound.  s and c2 (x' - y') are then
+// differences of O(|x'|^2) terms instead of direct differences (src/util.jl:40-47): the absolute error is ~1e-16 R^2 (R = the
+// radius of the pre-scaled cloud about the common centre), so the form is used while R^2 <= GRAD_EXPAND_GATE = 1000 — C4:
+// R^2 ~ 90, measured rel-err 3e-15 — and never in fp32.  Option "grad_expand": -1 this rule, 0 never, 1 always (tests).
+//
 // Software pipeline of the scalar stream.  The state (x_i, b_i [, r]) costs 2-3 d-vectors of VGPRs, so wide fp64 rows
 // run at 2 waves per SIMD and cannot hide scalar-load latency by occupancy: rocprofv3 showed 61 % of the wave cycles of
 // the first version parked in s_waitcnt (profiles/r01_pmc_counters_v1.txt).  SMEM returns out of order, so only
@@ -50,17 +59,19 @@ constexpr int grad_min_waves() {
 //   dot product:  bv =    gamma^2 (phi' av + (  phi'' t + phi' a0 / gamma) y'),   b0 = phi a0 +   gamma phi' t
 // i.e. one extra FMA on c2 and one scalar accumulator; a0 streams from A0 (one scalar load per column, prefetched with
 // the column's first chunk), vg_c = -+1/gamma, vg_b = -2 gamma | gamma, and b0 is scaled by alpha0 = alpha * scale.
-template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG>
+template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG, bool EXPD = false>
 __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
                                                                 const T* __restrict__ P, const T* __restrict__ P2,
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
                                                                 int64_t jchunk, T alpha, T beta, int32_t final_store,
                                                                 const T* __restrict__ A0, T alpha0, T vg_c, T vg_b,
-                                                                const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp) {
+                                                                const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp,
+                                                                const T* __restrict__ Ex) {
     constexpr bool ISO = fam_is_iso<FAM>;
+    static_assert(!EXPD || (ISO && !KEEP_R), "the expanded form is an isotropic variant that keeps no r");
     constexpr int DC = (64 / (int)sizeof(T) < D) ? 64 / (int)sizeof(T) : D;   // dims per chunk (one 64-byte s_load per operand)
     constexpr int NC = (D + DC - 1) / DC;
-    constexpr bool NEED_Y2 = !ISO || !KEEP_R;                                    // sweep 2 needs y_j again
+    constexpr bool NEED_Y2 = !ISO || !KEEP_R;                                    // sweep 2 needs y_j again (EXPD: -c2 y_j)
     using Chunk = GradChunk<T, DC>;
 
     const int tid = threadIdx.x;
@@ -82,6 +93,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
         }
 #pragma unroll
         for (int l = 0; l < D; ++l) b[l] = (T)0;
+    }
+    [[maybe_unused]] T nx = (T)0, csum = (T)0;                    // EXPD: |x'_i|^2 and sum_j c2_j (b_i += x'_i csum at the end)
+    if constexpr (EXPD) {
+#pragma unroll
+        for (int l = 0; l < D; ++l) nx = cg_fma(x[l], x[l], nx);
     }
 
     // chunk loaders: uniform addresses -> s_load_dwordx16.  The tail chunk of a D that is not a multiple of DC is
@@ -114,6 +130,10 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
     const T* __restrict__ a0p = VG ? A0 + j0 : nullptr;
     T a0 = (T)0, a0n = (T)0, b0 = (T)0;
     if constexpr (VG) a0 = a0p[0];
+    // EXPD: the column scalars (|y'_j|^2, y'_j . a_j) stream beside the records, prefetched one column ahead like a0
+    const T* __restrict__ exq = EXPD ? Ex + 2 * j0 : nullptr;
+    [[maybe_unused]] T eny = (T)0, eya = (T)0, enyn = (T)0, eyan = (T)0;
+    if constexpr (EXPD) { eny = exq[0]; eya = exq[1]; }
     for (int jj = 0; jj < cnt; ++jj, p += 2 * D, q += 2 * D) {
         T s = (T)0, t = (T)0;
         T r[(ISO && KEEP_R) ? D : 1];
@@ -127,7 +147,10 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             for (int e = 0; e < DC; ++e) {
                 if (e < skip) continue;
                 const int l = base + e;
-                if constexpr (ISO) {
+                if constexpr (EXPD) {
+                    s = cg_fma(x[l], cur.y[e], s);
+                    t = cg_fma(x[l], cur.a[e], t);
+                } else if constexpr (ISO) {
                     const T rl = x[l] - cur.y[e];
                     if constexpr (KEEP_R) r[l] = rl;
                     s = cg_fma(rl, rl, s);
@@ -146,6 +169,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
+        if constexpr (EXPD) {                                     // x'.y' -> |x' - y'|^2 (never negative), x'.a -> r'.a
+            s = cg_fma((T)-2, s, nx + eny);
+            s = s > (T)0 ? s : (T)0;
+            t -= eya;
+        }
         T k1, k2, c2;
         if constexpr (VG) {
             T v;
@@ -156,6 +184,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             phi_derivs<FAM, T, POW>(s, kp, k1, k2);
             c2 = ISO ? (T)2 * k2 * t : k2 * t;
         }
+        if constexpr (EXPD) { csum += c2; c2 = -c2; }            // b += k1 a - c2 y' here, + c2 x' through csum
         // ---- sweep 2: b += k1 a + c2 r   (or k1 a + c2 y) --------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -167,7 +196,9 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
                 if (e < skip) continue;
                 const int l = base + e;
                 T v;
-                if constexpr (ISO) {
+                if constexpr (EXPD) {
+                    v = cur.y[e];
+                } else if constexpr (ISO) {
                     if constexpr (KEEP_R) v = r[l];
                     else v = x[l] - cur.y[e];
                 } else {
@@ -178,6 +209,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
                     __builtin_amdgcn_sched_barrier(0);
                     nxt = (c + 1 < NC) ? load_a(q, c + 1) : load_ya(p + 2 * D, 0);   // last chunk: next column (stream is padded)
                     if constexpr (VG) { if (c + 1 == NC) a0n = a0p[jj + 1]; }
+                    if constexpr (EXPD) { if (c + 1 == NC) { enyn = exq[2 * (jj + 1)]; eyan = exq[2 * (jj + 1) + 1]; } }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -185,6 +217,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             cur = nxt;
         }
         if constexpr (VG) a0 = a0n;
+        if constexpr (EXPD) { eny = enyn; eya = eyan; }
+    }
+    if constexpr (EXPD) {
+#pragma unroll
+        for (int l = 0; l < D; ++l) b[l] = cg_fma(x[l], csum, b[l]);
     }
 
     if (!live) return;
@@ -250,6 +287,22 @@ __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y,
     if (vg && l == 0) A0[j] = (j < m) ? A[j * (int64_t)(d + 1)] : (T)0;
 }
 
+// EXPD: Ex[2 j] = |gamma (y_j - c)|^2, Ex[2 j + 1] = gamma (y_j - c) . a_j for j < m; entry m (prefetch only) is zero
+template <typename T>
+__global__ __launch_bounds__(256) void grad_pack_extra_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A, T gamma, int32_t vg,
+                                                              const T* __restrict__ Cn, T* __restrict__ Ex) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > m) return;
+    T ny = (T)0, ya = (T)0;
+    if (j < m)
+        for (int l = 0; l < d; ++l) {
+            const T yl = (Y[j * (int64_t)d + l] - (Cn ? Cn[l] : (T)0)) * gamma;
+            ny = cg_fma(yl, yl, ny);
+            ya = cg_fma(yl, A[j * (int64_t)(d + vg) + vg + l], ya);
+        }
+    Ex[2 * j] = ny; Ex[2 * j + 1] = ya;
+}
+
 template <typename T, int FAM, int D>
 static int launch_grad_one(const GradArgs& a) {
     const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
@@ -269,9 +322,21 @@ static int launch_grad_one(const GradArgs& a) {
 #define CG_GRAD_LAUNCH(KEEPV, POWV, VGV)                                                                                                \
     hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,  \
                        (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,             \
-                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp)
+                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)nullptr)
     bool done = false;
-    if (a.vg) {   // the value-gradient variant always recomputes r (one instantiation per D)
+    if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
+        if (a.expd) {   // expanded form: 4 fma per dimension and pair (header)
+#define CG_GRAD_LAUNCH_X(POWV, VGV)                                                                                                     \
+            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false, POWV, VGV, true>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, \
+                               (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,     \
+                               (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)a.Ex)
+            if (a.vg) { if (pow) CG_GRAD_LAUNCH_X(POWT, true); else CG_GRAD_LAUNCH_X(false, true); }
+            else { if (pow) CG_GRAD_LAUNCH_X(POWT, false); else CG_GRAD_LAUNCH_X(false, false); }
+#undef CG_GRAD_LAUNCH_X
+            done = true;
+        }
+    }
+    if (!done && a.vg) {   // the value-gradient variant always recomputes r (one instantiation per D)
         if (pow) CG_GRAD_LAUNCH(false, POWT, true); else CG_GRAD_LAUNCH(false, false, true);
         done = true;
     }

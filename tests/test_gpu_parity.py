@@ -141,6 +141,53 @@ def test_gradient_mvm(cg, oracle, dtype, d):
                 assert relerr((K @ ad).cpu().numpy(), MK @ a.astype(np.float64)) <= 10 * tol
 
 
+@pytest.mark.parametrize("d", [1, 3, 8, 32, 48])
+def test_gradient_expanded_form_fp64(cg, oracle, d):
+    """fp64 isotropic gradient Gramians run the block mul! of src/gradient.jl:86-92 in the expanded form (|x - y|^2 from cached
+    norms, 4 instead of 6 fp64 instructions per dimension and pair; csrc/grad_mvm.hpp) while the pre-scaled clouds stay inside
+    the radius gate: both forms against the oracle at 1e-12, the gate sends wide / short-lengthscale data to direct
+    differences, fp32 and dot-product kernels never expand; value-gradient blocks too."""
+    rng = np.random.default_rng(990 + d)
+    n, m = 300, 211
+    X = rng.standard_normal((n, d)); Y = rng.standard_normal((m, d)) + 0.3
+    a = rng.standard_normal(m * d); y0 = rng.standard_normal(n * d)
+    av = rng.standard_normal(m * (d + 1))
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    try:
+        for k, ko in ((cg.EQ(), oracle.Kernel(oracle.EQ)), (cg.Lengthscale(cg.MaternP(2), 1.7), oracle.Kernel(oracle.MATERNP, p=2, lengthscale=1.7)),
+                      (1.5 * cg.RQ(2.0), oracle.Kernel(oracle.RQ, param=2.0, scale=1.5)), (cg.EQ() ** 2, oracle.Kernel(oracle.EQ, power=2))):
+            G = cg.gramian(cg.GradientKernel(k), Xd, Yd)
+            ref = oracle.grad_mul(y0, ko, X, Y, a, 0.7, -1.1)
+            outs = {}
+            for ex in (0, 1, -1):
+                cg.set_option("grad_expand", ex)
+                yd = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yd, G, torch.from_numpy(a).cuda(), 0.7, -1.1)
+                assert cg.get_info("last_grad_expand") == (0 if ex == 0 else 1), (ex, d)
+                outs[ex] = yd.cpu().numpy()
+                assert relerr(outs[ex], ref) <= 1e-12, (type(k).__name__, d, ex, relerr(outs[ex], ref))
+            assert relerr(outs[1], outs[0]) <= 1e-13
+            cg.set_option("grad_expand", -1)
+            Gv = cg.gramian(cg.ValueGradientKernel(k), Xd, Yd)
+            bv = (Gv @ torch.from_numpy(av).cuda()).cpu().numpy()
+            assert cg.get_info("last_grad_expand") == 1
+            assert relerr(bv, oracle.valgrad_mul(None, ko, X, Y, av)) <= 1e-12
+        # outside the gate: a cloud 100 lengthscales wide falls back to direct differences (and stays accurate)
+        Gw = cg.gramian(cg.GradientKernel(cg.Lengthscale(cg.EQ(), 0.02)), Xd, Yd)
+        bw = (Gw @ torch.from_numpy(a).cuda()).cpu().numpy()
+        assert cg.get_info("last_grad_expand") == 0
+        assert relerr(bw, oracle.grad_mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.02), X, Y, a)) <= 1e-12
+        # a translated cloud is centred first: still inside the gate, still accurate
+        Gs = cg.gramian(cg.GradientKernel(cg.EQ()), Xd + 1.0e4, Yd + 1.0e4)
+        bs = (Gs @ torch.from_numpy(a).cuda()).cpu().numpy()
+        assert cg.get_info("last_grad_expand") == 1
+        assert relerr(bs, oracle.grad_mul(None, oracle.Kernel(oracle.EQ), X + 1.0e4, Y + 1.0e4, a)) <= 1e-11
+        # fp32 and dot-product kernels never take it
+        (cg.gramian(cg.GradientKernel(cg.EQ()), Xd.float(), Yd.float()) @ torch.from_numpy(a).cuda().float()); assert cg.get_info("last_grad_expand") == 0
+        (cg.gramian(cg.GradientKernel(cg.Dot() ** 2), Xd, Yd) @ torch.from_numpy(a).cuda()); assert cg.get_info("last_grad_expand") == 0
+    finally:
+        cg.set_option("grad_expand", -1)
+
+
 def test_gradient_eq_block_closed_form(cg):
     """EQ gradient block = k (I - r r') (SURVEY §3.3 known answer)."""
     x = np.array([[0.3, -0.2, 0.5]]); y = np.array([[-0.1, 0.4, 0.2]])
