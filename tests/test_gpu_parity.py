@@ -162,15 +162,17 @@ def test_gradient_expanded_form_fp64(cg, oracle, d):
             for ex in (0, 1, -1):
                 cg.set_option("grad_expand", ex)
                 yd = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yd, G, torch.from_numpy(a).cuda(), 0.7, -1.1)
-                assert cg.get_info("last_grad_expand") == (0 if ex == 0 else 1), (ex, d)
+                auto = d >= 7 and not isinstance(k, cg.Lengthscale)           # the automatic rule: padded d >= 8, not MaternP
+                assert cg.get_info("last_grad_expand") == (0 if ex == 0 else (1 if ex == 1 else int(auto))), (ex, d)
                 outs[ex] = yd.cpu().numpy()
                 assert relerr(outs[ex], ref) <= 1e-12, (type(k).__name__, d, ex, relerr(outs[ex], ref))
             assert relerr(outs[1], outs[0]) <= 1e-13
-            cg.set_option("grad_expand", -1)
+            cg.set_option("grad_expand", 1)
             Gv = cg.gramian(cg.ValueGradientKernel(k), Xd, Yd)
             bv = (Gv @ torch.from_numpy(av).cuda()).cpu().numpy()
             assert cg.get_info("last_grad_expand") == 1
             assert relerr(bv, oracle.valgrad_mul(None, ko, X, Y, av)) <= 1e-12
+        cg.set_option("grad_expand", -1)
         # outside the gate: a cloud 100 lengthscales wide falls back to direct differences (and stays accurate)
         Gw = cg.gramian(cg.GradientKernel(cg.Lengthscale(cg.EQ(), 0.02)), Xd, Yd)
         bw = (Gw @ torch.from_numpy(a).cuda()).cpu().numpy()
@@ -179,7 +181,7 @@ def test_gradient_expanded_form_fp64(cg, oracle, d):
         # a translated cloud is centred first: still inside the gate, still accurate
         Gs = cg.gramian(cg.GradientKernel(cg.EQ()), Xd + 1.0e4, Yd + 1.0e4)
         bs = (Gs @ torch.from_numpy(a).cuda()).cpu().numpy()
-        assert cg.get_info("last_grad_expand") == 1
+        assert cg.get_info("last_grad_expand") == (1 if d >= 7 else 0)
         assert relerr(bs, oracle.grad_mul(None, oracle.Kernel(oracle.EQ), X + 1.0e4, Y + 1.0e4, a)) <= 1e-11
         # fp32 and dot-product kernels never take it
         (cg.gramian(cg.GradientKernel(cg.EQ()), Xd.float(), Yd.float()) @ torch.from_numpy(a).cuda().float()); assert cg.get_info("last_grad_expand") == 0
