@@ -451,6 +451,213 @@ __global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void 
     for (int i = 0; i < 4; ++i) { gA[tid + i * NT] = rowA[P(tid + i * NT)]; gB[tid + i * NT] = rowB[P(tid + i * NT)]; }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same fused kernel for M' = 4096 with RADIX-16 stages (round 2): a thread carries 16 elements of one row through a
+// 16-point DFT in registers (two radix-4 layers); the FIRST forward stage takes its inputs straight from global memory and the
+// LAST inverse stage writes its outputs there (span 256: coalesced along the butterfly index), so a row makes 2 + 2 round trips
+// through LDS instead of 6 + 6 plus a load and a store pass, and a butterfly's 15 twiddles W^(e q) come from ONE table read and
+// repeated multiplication (<= 15 roundings; the table reads were scattered 16-byte LDS accesses).  512 threads: thread (row, b)
+// owns butterfly b of its row.  Measured on C5 (fp64): 128 -> 103 us per MVM, fp32 85 -> 75 us (tools/c5_probe.py); radix-16 stages
+// alone, with the load / store passes and the table twiddles kept, measured 129 us — the passes, not the stage count, were the cost.  Forward = decimation in frequency (natural in,
+// base-16 digit-reversed out), inverse = decimation in time with conjugated twiddles; frequency k' lives at slot rev16(k')
+// between the two, and rev16(M' - 1 - k') = M' - 1 - rev16(k') as for any digit reversal.
+// ------------------------------------------------------------------------------------------------------------------------
+// W^idx from the quarter table, any idx < 4 Q (forward W = exp(-2 pi i / M'): W^Q = -i, W^2Q = -1, W^3Q = i)
+template <typename V, bool INV>
+__device__ __forceinline__ V full_tw(const V* __restrict__ stw, int idx, int Q) {
+    const int quad = idx / Q, r = idx & (Q - 1);
+    V w = stw[r];
+    if (quad == 1) w = V{w.y, -w.x};
+    else if (quad == 2) w = V{-w.x, -w.y};
+    else if (quad == 3) w = V{-w.y, w.x};
+    if (INV) w.y = -w.y;
+    return w;
+}
+
+// in-place 16-point DFT, output X[q] at index q (forward: e^{-2 pi i p q / 16}; INV: conjugate), as two radix-4 layers:
+// T[p1][q2] = sum_p2 w4^(p2 q2) x[p1 + 4 p2];  X[q2 + 4 q1] = sum_p1 w4^(p1 q1) (w16^(p1 q2) T[p1][q2])
+template <typename V, bool INV>
+__device__ __forceinline__ void dft16(V (&x)[16]) {
+    using T = decltype(x[0].x);
+    constexpr double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, C2 = 0.70710678118654752440;   // cos / sin of pi/8, pi/4
+    V t[16];
+#pragma unroll
+    for (int p1 = 0; p1 < 4; ++p1) {
+        const V a = x[p1], b = x[p1 + 4], c = x[p1 + 8], d = x[p1 + 12];
+        const V apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+        const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+        t[p1 * 4 + 0] = cadd(apc, bpd);
+        t[p1 * 4 + 1] = cadd(amc, ib);
+        t[p1 * 4 + 2] = csub(apc, bpd);
+        t[p1 * 4 + 3] = csub(amc, ib);
+    }
+    // twiddles w16^(p1 q2), p1 q2 in {1, 2, 3, 4, 6, 9}; forward w16^k = (cos(k pi/8), -sin(k pi/8))
+    auto tw = [](V v, double c, double sn) { const T cr = (T)c, si = (T)(INV ? sn : -sn); return V{v.x * cr - v.y * si, v.x * si + v.y * cr}; };
+    t[1 * 4 + 1] = tw(t[1 * 4 + 1], C1, S1);          // k = 1
+    t[1 * 4 + 2] = tw(t[1 * 4 + 2], C2, C2);          // k = 2
+    t[1 * 4 + 3] = tw(t[1 * 4 + 3], S1, C1);          // k = 3
+    t[2 * 4 + 1] = tw(t[2 * 4 + 1], C2, C2);          // k = 2
+    t[2 * 4 + 2] = INV ? cmuli(t[2 * 4 + 2]) : cmulmi(t[2 * 4 + 2]);   // k = 4: -i (forward)
+    t[2 * 4 + 3] = tw(t[2 * 4 + 3], -C2, C2);         // k = 6
+    t[3 * 4 + 1] = tw(t[3 * 4 + 1], S1, C1);          // k = 3
+    t[3 * 4 + 2] = tw(t[3 * 4 + 2], -C2, C2);         // k = 6
+    t[3 * 4 + 3] = tw(t[3 * 4 + 3], -C1, -S1);        // k = 9
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+        const V a = t[q2], b = t[4 + q2], c = t[8 + q2], d = t[12 + q2];
+        const V apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+        const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+        x[q2 + 0] = cadd(apc, bpd);
+        x[q2 + 4] = cadd(amc, ib);
+        x[q2 + 8] = csub(apc, bpd);
+        x[q2 + 12] = csub(amc, ib);
+    }
+}
+
+__device__ __forceinline__ int rev16_3(int x) { return ((x & 0xF) << 8) | (x & 0xF0) | ((x >> 8) & 0xF); }
+
+// (Reading the REAL spectrum of a symmetric embedding as M + 1 scalars — a sixth less traffic — was measured: 102.1 vs 102.6 us, not kept.)
+template <typename T>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
+                                                                          const typename V2T<T>::type* __restrict__ S,
+                                                                          const typename V2T<T>::type* __restrict__ tA,
+                                                                          const typename V2T<T>::type* __restrict__ tB,
+                                                                          const typename V2T<T>::type* __restrict__ twr) {
+    using V = typename V2T<T>::type;
+    constexpr int Mp = 4096, Q = Mp / 4, NT = 512;
+    constexpr int MpP = Mp + Mp / 16;
+    auto P = [](int i) { return i + (i >> 4); };
+    __shared__ V rowA[MpP];
+    __shared__ V rowB[MpP];
+    __shared__ V stw[Q];
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x;
+    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? COLFFT_N1 / 2 : COLFFT_N1 - wg;
+    V* __restrict__ gA = zbuf + (int64_t)kA * Mp;
+    V* __restrict__ gB = zbuf + (int64_t)kB * Mp;
+    V* __restrict__ xr = (tid >> 8) ? rowB : rowA;          // this thread's row
+    V* __restrict__ gr = (tid >> 8) ? gB : gA;
+    const int b = tid & 255;
+    // the first forward stage (span 256) takes its 16 inputs b + 256 q straight from global memory — coalesced along b — and
+    // the last inverse stage writes its outputs the same way: no separate load / store pass through LDS
+    V x0[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x0[q] = gr[b + 256 * q];
+#pragma unroll
+    for (int i = 0; i < Q / NT; ++i) stw[tid + i * NT] = twr[tid + i * NT];
+    __syncthreads();
+    // twiddles of a butterfly: w1 = W^e from the table, W^(e q) by repeated multiplication (15 roundings at most)
+    {
+        dft16<V, false>(x0);
+        const V w1 = full_tw<V, false>(stw, b, Q);
+        V w = w1;
+        xr[P(b)] = x0[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { xr[P(b + 256 * q)] = cmul(x0[q], w); w = cmul(w, w1); }
+        __syncthreads();
+    }
+
+    // ---- forward: radix-16 decimation in frequency, remaining spans 16, 1 ------------------------------------------------
+#pragma unroll 1
+    for (int s = 1; s < 3; ++s) {
+        const int lg = 8 - 4 * s, Ls = 1 << lg;
+        const int j = b & (Ls - 1), g = b >> lg;
+        const int i0 = g * 16 * Ls + j;
+        V x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = xr[P(i0 + q * Ls)];
+        dft16<V, false>(x);
+        xr[P(i0)] = x[0];
+        if (s == 2) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) xr[P(i0 + q)] = x[q];
+        } else {
+            const V w1 = full_tw<V, false>(stw, j << 4, Q);
+            V w = w1;
+#pragma unroll
+            for (int q = 1; q < 16; ++q) { xr[P(i0 + q * Ls)] = cmul(x[q], w); w = cmul(w, w1); }
+        }
+        __syncthreads();
+    }
+
+    // ---- spectral step on conjugate pairs (same algebra as spectral_kernel; frequency k' lives at slot rev16(k')) --------
+    auto pair = [&](V& zs, V& zps, bool self, int k1, int kp, int64_t pos, int64_t ppos) {
+        const V Z = zs;
+        if (pos == 0) {
+            const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
+            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+            zs = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
+            return;
+        }
+        const V Zp = zps;
+        const V w = cmul(tA[k1], tB[kp]);
+        const V wc = cconj(w);
+        const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
+        const V wo = cmul(w, o);
+        const V X{(T)0.5 * (e.x + wo.y), (T)0.5 * (e.y - wo.x)};
+        const V ep = cconj(e), op = V{-o.x, o.y};
+        const V wop = cmul(wc, op);
+        const V Xp{(T)0.5 * (ep.x - wop.y), (T)0.5 * (ep.y + wop.x)};
+        const V Y = cmul(X, S[pos]), Yp = cmul(Xp, S[ppos]);
+        const V f = cadd(Y, cconj(Yp)), h = csub(Y, cconj(Yp));
+        const V wh = cmul(wc, h);
+        zs = V{(T)0.5 * (f.x - wh.y), (T)0.5 * (f.y + wh.x)};
+        if (!self) {
+            const V fp = cconj(f), hp = V{-h.x, h.y};
+            const V whp = cmul(w, hp);
+            zps = V{(T)0.5 * (fp.x + whp.y), (T)0.5 * (fp.y - whp.x)};
+        }
+    };
+    if (wg != 0) {
+#pragma unroll 2
+        for (int i = 0; i < Mp / NT; ++i) {
+            const int kp = tid + i * NT;
+            const int p = rev16_3(kp);
+            pair(rowA[P(p)], rowB[P(Mp - 1 - p)], false, kA, kp, (int64_t)kA * Mp + kp, (int64_t)kB * Mp + (Mp - 1 - kp));
+        }
+    } else {
+        for (int i = 0; i < Mp / NT; ++i) {
+            const int kp = tid + i * NT;
+            const int kq = (Mp - kp) & (Mp - 1);
+            if (kp <= kq) pair(rowA[P(rev16_3(kp))], rowA[P(rev16_3(kq))], kp == kq, 0, kp, (int64_t)kp, (int64_t)kq);
+            const int kr = Mp - 1 - kp;
+            if (kp < kr) {
+                const int p = rev16_3(kp);
+                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, COLFFT_N1 / 2, kp, (int64_t)(COLFFT_N1 / 2) * Mp + kp, (int64_t)(COLFFT_N1 / 2) * Mp + kr);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- inverse: radix-16 decimation in time, conjugated twiddles, spans 1, 16, 256 -------------------------------------
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        const int lg = 4 * s, Ls = 1 << lg;
+        const int j = b & (Ls - 1), g = b >> lg;
+        const int i0 = g * 16 * Ls + j;
+        V x[16];
+        x[0] = xr[P(i0)];
+        if (s == 0) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) x[q] = xr[P(i0 + q)];
+        } else {
+            const V w1 = full_tw<V, true>(stw, j << (4 * (2 - s)), Q);     // conj W^(j M' / (16 Ls))
+            V w = w1;
+#pragma unroll
+            for (int q = 1; q < 16; ++q) { x[q] = cmul(w, xr[P(i0 + q * Ls)]); w = cmul(w, w1); }
+        }
+        dft16<V, true>(x);
+        if (s == 2) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gr[b + 256 * q] = x[q];            // natural order, coalesced along b
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xr[P(i0 + q * Ls)] = x[q];
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace covgram
 
 using namespace covgram;
@@ -544,6 +751,9 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
         const dim3 fg(COLFFT_N1 / 2);
 #define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
                                         (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
+        if (L == 6 && Tz->ctx->toeplitz_fused != 2)   // M' = 4096: radix-16 stages (option toeplitz_fused = 2 keeps the radix-4 kernel: A/B)
+            hipLaunchKernelGGL((rowfft16_fused_kernel<T>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr);
+        else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
 #undef CG_FUSED
         hipLaunchKernelGGL((colfft_kernel<T, TW, true>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, (const T*)nullptr, (int64_t)0,

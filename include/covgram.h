@@ -133,7 +133,8 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 /* tuning / A-B knobs: "dense_variant" (0 = auto: fp32 EQ runs on the matrix cores when the norm bound of dense_mfma.hip
  * holds and the plain dot-product Gramian is applied as X (Y' a), 1 = always the entry-by-entry direct kernel, 2 = matrix
  * cores whenever the shape allows), "rows_per_lane", "jsplit",
- * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused", "mfma_lds" (matrix-core EQ path: four waves share the
+ * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused" (1 = fused row-FFT kernels, radix-16 stages at M' = 4096; 0 = rocFFT
+ * batches; 2 = radix-4 stages everywhere), "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
  * -1 = from n = 24000, 0 = never, 1 = always),

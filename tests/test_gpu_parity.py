@@ -1235,7 +1235,7 @@ def test_toeplitz_direct_solvers_durbin_levinson_trench(cg, oracle, n):
                                      (torch.float32, 250000), (torch.float32, 4000000)])
 def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
     """M' = N / 2048 in {64, 256, 1024, 4096}: the row FFT, spectral step and inverse row FFT run as ONE kernel
-    (rowfft_fused_kernel) — against the numpy circulant-embedding oracle, explicit dense rows, and the rocFFT-batch path
+    (rowfft_fused_kernel; M' = 4096: rowfft16_fused_kernel, radix-16 stages with global I/O in the outer stages) — against the numpy circulant-embedding oracle, explicit dense rows, and the rocFFT-batch path
     (option toeplitz_fused = 0), symmetric and non-symmetric, alpha / beta."""
     tol = 1e-5 if dtype == torch.float32 else 1e-10
     rng = np.random.default_rng(n)
@@ -1248,13 +1248,13 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
     ref = oracle.toeplitz_mul(None, vc, None, a.astype(np.float64))
     try:
         out = {}
-        for fused in (1, 0):
+        for fused in (1, 0, 2):      # 1: the default (radix-16 stages at M' = 4096), 0: rocFFT batches, 2: radix-4 stages everywhere
             cg.set_option("toeplitz_fused", fused)
             yd = torch.from_numpy(y0.copy()).cuda()
             cg.mul_(yd, G, ad, 0.3, -1.1)
             out[fused] = yd.cpu().numpy()
             assert relerr(out[fused], 0.3 * ref - 1.1 * y0) <= tol, (fused, n, relerr(out[fused], 0.3 * ref - 1.1 * y0))
-        assert relerr(out[1], out[0]) <= tol
+        assert relerr(out[1], out[0]) <= tol and relerr(out[2], out[1]) <= tol
         cg.set_option("toeplitz_fused", 1)
         b = (G @ ad).cpu().numpy()
         rows = rng.choice(n, 8, replace=False)

@@ -7,10 +7,13 @@ e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=T
 for dt in (torch.float64, torch.float32):
     T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n, dtype=dt))
     a = torch.randn(n, dtype=T.dtype, device="cuda"); y = torch.empty_like(a)
-    for _ in range(10): T.mul_(y, a)
-    torch.cuda.synchronize(); ts = []
+    res = {}
     for rep in range(5):
-        e0.record()
-        for _ in range(50): T.mul_(y, a)
-        e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 50 * 1e3)
-    print(f"C5 {T.dtype}: median {np.median(ts):.1f} us  min {min(ts):.1f} us")
+        for fused in (1, 2):         # interleaved A/B of the two fused row-FFT kernels (option toeplitz_fused)
+            cg.set_option("toeplitz_fused", fused)
+            for _ in range(5): T.mul_(y, a)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(50): T.mul_(y, a)
+            e1.record(); e1.synchronize(); res.setdefault(fused, []).append(e0.elapsed_time(e1) / 50 * 1e3)
+    cg.set_option("toeplitz_fused", 1)
+    print(f"C5 {T.dtype}: " + "  ".join(f"toeplitz_fused={k}: median {np.median(v):.1f} us min {min(v):.1f} us" for k, v in res.items()))
