@@ -435,6 +435,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     CG_REQUIRE(ctx && key, COVGRAM_EINVAL, "NULL argument");
     if (!strcmp(key, "dense_variant")) ctx->dense_variant = value;
     else if (!strcmp(key, "toeplitz_fused")) ctx->toeplitz_fused = value;
+    else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;

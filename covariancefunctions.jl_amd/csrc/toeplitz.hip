@@ -514,6 +514,146 @@ __device__ __forceinline__ void dft16(V (&x)[16]) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// colfft16_kernel: the column FFT (length 1024, stride M') as 16 x 4 x 16 with the radix-16 butterflies in registers.
+//
+// Same job and same tile shape as colfft_kernel (TW adjacent columns = 64-byte row segments, inter-step twiddle W_M^(n' k1),
+// real input read directly, y <- alpha t + beta y on the way out) with two LDS exchanges instead of four passes:
+//   forward (decimation in frequency):  rows b + 64 q from HBM -> dft16 over q, x W_1024^(b q') -> LDS
+//                                       radix 4 over the span 16 inside each 64-block, x W_64^(j m')      (in place)
+//                                       dft16 over the span 1 -> rows q' + 16 m' + 64 q'' to HBM, x W_M^(n' row)
+//   inverse (decimation in time):       the transposed graph, conjugated: rows k0 + 64 q'' from HBM -> ... -> rows b + 64 q.
+// The frequency digits come out of a DIF in reversed order; the last stage holds them in registers and simply stores each
+// value to its true row (rows are 64-byte segments 16 M' bytes apart either way), so no reordering pass exists.
+// Position p of a column lives at LDS row p + (p >> 4): the span-1 stage (lanes 16 positions apart) then falls on all four
+// 64-byte quarters of the 256-byte bank row inside every lane group of ds_read_b128 (MI355X_MICROARCH.md, LDS) and the
+// other two stages stay contiguous.  Twiddles: one table read per butterfly, powers by squaring / one multiply (depth <= 6).
+// 64 TW threads, 68 KB of LDS: two workgroups per CU, each thread 16 loads in flight.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename V> __device__ __forceinline__ void pow_chain16(V w1, V (&w)[16]) {   // w[q] = w1^q, q = 1..15 (w[0] unused)
+    w[1] = w1;
+#pragma unroll
+    for (int q = 2; q < 16; ++q) w[q] = (q & 1) ? cmul(w[q - 1], w1) : cmul(w[q / 2], w[q / 2]);
+}
+
+template <typename V, bool INV> __device__ __forceinline__ void dft4(V (&v)[4]) {
+    const V apc = cadd(v[0], v[2]), amc = csub(v[0], v[2]), bpd = cadd(v[1], v[3]), bmd = csub(v[1], v[3]);
+    const V ib = INV ? cmuli(bmd) : cmulmi(bmd);
+    v[0] = cadd(apc, bpd); v[1] = cadd(amc, ib); v[2] = csub(apc, bpd); v[3] = csub(amc, ib);
+}
+
+template <typename T, int TW, bool INV>
+__global__ __launch_bounds__(64 * TW, 2) void colfft16_kernel(const T* __restrict__ src, int64_t src_len,
+                                                               typename V2T<T>::type* __restrict__ zbuf, int64_t Mp,
+                                                               const typename V2T<T>::type* __restrict__ tw1024,
+                                                               const typename V2T<T>::type* __restrict__ tlo,
+                                                               const typename V2T<T>::type* __restrict__ thi, T* __restrict__ y, int64_t n,
+                                                               T alpha, T beta) {
+    using V = typename V2T<T>::type;
+    constexpr int ROWS = COLFFT_N1 + COLFFT_N1 / 16;
+    __shared__ V buf[ROWS * TW];
+    const int tid = threadIdx.x;
+    const unsigned bid = blockIdx.x;
+    const unsigned tile = (gridDim.x % 16 == 0) ? (2 * (8 * (bid / 16) + (bid % 8)) + ((bid / 8) % 2)) : bid;   // as colfft_kernel
+    const int c = tid % TW, r = tid / TW;                  // r = 0..63: the butterfly of this thread in the radix-16 stages
+    const int64_t np = (int64_t)tile * TW + c;             // column n'
+    auto twM = [&](int64_t idx) { return cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]); };   // W_M^idx
+    const int k0 = (r >> 2) + 16 * (r & 3);                // span-1 stage: butterfly r = 4 q' + m' owns the rows q' + 16 m' + 64 q''
+    const int j = r & 15, gw = r >> 4;                     // radix-4 stage: butterflies (g = 4 gw + i, j)
+    V x[16], w[16];
+    if constexpr (!INV) {
+        // ---- rows b + 64 q of column n' (b = r): z_j = x[2j] + i x[2j+1], zero beyond src_len -------------------------------
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t e = 2 * ((int64_t)(r + 64 * q) * Mp + np);
+            x[q].x = (e < src_len) ? src[e] : (T)0;
+            x[q].y = (e + 1 < src_len) ? src[e + 1] : (T)0;
+        }
+        dft16<V, false>(x);
+        pow_chain16(tw1024[r], w);
+        const int p0 = (r + (r >> 4)) * TW + c;
+        buf[p0] = x[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) buf[p0 + 68 * q * TW] = cmul(x[q], w[q]);
+        __syncthreads();
+        {
+            const V w1 = tw1024[16 * j], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = (68 * (4 * gw + i) + j) * TW + c;
+                V v[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = buf[p + 17 * m * TW];
+                dft4<V, false>(v);
+                buf[p] = v[0];
+                buf[p + 17 * TW] = cmul(v[1], w1);
+                buf[p + 34 * TW] = cmul(v[2], w2);
+                buf[p + 51 * TW] = cmul(v[3], w3);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = buf[(17 * r + q) * TW + c];
+        dft16<V, false>(x);
+        // inter-step twiddle W_M^(n' (k0 + 64 q)) = W_M^(n' k0) (W_M^(64 n'))^q
+        pow_chain16(twM(64 * np), w);
+        const V wk = twM(np * k0);
+        V* __restrict__ zo = zbuf + (int64_t)k0 * Mp + np;
+        zo[0] = cmul(x[0], wk);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) zo[(int64_t)64 * q * Mp] = cmul(x[q], cmul(wk, w[q]));
+    } else {
+        const V* __restrict__ zi = zbuf + (int64_t)k0 * Mp + np;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = zi[(int64_t)64 * q * Mp];
+        pow_chain16(cconj(twM(64 * np)), w);
+        const V wk = cconj(twM(np * k0));
+        x[0] = cmul(x[0], wk);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], cmul(wk, w[q]));
+        dft16<V, true>(x);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) buf[(17 * r + q) * TW + c] = x[q];
+        __syncthreads();
+        {
+            const V w1 = cconj(tw1024[16 * j]), w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = (68 * (4 * gw + i) + j) * TW + c;
+                V v[4];
+                v[0] = buf[p];
+                v[1] = cmul(buf[p + 17 * TW], w1);
+                v[2] = cmul(buf[p + 34 * TW], w2);
+                v[3] = cmul(buf[p + 51 * TW], w3);
+                dft4<V, true>(v);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) buf[p + 17 * m * TW] = v[m];
+            }
+        }
+        __syncthreads();
+        pow_chain16(cconj(tw1024[r]), w);
+        const int p0 = (r + (r >> 4)) * TW + c;
+        x[0] = buf[p0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmul(buf[p0 + 68 * q * TW], w[q]);
+        dft16<V, true>(x);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t e = 2 * ((int64_t)(r + 64 * q) * Mp + np);       // natural order: y[e], y[e + 1]
+            if (e < n) {
+                T ov = alpha * x[q].x;
+                if (beta != (T)0) ov = __builtin_fma(beta, y[e], ov);
+                y[e] = ov;
+            }
+            if (e + 1 < n) {
+                T ov = alpha * x[q].y;
+                if (beta != (T)0) ov = __builtin_fma(beta, y[e + 1], ov);
+                y[e + 1] = ov;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ int rev16_3(int x) { return ((x & 0xF) << 8) | (x & 0xF0) | ((x >> 8) & 0xF); }
 
 // (Reading the REAL spectrum of a symmetric embedding as M + 1 scalars — a sixth less traffic — was measured: 102.1 vs 102.6 us, not kept.)
@@ -722,6 +862,21 @@ static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     return t;
 }
 
+// the column FFT of the fast path, either direction (option toeplitz_colfft: 16 = colfft16_kernel, default; 4 = colfft_kernel)
+template <typename T, bool INV>
+static void launch_colfft(covgram_toeplitz* Tz, const FastTables& t, const T* src, int64_t len, T* y, int64_t n, T alpha, T beta) {
+    using V = typename V2T<T>::type;
+    constexpr int TW = colfft_tw<T>();
+    hipStream_t st = Tz->ctx->stream;
+    const dim3 grid((unsigned)(Tz->Mp / TW));
+    if (Tz->ctx->toeplitz_colfft != 4)
+        hipLaunchKernelGGL((colfft16_kernel<T, TW, INV>), grid, dim3(64 * TW), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
+                           (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, n, alpha, beta);
+    else
+        hipLaunchKernelGGL((colfft_kernel<T, TW, INV>), grid, dim3(COLFFT_THREADS), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
+                           (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, n, alpha, beta);
+}
+
 // zbuf <- permuted packed spectrum of the real signal src[0..len) (zero beyond), length N
 template <typename T>
 static int fast_forward(covgram_toeplitz* Tz, const T* src, int64_t len) {
@@ -729,8 +884,7 @@ static int fast_forward(covgram_toeplitz* Tz, const T* src, int64_t len) {
     constexpr int TW = colfft_tw<T>();
     const FastTables t = table_ptrs(Tz);
     hipStream_t st = Tz->ctx->stream;
-    hipLaunchKernelGGL((colfft_kernel<T, TW, false>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
-                       (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, (T*)nullptr, (int64_t)0, (T)0, (T)0);
+    launch_colfft<T, false>(Tz, t, src, len, (T*)nullptr, (int64_t)0, (T)0, (T)0);
     void* io[1] = {Tz->zbuf};
     CG_CHECK_FFT(rocfft_execute(Tz->bfwd, io, nullptr, Tz->info));
     return COVGRAM_OK;
@@ -746,8 +900,7 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
     for (int l = 3; l <= 6; ++l) if (Tz->Mp == ((int64_t)1 << (2 * l))) L = l;
     if (L && Tz->ctx->toeplitz_fused) {
         // column FFT -> [row FFT, spectral step, inverse row FFT] in one kernel -> inverse column FFT: three passes over zbuf
-        hipLaunchKernelGGL((colfft_kernel<T, TW, false>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, a, Tz->m, (V*)Tz->zbuf, Tz->Mp,
-                           (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, (T*)nullptr, (int64_t)0, (T)0, (T)0);
+        launch_colfft<T, false>(Tz, t, a, Tz->m, (T*)nullptr, (int64_t)0, (T)0, (T)0);
         const dim3 fg(COLFFT_N1 / 2);
 #define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
                                         (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
@@ -756,8 +909,7 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
         else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
 #undef CG_FUSED
-        hipLaunchKernelGGL((colfft_kernel<T, TW, true>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, (const T*)nullptr, (int64_t)0,
-                           (V*)Tz->zbuf, Tz->Mp, (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, Tz->n, (T)alpha, (T)beta);
+        launch_colfft<T, true>(Tz, t, (const T*)nullptr, (int64_t)0, y, Tz->n, (T)alpha, (T)beta);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { set_error("toeplitz fused path launch failed: %s", hipGetErrorString(e2)); return COVGRAM_EHIP; }
         return COVGRAM_OK;
@@ -769,8 +921,7 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
                        (const V*)t.tA, (const V*)t.tB);
     void* io[1] = {Tz->zbuf};
     CG_CHECK_FFT(rocfft_execute(Tz->binv, io, nullptr, Tz->info));
-    hipLaunchKernelGGL((colfft_kernel<T, TW, true>), dim3((unsigned)(Tz->Mp / TW)), dim3(COLFFT_THREADS), 0, st, (const T*)nullptr, (int64_t)0, (V*)Tz->zbuf,
-                       Tz->Mp, (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, Tz->n, (T)alpha, (T)beta);
+    launch_colfft<T, true>(Tz, t, (const T*)nullptr, (int64_t)0, y, Tz->n, (T)alpha, (T)beta);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("toeplitz fast path launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -1256,6 +1256,12 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
             assert relerr(out[fused], 0.3 * ref - 1.1 * y0) <= tol, (fused, n, relerr(out[fused], 0.3 * ref - 1.1 * y0))
         assert relerr(out[1], out[0]) <= tol and relerr(out[2], out[1]) <= tol
         cg.set_option("toeplitz_fused", 1)
+        # the column FFT: radix-16 register butterflies (colfft16_kernel, the default, used above) against the radix-4 LDS kernel
+        cg.set_option("toeplitz_colfft", 4)
+        yd = torch.from_numpy(y0.copy()).cuda()
+        cg.mul_(yd, G, ad, 0.3, -1.1)
+        cg.set_option("toeplitz_colfft", 16)
+        assert relerr(yd.cpu().numpy(), 0.3 * ref - 1.1 * y0) <= tol and relerr(yd.cpu().numpy(), out[1]) <= tol
         b = (G @ ad).cpu().numpy()
         rows = rng.choice(n, 8, replace=False)
         dense_rows = np.array([np.dot(vc[np.abs(i - np.arange(n))], a.astype(np.float64)) for i in rows])
@@ -1266,6 +1272,7 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
         assert relerr((Tn @ ad).cpu().numpy(), oracle.toeplitz_mul(None, vc2, vr2, a.astype(np.float64))) <= tol
     finally:
         cg.set_option("toeplitz_fused", 1)
+        cg.set_option("toeplitz_colfft", 16)
 
 
 def test_matern_real_nu_golden(cg, oracle):

@@ -9,11 +9,11 @@ for dt in (torch.float64, torch.float32):
     a = torch.randn(n, dtype=T.dtype, device="cuda"); y = torch.empty_like(a)
     res = {}
     for rep in range(5):
-        for fused in (1, 2):         # interleaved A/B of the two fused row-FFT kernels (option toeplitz_fused)
-            cg.set_option("toeplitz_fused", fused)
+        for fused in ((1, 16), (1, 4), (2, 4)):   # interleaved A/B: (toeplitz_fused, toeplitz_colfft) = the default, radix-4 column FFT, round 1's kernels
+            cg.set_option("toeplitz_fused", fused[0]); cg.set_option("toeplitz_colfft", fused[1])
             for _ in range(5): T.mul_(y, a)
             torch.cuda.synchronize(); e0.record()
             for _ in range(50): T.mul_(y, a)
             e1.record(); e1.synchronize(); res.setdefault(fused, []).append(e0.elapsed_time(e1) / 50 * 1e3)
-    cg.set_option("toeplitz_fused", 1)
-    print(f"C5 {T.dtype}: " + "  ".join(f"toeplitz_fused={k}: median {np.median(v):.1f} us min {min(v):.1f} us" for k, v in res.items()))
+    cg.set_option("toeplitz_fused", 1); cg.set_option("toeplitz_colfft", 16)
+    print(f"C5 {T.dtype}: " + "  ".join(f"(fused, colfft)={k}: median {np.median(v):.1f} us min {min(v):.1f} us" for k, v in res.items()))
