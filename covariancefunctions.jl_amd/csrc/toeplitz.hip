@@ -656,13 +656,26 @@ __global__ __launch_bounds__(64 * TW, 2) void colfft16_kernel(const T* __restric
 
 __device__ __forceinline__ int rev16_3(int x) { return ((x & 0xF) << 8) | (x & 0xF0) | ((x >> 8) & 0xF); }
 
-// (Reading the REAL spectrum of a symmetric embedding as M + 1 scalars — a sixth less traffic — was measured: 102.1 vs 102.6 us, not kept.)
+// S16[k1][rev16(k')] = S[k1][k'] for M' = 4096 (rowfft16_fused_kernel reads the spectrum in the slot order of its LDS rows)
+template <typename T>
+__global__ void permute16_kernel(const typename V2T<T>::type* __restrict__ S, typename V2T<T>::type* __restrict__ S16, int64_t tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    const int p = (int)(i & 4095);
+    S16[i] = S[(i & ~(int64_t)4095) | (((p & 0xF) << 8) | (p & 0xF0) | ((p >> 8) & 0xF))];
+}
+
+
+// (Measured and not kept: the REAL spectrum of a symmetric embedding read as M + 1 scalars, a sixth less traffic: 102.1 vs 102.6 us;
+// fetching the thread's 16 spectrum values into registers at kernel start (fp64, 206 VGPRs): 96.1 vs 89.7 us.)
 template <typename T>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
                                                                           const typename V2T<T>::type* __restrict__ S,
                                                                           const typename V2T<T>::type* __restrict__ tA,
                                                                           const typename V2T<T>::type* __restrict__ tB,
-                                                                          const typename V2T<T>::type* __restrict__ twr) {
+                                                                          const typename V2T<T>::type* __restrict__ twr,
+                                                                          const typename V2T<T>::type* __restrict__ S16,
+                                                                          const typename V2T<T>::type* __restrict__ tB16) {
     using V = typename V2T<T>::type;
     constexpr int Mp = 4096, Q = Mp / 4, NT = 512;
     constexpr int MpP = Mp + Mp / 16;
@@ -721,7 +734,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
     }
 
     // ---- spectral step on conjugate pairs (same algebra as spectral_kernel; frequency k' lives at slot rev16(k')) --------
-    auto pair = [&](V& zs, V& zps, bool self, int k1, int kp, int64_t pos, int64_t ppos) {
+    // S16 / tB16 = the rows of S and the table tB with their entries at the digit-reversed index (built with the handle): thread
+    // t then owns the LDS slots t + 512 i — consecutive lanes on consecutive slots, no bank conflicts — and still reads the
+    // spectrum contiguously.  (With natural-order S the lanes sat 256 slots apart: 8-way conflicts, more LDS cycles than all six stages.)
+    auto pair = [&](V& zs, V& zps, bool self, int k1, int kp, int64_t pos, int64_t ppos, const V* sp = nullptr, const V* spp = nullptr, const V* wp = nullptr) {
         const V Z = zs;
         if (pos == 0) {
             const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
@@ -730,7 +746,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
             return;
         }
         const V Zp = zps;
-        const V w = cmul(tA[k1], tB[kp]);
+        const V w = cmul(tA[k1], wp ? *wp : tB[kp]);
         const V wc = cconj(w);
         const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
         const V wo = cmul(w, o);
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
         const V ep = cconj(e), op = V{-o.x, o.y};
         const V wop = cmul(wc, op);
         const V Xp{(T)0.5 * (ep.x - wop.y), (T)0.5 * (ep.y + wop.x)};
-        const V Y = cmul(X, S[pos]), Yp = cmul(Xp, S[ppos]);
+        const V Y = cmul(X, sp ? *sp : S[pos]), Yp = cmul(Xp, spp ? *spp : S[ppos]);
         const V f = cadd(Y, cconj(Yp)), h = csub(Y, cconj(Yp));
         const V wh = cmul(wc, h);
         zs = V{(T)0.5 * (f.x - wh.y), (T)0.5 * (f.y + wh.x)};
@@ -749,11 +765,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
         }
     };
     if (wg != 0) {
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < Mp / NT; ++i) {
-            const int kp = tid + i * NT;
-            const int p = rev16_3(kp);
-            pair(rowA[P(p)], rowB[P(Mp - 1 - p)], false, kA, kp, (int64_t)kA * Mp + kp, (int64_t)kB * Mp + (Mp - 1 - kp));
+            const int p = tid + i * NT;                    // slot p holds frequency k' = rev16(p); its partner M' - 1 - k' sits at slot M' - 1 - p
+            const V wt = tB16[p];
+            const V s1 = S16[(int64_t)kA * Mp + p], s2 = S16[(int64_t)kB * Mp + (Mp - 1 - p)];
+            pair(rowA[P(p)], rowB[P(Mp - 1 - p)], false, kA, 0, 1, 1, &s1, &s2, &wt);
         }
     } else {
         for (int i = 0; i < Mp / NT; ++i) {
@@ -820,6 +837,7 @@ struct covgram_toeplitz {
     rocfft_plan bfwd = nullptr, binv = nullptr;   // 1024 contiguous length-Mp complex transforms, in place
     void* zbuf = nullptr;    // M complex
     void* sperm = nullptr;   // M + 1 complex: permuted half spectrum of the embedding / M, Nyquist bin last
+    void* sperm16 = nullptr; // M' = 4096: the same rows with their entries at the base-16 digit-reversed index (rowfft16_fused_kernel)
     void* tables = nullptr;  // tw1024 | tlo(2048) | thi(M/2048) | tA(1024) | tB(Mp)   (complex)
 };
 
@@ -836,7 +854,7 @@ template <typename T>
 static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
     const long double PI = 3.14159265358979323846264338327950288L;
     const int64_t nhi = M >> TWID_LB;
-    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp + Mp / 4));
+    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp + Mp / 4 + Mp));
     size_t o = 0;
     auto put = [&](long double ang) { h[o++] = (T)cosl(ang); h[o++] = (T)sinl(ang); };
     for (int t = 0; t < COLFFT_N1; ++t) put(-2 * PI * t / COLFFT_N1);                 // tw1024[t] = W_1024^t
@@ -845,9 +863,13 @@ static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
     for (int k1 = 0; k1 < COLFFT_N1; ++k1) put(-PI * k1 / (long double)M);             // tA[k1]    = exp(-i pi k1 / M)
     for (int64_t kp = 0; kp < Mp; ++kp) put(-PI * kp / (long double)Mp);               // tB[k']    = exp(-i pi 1024 k' / M)
     for (int64_t r = 0; r < Mp / 4; ++r) put(-2 * PI * r / (long double)Mp);           // twr[r]    = W_M'^r (quarter table)
+    for (int64_t p = 0; p < Mp; ++p) {                                                 // tB16[p]   = tB[rev16(p)] (M' = 4096 only)
+        const int64_t kp = (Mp == 4096) ? (((p & 0xF) << 8) | (p & 0xF0) | ((p >> 8) & 0xF)) : p;
+        put(-PI * kp / (long double)Mp);
+    }
 }
 
-struct FastTables { const void *tw, *tlo, *thi, *tA, *tB, *twr; };
+struct FastTables { const void *tw, *tlo, *thi, *tA, *tB, *twr, *tB16; };
 static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     const size_t cs = 2 * dtype_size(Tz->dtype);
     const char* b = (const char*)Tz->tables;
@@ -858,7 +880,8 @@ static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     t.thi = b; b += cs * nhi;
     t.tA = b; b += cs * COLFFT_N1;
     t.tB = b; b += cs * Tz->Mp;
-    t.twr = b;
+    t.twr = b; b += cs * (Tz->Mp / 4);
+    t.tB16 = b;
     return t;
 }
 
@@ -905,7 +928,8 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
 #define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
                                         (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
         if (L == 6 && Tz->ctx->toeplitz_fused != 2)   // M' = 4096: radix-16 stages (option toeplitz_fused = 2 keeps the radix-4 kernel: A/B)
-            hipLaunchKernelGGL((rowfft16_fused_kernel<T>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr);
+            hipLaunchKernelGGL((rowfft16_fused_kernel<T>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
+                               (const V*)Tz->sperm16, (const V*)t.tB16);
         else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
 #undef CG_FUSED
@@ -942,7 +966,7 @@ int covgram_toeplitz_destroy(covgram_toeplitz* T) {
     if (T->bfwd) rocfft_plan_destroy(T->bfwd);
     if (T->binv) rocfft_plan_destroy(T->binv);
     if (T->info) rocfft_execution_info_destroy(T->info);
-    void* bufs[] = {T->work, T->spec, T->rbuf, T->cbuf, T->stage_a, T->stage_y, T->zbuf, T->sperm, T->tables};
+    void* bufs[] = {T->work, T->spec, T->rbuf, T->cbuf, T->stage_a, T->stage_y, T->zbuf, T->sperm, T->sperm16, T->tables};
     for (void* b : bufs) if (b) (void)hipFree(b);
     T->ctx->live_handles--;
     if (--g_rocfft_users == 0) rocfft_cleanup();
@@ -1040,6 +1064,11 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
             if (fast_forward<double>(T, (const double*)T->rbuf, N)) return fail(COVGRAM_EHIP);
             hipLaunchKernelGGL(half_spectrum_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)T->zbuf, T->Mp,
                                (const double2*)ft.tA, (const double2*)ft.tB, (double2*)T->sperm, 1.0 / (double)Mh);
+        }
+        if (T->Mp == 4096) {
+            TRY_HIP(hipMalloc(&T->sperm16, (size_t)tot * 2 * ts));
+            if (dtype == COVGRAM_F32) hipLaunchKernelGGL(permute16_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const float2*)T->sperm, (float2*)T->sperm16, tot);
+            else hipLaunchKernelGGL(permute16_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)T->sperm, (double2*)T->sperm16, tot);
         }
         TRY_HIP(hipStreamSynchronize(ctx->stream));
         (void)hipFree(T->rbuf); T->rbuf = nullptr;      // the fast path needs no real scratch buffer per MVM
