@@ -657,24 +657,27 @@ __global__ __launch_bounds__(64 * TW, 2) void colfft16_kernel(const T* __restric
 __device__ __forceinline__ int rev16_3(int x) { return ((x & 0xF) << 8) | (x & 0xF0) | ((x >> 8) & 0xF); }
 
 // S16[k1][rev16(k')] = S[k1][k'] for M' = 4096 (rowfft16_fused_kernel reads the spectrum in the slot order of its LDS rows)
-template <typename T>
-__global__ void permute16_kernel(const typename V2T<T>::type* __restrict__ S, typename V2T<T>::type* __restrict__ S16, int64_t tot) {
+// REALS (SymmetricToeplitz: the embedding is even, its spectrum real): the copy keeps the real parts only, M scalars
+template <typename T, bool REALS>
+__global__ void permute16_kernel(const typename V2T<T>::type* __restrict__ S, void* __restrict__ S16, int64_t tot) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tot) return;
     const int p = (int)(i & 4095);
-    S16[i] = S[(i & ~(int64_t)4095) | (((p & 0xF) << 8) | (p & 0xF0) | ((p >> 8) & 0xF))];
+    const auto v = S[(i & ~(int64_t)4095) | (((p & 0xF) << 8) | (p & 0xF0) | ((p >> 8) & 0xF))];
+    if constexpr (REALS) ((T*)S16)[i] = v.x;
+    else ((typename V2T<T>::type*)S16)[i] = v;
 }
 
 
-// (Measured and not kept: the REAL spectrum of a symmetric embedding read as M + 1 scalars, a sixth less traffic: 102.1 vs 102.6 us;
-// fetching the thread's 16 spectrum values into registers at kernel start (fp64, 206 VGPRs): 96.1 vs 89.7 us.)
-template <typename T>
+// REALS: the digit-reversed spectrum copy of a symmetric matrix holds real parts only (C5 fp64 89.2 -> 86.7 us).
+// (Measured and not kept: fetching the thread's 16 spectrum values into registers at kernel start (fp64, 206 VGPRs): 96.1 vs 89.7 us.)
+template <typename T, bool REALS>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
                                                                           const typename V2T<T>::type* __restrict__ S,
                                                                           const typename V2T<T>::type* __restrict__ tA,
                                                                           const typename V2T<T>::type* __restrict__ tB,
                                                                           const typename V2T<T>::type* __restrict__ twr,
-                                                                          const typename V2T<T>::type* __restrict__ S16,
+                                                                          const void* __restrict__ S16v,
                                                                           const typename V2T<T>::type* __restrict__ tB16) {
     using V = typename V2T<T>::type;
     constexpr int Mp = 4096, Q = Mp / 4, NT = 512;
@@ -754,7 +757,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
         const V ep = cconj(e), op = V{-o.x, o.y};
         const V wop = cmul(wc, op);
         const V Xp{(T)0.5 * (ep.x - wop.y), (T)0.5 * (ep.y + wop.x)};
-        const V Y = cmul(X, sp ? *sp : S[pos]), Yp = cmul(Xp, spp ? *spp : S[ppos]);
+        V Y, Yp;
+        if (REALS && sp) { Y = V{X.x * sp->x, X.y * sp->x}; Yp = V{Xp.x * spp->x, Xp.y * spp->x}; }      // real spectrum: two products each
+        else { Y = cmul(X, sp ? *sp : S[pos]); Yp = cmul(Xp, spp ? *spp : S[ppos]); }
         const V f = cadd(Y, cconj(Yp)), h = csub(Y, cconj(Yp));
         const V wh = cmul(wc, h);
         zs = V{(T)0.5 * (f.x - wh.y), (T)0.5 * (f.y + wh.x)};
@@ -769,7 +774,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
         for (int i = 0; i < Mp / NT; ++i) {
             const int p = tid + i * NT;                    // slot p holds frequency k' = rev16(p); its partner M' - 1 - k' sits at slot M' - 1 - p
             const V wt = tB16[p];
-            const V s1 = S16[(int64_t)kA * Mp + p], s2 = S16[(int64_t)kB * Mp + (Mp - 1 - p)];
+            V s1, s2;
+            if constexpr (REALS) {
+                s1 = V{((const T*)S16v)[(int64_t)kA * Mp + p], (T)0}; s2 = V{((const T*)S16v)[(int64_t)kB * Mp + (Mp - 1 - p)], (T)0};
+            } else {
+                s1 = ((const V*)S16v)[(int64_t)kA * Mp + p]; s2 = ((const V*)S16v)[(int64_t)kB * Mp + (Mp - 1 - p)];
+            }
             pair(rowA[P(p)], rowB[P(Mp - 1 - p)], false, kA, 0, 1, 1, &s1, &s2, &wt);
         }
     } else {
@@ -837,6 +847,7 @@ struct covgram_toeplitz {
     rocfft_plan bfwd = nullptr, binv = nullptr;   // 1024 contiguous length-Mp complex transforms, in place
     void* zbuf = nullptr;    // M complex
     void* sperm = nullptr;   // M + 1 complex: permuted half spectrum of the embedding / M, Nyquist bin last
+    bool sperm16_real = false; // sperm16 holds real parts only (symmetric matrix)
     void* sperm16 = nullptr; // M' = 4096: the same rows with their entries at the base-16 digit-reversed index (rowfft16_fused_kernel)
     void* tables = nullptr;  // tw1024 | tlo(2048) | thi(M/2048) | tA(1024) | tB(Mp)   (complex)
 };
@@ -928,8 +939,14 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
 #define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
                                         (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
         if (L == 6 && Tz->ctx->toeplitz_fused != 2)   // M' = 4096: radix-16 stages (option toeplitz_fused = 2 keeps the radix-4 kernel: A/B)
-            hipLaunchKernelGGL((rowfft16_fused_kernel<T>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
-                               (const V*)Tz->sperm16, (const V*)t.tB16);
+        {
+            if (Tz->sperm16_real)
+                hipLaunchKernelGGL((rowfft16_fused_kernel<T, true>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
+                                   (const void*)Tz->sperm16, (const V*)t.tB16);
+            else
+                hipLaunchKernelGGL((rowfft16_fused_kernel<T, false>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
+                                   (const void*)Tz->sperm16, (const V*)t.tB16);
+        }
         else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
 #undef CG_FUSED
@@ -1066,9 +1083,16 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
                                (const double2*)ft.tA, (const double2*)ft.tB, (double2*)T->sperm, 1.0 / (double)Mh);
         }
         if (T->Mp == 4096) {
-            TRY_HIP(hipMalloc(&T->sperm16, (size_t)tot * 2 * ts));
-            if (dtype == COVGRAM_F32) hipLaunchKernelGGL(permute16_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const float2*)T->sperm, (float2*)T->sperm16, tot);
-            else hipLaunchKernelGGL(permute16_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)T->sperm, (double2*)T->sperm16, tot);
+            T->sperm16_real = (vr == nullptr) && ctx->toeplitz_real_spectrum != 0;       // c_j = c_(N-j): the spectrum has no imaginary part
+            TRY_HIP(hipMalloc(&T->sperm16, (size_t)tot * (T->sperm16_real ? 1 : 2) * ts));
+            const dim3 pg((unsigned)((tot + 255) / 256));
+            if (dtype == COVGRAM_F32) {
+                if (T->sperm16_real) hipLaunchKernelGGL((permute16_kernel<float, true>), pg, dim3(256), 0, ctx->stream, (const float2*)T->sperm, T->sperm16, tot);
+                else hipLaunchKernelGGL((permute16_kernel<float, false>), pg, dim3(256), 0, ctx->stream, (const float2*)T->sperm, T->sperm16, tot);
+            } else {
+                if (T->sperm16_real) hipLaunchKernelGGL((permute16_kernel<double, true>), pg, dim3(256), 0, ctx->stream, (const double2*)T->sperm, T->sperm16, tot);
+                else hipLaunchKernelGGL((permute16_kernel<double, false>), pg, dim3(256), 0, ctx->stream, (const double2*)T->sperm, T->sperm16, tot);
+            }
         }
         TRY_HIP(hipStreamSynchronize(ctx->stream));
         (void)hipFree(T->rbuf); T->rbuf = nullptr;      // the fast path needs no real scratch buffer per MVM
