@@ -1,5 +1,5 @@
 """Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).
-usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
+usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -27,6 +27,10 @@ elif which == "grad":
     X = torch.from_numpy(rng.standard_normal((n, d))).cuda(); a = torch.from_numpy(rng.standard_normal(n * d)).cuda()
     G = cg.gramian(cg.GradientKernel(cg.EQ()), X); y = torch.empty(n * d, dtype=torch.float64, device="cuda")
     for _ in range(K): G.mul_(y, a)
+elif which == "toeplitz32":
+    n = 1 << 22
+    T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n, dtype=torch.float32)); a = torch.randn(n, dtype=torch.float32, device="cuda"); y = torch.empty_like(a)
+    for _ in range(K): T.mul_(y, a)
 elif which in ("toeplitz", "toeplitz4"):          # toeplitz4: the radix-4 fused row kernel (round 1) instead of the radix-16 one
     if which == "toeplitz4": cg.set_option("toeplitz_fused", 2)
     n = 1 << 22
