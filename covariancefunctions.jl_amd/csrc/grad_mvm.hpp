@@ -182,7 +182,8 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) voi
             b0 = cg_fma(v, a0, cg_fma(vg_b * k1, t, b0));
         } else {
             phi_derivs<FAM, T, POW>(s, kp, k1, k2);
-            c2 = ISO ? (T)2 * k2 * t : k2 * t;
+            if constexpr (FAM == COVGRAM_EQ && !POW) c2 = -k1 * t;       // EQ: 2 k2 = -k1 (both exact scalings of the same exponential)
+            else c2 = ISO ? (T)2 * k2 * t : k2 * t;
         }
         if constexpr (EXPD) { csum += c2; c2 = -c2; }            // b += k1 a - c2 y' here, + c2 x' through csum
         // ---- sweep 2: b += k1 a + c2 r   (or k1 a + c2 y) --------------------------------------------------------

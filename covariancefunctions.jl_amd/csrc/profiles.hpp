@@ -57,10 +57,39 @@ __device__ __forceinline__ T ipow(T v, int q) {
 template <int FAM, typename T, bool FOLDED>
 struct Phi;
 
+// exp(-s/2) in fp64 for the EQ profile of the gradient and direct-difference kernels (s >= 0; NaN propagates, s = inf gives 0).  The library exp2 costs 34
+// instructions here (hipcc expands each Horner step of its polynomial into v_mov_b64 + v_fmac_f64, range checks on both sides,
+// and the factor kp.c0 is re-read from the kernarg segment inside the column loop — an s_load whose lgkmcnt(0) also cuts the
+// software-pipelined record stream short); this one is 22: x = s (-log2(e)/2) as a literal, n = rint(x), y = (x - n) ln 2,
+// a degree-11 polynomial for exp(y) on |y| <= ln(2)/2 (interpolation at Chebyshev nodes computed with mpmath, max relative
+// error 1.7e-17 before rounding; c0 = c1 = 1 exactly), ldexp, one underflow select.
+__device__ __forceinline__ double eq_exp_neg_half(double s) {
+    const double x = s * -0.72134752044448170368;
+    const double n = __builtin_rint(x);
+    const double y = (x - n) * 0.69314718055994530942;
+    // a Horner step as ONE three-address v_fma_f64 (the compiler's two-address form copies the coefficient first)
+    auto step = [](double q, double yy, double c) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(yy), "v"(c)); return r; };
+    double p = 0x1.af631d0059becp-26;
+    p = __builtin_fma(p, y, 0x1.28b4057f44145p-22);
+    p = step(p, y, 0x1.71ddf5749d126p-19);
+    p = step(p, y, 0x1.a01991ac8730ap-16);
+    p = step(p, y, 0x1.a01a01b14378fp-13);
+    p = step(p, y, 0x1.6c16c187fbe02p-10);
+    p = step(p, y, 0x1.111111110f225p-7);
+    p = step(p, y, 0x1.555555554f0cfp-5);
+    p = step(p, y, 0x1.555555555555ap-3);
+    p = step(p, y, 0x1.0000000000011p-1);
+    p = __builtin_fma(p, y, 1.0);
+    p = __builtin_fma(p, y, 1.0);
+    const double e = __builtin_ldexp(p, (int)n);
+    return x < -1100.0 ? 0.0 : e;
+}
+
 template <typename T, bool FOLDED>
 struct Phi<COVGRAM_EQ, T, FOLDED> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         if constexpr (FOLDED) return cg_exp2(-s);       // one v_exp_f32 with a free neg modifier
+        else if constexpr (sizeof(T) == 8) return eq_exp_neg_half(s);
         else return cg_exp2(s * kp.c0);                 // c0 = -log2(e)/2
     }
 };
@@ -327,7 +356,9 @@ struct DPhi;
 template <typename T>
 struct DPhi<COVGRAM_EQ, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
-        v = cg_exp2(s * kp.c0); d1 = (T)-0.5 * v; d2 = (T)0.25 * v;
+        if constexpr (sizeof(T) == 8) v = eq_exp_neg_half(s);
+        else v = cg_exp2(s * kp.c0);
+        d1 = (T)-0.5 * v; d2 = (T)0.25 * v;
     }
 };
 template <typename T>
