@@ -46,10 +46,16 @@ struct GradChunk {
 
 // Register budget: the state is 2 (or 3 with KEEP_R) d-vectors; ask the allocator for the occupancy that state allows
 // with ~40 VGPRs of temporaries (e.g. fp64 d = 32 without r: 128 + 40 = 168 -> 3 waves per SIMD instead of 2).
-template <typename T, int D, bool KEEP_R>
+// fp64 profiles built on the library's log / pow (RQ, gamma-exponential) keep ~20 polynomial coefficients live: with 40
+// registers of temporaries they spilled to scratch inside the column loop (RQ at the C4 shape: 6.0 ms, 40 VGPRs spilled,
+// every reload a serial vmcnt(0) wait) — those families get 110, i.e. one wave per SIMD less and no spills.
+template <typename T, int FAM> constexpr int grad_temp_regs() {
+    return (sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP)) ? 110 : 40;
+}
+template <typename T, int D, bool KEEP_R, int FAM = COVGRAM_EQ>
 constexpr int grad_min_waves() {
     const int state = (KEEP_R ? 3 : 2) * D * (int)(sizeof(T) / 4);
-    const int w = 512 / (state + 40);
+    const int w = 512 / (state + grad_temp_regs<T, FAM>());
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 
@@ -60,7 +66,7 @@ constexpr int grad_min_waves() {
 // i.e. one extra FMA on c2 and one scalar accumulator; a0 streams from A0 (one scalar load per column, prefetched with
 // the column's first chunk), vg_c = -+1/gamma, vg_b = -2 gamma | gamma, and b0 is scaled by alpha0 = alpha * scale.
 template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG, bool EXPD = false>
-__global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
+__global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
                                                                 const T* __restrict__ P, const T* __restrict__ P2,
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
                                                                 int64_t jchunk, T alpha, T beta, int32_t final_store,
