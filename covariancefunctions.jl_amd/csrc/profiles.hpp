@@ -57,16 +57,18 @@ __device__ __forceinline__ T ipow(T v, int q) {
 template <int FAM, typename T, bool FOLDED>
 struct Phi;
 
-// exp(-s/2) in fp64 for the EQ profile of the gradient and direct-difference kernels (s >= 0; NaN propagates, s = inf gives 0).  The library exp2 costs 34
-// instructions here (hipcc expands each Horner step of its polynomial into v_mov_b64 + v_fmac_f64, range checks on both sides,
-// and the factor kp.c0 is re-read from the kernarg segment inside the column loop — an s_load whose lgkmcnt(0) also cuts the
-// software-pipelined record stream short); this one is 22: x = s (-log2(e)/2) as a literal, n = rint(x), y = (x - n) ln 2,
-// a degree-11 polynomial for exp(y) on |y| <= ln(2)/2 (interpolation at Chebyshev nodes computed with mpmath, max relative
-// error 1.7e-17 before rounding; c0 = c1 = 1 exactly), ldexp, one underflow select.
-__device__ __forceinline__ double eq_exp_neg_half(double s) {
-    const double x = s * -0.72134752044448170368;
+// exp2(s c) in fp64 for s >= 0 and a negative constant c = chi + clo (NaN propagates, s = inf gives 0): exp(-s/2) of the EQ
+// profile and exp(-r) of the Matern / exponential profiles in the gradient and direct-difference kernels.  The library exp /
+// exp2 cost 34 instructions there (hipcc expands each Horner step of their polynomial into v_mov_b64 + v_fmac_f64, both ends of
+// the range are checked, and in the gradient kernel the factor kp.c0 was re-read from the kernarg segment inside the column
+// loop — an s_load whose lgkmcnt(0) also cut the software-pipelined record stream short); this is 23: n = rint(s chi),
+// r = fma(s, chi, -n) + s clo (the product never rounded), y = r ln 2, a degree-11 polynomial for exp(y) on |y| <= ln(2)/2
+// (interpolation at Chebyshev nodes computed with mpmath, max relative error 1.7e-17 before rounding; c0 = c1 = 1 exactly) as
+// three-address v_fma_f64, ldexp, one underflow select.
+__device__ __forceinline__ double exp2_scaled_nonpos(double s, double chi, double clo) {
+    const double x = s * chi;
     const double n = __builtin_rint(x);
-    const double y = (x - n) * 0.69314718055994530942;
+    const double y = __builtin_fma(s, clo, __builtin_fma(s, chi, -n)) * 0.69314718055994530942;
     // a Horner step as ONE three-address v_fma_f64 (the compiler's two-address form copies the coefficient first)
     auto step = [](double q, double yy, double c) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(yy), "v"(c)); return r; };
     double p = 0x1.af631d0059becp-26;
@@ -84,6 +86,13 @@ __device__ __forceinline__ double eq_exp_neg_half(double s) {
     const double e = __builtin_ldexp(p, (int)n);
     return x < -1100.0 ? 0.0 : e;
 }
+__device__ __forceinline__ double eq_exp_neg_half(double s) { return exp2_scaled_nonpos(s, -0x1.71547652b82fep-1, -0x1.777d0ffda0d24p-57); }   // -log2(e)/2
+// exp(-t/2), t >= 0
+__device__ __forceinline__ float cg_exp_neg_half(float t) { return cg_exp(-0.5f * t); }
+__device__ __forceinline__ double cg_exp_neg_half(double t) { return eq_exp_neg_half(t); }
+// exp(-r), r >= 0
+__device__ __forceinline__ float cg_exp_neg(float r) { return cg_exp(-r); }
+__device__ __forceinline__ double cg_exp_neg(double r) { return exp2_scaled_nonpos(r, -0x1.71547652b82fep+0, -0x1.777d0ffda0d24p-56); }      // -log2(e)
 
 template <typename T, bool FOLDED>
 struct Phi<COVGRAM_EQ, T, FOLDED> {
@@ -95,7 +104,7 @@ struct Phi<COVGRAM_EQ, T, FOLDED> {
 };
 template <typename T, bool F>
 struct Phi<COVGRAM_EXP, T, F> {
-    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(-cg_sqrt(s)); }
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(-cg_sqrt(s)); }   // (cg_exp_neg measured 6 % slower in the dense fp64 kernel, whose constants sit in SGPRs)
 };
 template <typename T, bool F>
 struct Phi<COVGRAM_RQ, T, F> {
@@ -109,7 +118,7 @@ struct Phi<COVGRAM_GAMMAEXP, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         // s^(gamma/2); s == 0 -> 0 (gamma > 0) — log2(0) = -inf, exp2(-inf) = 0
         T t = (kp.param == (T)0) ? (T)1 : cg_pow(s, kp.param);
-        return cg_exp((T)-0.5 * t);
+        return cg_exp_neg_half(t);
     }
 };
 template <typename T, bool F>
@@ -364,7 +373,7 @@ struct DPhi<COVGRAM_EQ, T> {
 template <typename T>
 struct DPhi<COVGRAM_EXP, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>&, T& v, T& d1, T& d2) {
-        T rt = cg_sqrt(s); v = cg_exp(-rt);
+        T rt = cg_sqrt(s); v = cg_exp_neg(rt);
         T ir = cg_rcp(rt);                               // s == 0: inf, like the reference's ForwardDiff
         d1 = (T)-0.5 * v * ir;
         d2 = (T)0.25 * v * (ir * ir + ir * ir * ir);
@@ -387,7 +396,7 @@ struct DPhi<COVGRAM_GAMMAEXP, T> {
         T g = kp.param;                                   // gamma / 2
         T sg = (g == (T)0) ? (T)1 : cg_pow(s, g);
         T is = cg_rcp(s);
-        v = cg_exp((T)-0.5 * sg);
+        v = cg_exp_neg_half(sg);
         T hg = (T)0.5 * g;
         d1 = -hg * sg * is * v;
         d2 = v * (hg * hg * sg * sg * is * is - hg * (g - (T)1) * sg * is * is);
@@ -411,7 +420,7 @@ struct DPhi<COVGRAM_MATERNP, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
         const int p = kp.p;
         T r = cg_sqrt(kp.mp_c * s);
-        T e = cg_exp(-r);
+        T e = cg_exp_neg(r);
         if (p == 0) {                                     // Exp profile (singular at 0)
             T ir = cg_rcp(r);
             v = e;
