@@ -1021,7 +1021,8 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
-        choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 64);
+        const int gthreads = grad_block_threads((int)ts, D, hk.tu_family);          // 64 or 256 threads per workgroup (grad_mvm.hpp)
+        choose_split(ctx, (n + gthreads - 1) / gthreads, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 64 * 64 / gthreads);
         GradArgs ga;
         ga.C = Cn;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;

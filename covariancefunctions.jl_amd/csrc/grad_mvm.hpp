@@ -36,7 +36,17 @@
 
 namespace covgram {
 
-constexpr int GRAD_THREADS = 64;   // one wave per workgroup: no LDS, no barriers — finer tail balance, smaller partial slabs
+constexpr int GRAD_THREADS = 256;   // largest workgroup; rows are padded to this
+// Waves per workgroup: the waves of a workgroup take consecutive 64-row blocks and walk the SAME column chunk from the same
+// start, so their record lines meet in the scalar cache (no LDS, no barrier).  Four waves per workgroup measured 2-3 % faster
+// than one wherever the kernel runs at >= 3 waves per SIMD (C4 1.829 -> 1.789 ms, d = 48 -3 %, value-gradient -2.7 %; d <= 8
+// neutral) and 2 % slower on the two-waves-per-SIMD kernels (wide fp64 RQ / gamma-exponential), which keep one
+// (tools/c4_lib_ab.py, profiles/r02_c4_exp_ab.txt).
+inline int grad_block_threads(int elem_size, int D, int fam) {
+    const int state = 2 * D * (elem_size / 4);
+    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP)) ? 110 : 40;
+    return (512 / (state + temps) >= 3) ? GRAD_THREADS : 64;
+}
 
 template <typename T, int DC>
 struct GradChunk {
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
     using Chunk = GradChunk<T, DC>;
 
     const int tid = threadIdx.x;
-    int64_t row = (int64_t)blockIdx.x * GRAD_THREADS + tid;
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + tid;
     const bool live = row < n;
     if (!live) row = n - 1;
     const int64_t j0 = (int64_t)blockIdx.y * jchunk;
@@ -313,7 +323,8 @@ __global__ __launch_bounds__(256) void grad_pack_extra_kernel(const T* __restric
 template <typename T, int FAM, int D>
 static int launch_grad_one(const GradArgs& a) {
     const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
-    dim3 grid((unsigned)((a.n + GRAD_THREADS - 1) / GRAD_THREADS), (unsigned)a.jsplit);
+    const int threads = grad_block_threads((int)sizeof(T), D, FAM);
+    dim3 grid((unsigned)((a.n + threads - 1) / threads), (unsigned)a.jsplit);
     const int final_store = (a.jsplit == 1) ? 1 : 0;
     // keep r = x - y in registers (4 flops per dim and block) while 3 d-vectors of state leave >= 2 waves per SIMD,
     // else recompute it in the second sweep (5 flops per dim, 2 d-vectors of state)
@@ -327,14 +338,14 @@ static int launch_grad_one(const GradArgs& a) {
     const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
     constexpr bool POWT = !fam_is_expr<FAM>;   // composites apply Power per factor: no POW = true instantiation
 #define CG_GRAD_LAUNCH(KEEPV, POWV, VGV)                                                                                                \
-    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d,  \
+    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(threads), 0, a.stream, (const T*)a.X, a.n, a.d,  \
                        (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,             \
                        (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)nullptr)
     bool done = false;
     if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
         if (a.expd) {   // expanded form: 4 fma per dimension and pair (header)
 #define CG_GRAD_LAUNCH_X(POWV, VGV)                                                                                                     \
-            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false, POWV, VGV, true>), grid, dim3(GRAD_THREADS), 0, a.stream, (const T*)a.X, a.n, a.d, \
+            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false, POWV, VGV, true>), grid, dim3(threads), 0, a.stream, (const T*)a.X, a.n, a.d, \
                                (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,     \
                                (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)a.Ex)
             if (a.vg) { if (pow) CG_GRAD_LAUNCH_X(POWT, true); else CG_GRAD_LAUNCH_X(false, true); }
