@@ -1022,7 +1022,28 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
         const int gthreads = grad_block_threads((int)ts, D, hk.tu_family);          // 64 or 256 threads per workgroup (grad_mvm.hpp)
-        choose_split(ctx, (n + gthreads - 1) / gthreads, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 64 * 64 / gthreads);
+        // Column split: about 64 waves per CU over the launch (round 1's sweep), then (round 2, tools/c4_jsplit_sweep.py)
+        //  * capped so that the partial slabs (split x n x d results, written here and read back by the reduction) stay inside the
+        //    256 MB Infinity Cache — C4 at 64 splits writes 268 MB, d = 48 403 MB: 3.86 ms against 3.61 at 48 splits —
+        //  * and, when that cap binds, snapped DOWN to a whole number of rounds of resident workgroups if one lies within reach (the
+        //    waves of the EQ kernel all take the same time, so a ragged last round idles most of the chip: C4 at 64 row workgroups x
+        //    {36, 42, 48, 54, 60} splits = {3.0, 3.5, 4.0, 4.5, 5.0} rounds: 1.744, 1.853, 1.748, 1.809, 1.770 ms).
+        //  Old and new library alternating on one box: C4 1.79 -> 1.77 ms, value-gradient -2 %, d = 48 3.85 -> 3.65; the heavier
+        //  profiles at the C4 shape lose 1.5 % (MaternP(2) 2.33 -> 2.37, RQ 3.60 -> 3.66): their slab is the same 268 MB but a
+        //  smaller share of a longer kernel.
+        const int64_t growwgs = (n + gthreads - 1) / gthreads;
+        const int64_t gslots = (int64_t)ctx->num_cus * 4 * grad_waves_per_simd((int)ts, D, hk.tu_family) / (gthreads / 64);
+        int64_t gsplit = std::max<int64_t>(1, ((int64_t)ctx->num_cus * 64 * 64 / gthreads + growwgs - 1) / growwgs);
+        const int64_t gcap = std::max<int64_t>(1, (int64_t)(256.0e6 / ((double)npad * (D + vg) * ts)));
+        if (ctx->jsplit <= 0 && ctx->target_wgs <= 0 && gsplit > gcap) {
+            gsplit = gcap;
+            for (int64_t js = gsplit; js >= std::max<int64_t>(1, gsplit / 2); --js) {
+                const double rounds = (double)(js * growwgs) / (double)gslots;
+                const double ragged = std::ceil(rounds) - rounds;
+                if (rounds >= 1.0 && ragged <= 0.04) { gsplit = js; break; }
+            }
+        }
+        choose_split(ctx, growwgs, m, 8, &jchunk, &jsplit, gsplit * growwgs);
         GradArgs ga;
         ga.C = Cn;
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;

@@ -42,6 +42,12 @@ constexpr int GRAD_THREADS = 256;   // largest workgroup; rows are padded to thi
 // than one wherever the kernel runs at >= 3 waves per SIMD (C4 1.829 -> 1.789 ms, d = 48 -3 %, value-gradient -2.7 %; d <= 8
 // neutral) and 2 % slower on the two-waves-per-SIMD kernels (wide fp64 RQ / gamma-exponential), which keep one
 // (tools/c4_lib_ab.py, profiles/r02_c4_exp_ab.txt).
+inline int grad_waves_per_simd(int elem_size, int D, int fam) {
+    const int state = 2 * D * (elem_size / 4);
+    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP)) ? 110 : 40;
+    const int w = 512 / (state + temps);
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
 inline int grad_block_threads(int elem_size, int D, int fam) {
     const int state = 2 * D * (elem_size / 4);
     const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP)) ? 110 : 40;

@@ -6,7 +6,8 @@ import covgram as cg
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 out = []
 for (n, d, kern, vg) in ((16384, 32, cg.EQ(), 0), (16384, 32, cg.EQ(), 1), (32768, 8, cg.EQ(), 0), (16384, 48, cg.EQ(), 0), (65536, 3, cg.EQ(), 0), (16384, 32, cg.RQ(1.5), 0),
-                          (16384, 32, cg.MaternP(2), 0), (16384, 32, cg.Exp(), 0), (16384, 32, cg.GammaExponential(1.3), 0)):
+                          (16384, 32, cg.MaternP(2), 0), (16384, 32, cg.Exp(), 0), (16384, 32, cg.GammaExponential(1.3), 0),
+                          (20000, 32, cg.EQ(), 0), (4096, 32, cg.EQ(), 0), (50000, 8, cg.EQ(), 0), (8192, 16, cg.EQ(), 0)):
     rng = np.random.default_rng(0xC0F + 3)
     X = torch.from_numpy(rng.standard_normal((n, d))).cuda(); a = torch.from_numpy(rng.standard_normal(n * (d + vg))).cuda()
     K = cg.gramian((cg.ValueGradientKernel if vg else cg.GradientKernel)(kern), X); y = torch.empty_like(a)
