@@ -52,6 +52,10 @@ def cpu_baseline(X: np.ndarray, a: np.ndarray, budget_s: float = 12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes
     import c_oracle
+    # the OpenMP workers must SLEEP after the baseline's parallel regions: spinning on all host cores (libgomp's default wait
+    # policy) they delay this process's kernel launches afterwards (seen as 0.15 ms gaps per step in the symmetric variant's loop)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     out_dir = None
     # under a profiler (rocprofv3 preloads its library into every child) nothing is spawned: the prebuilt object is loaded in-process
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
