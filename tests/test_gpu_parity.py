@@ -1262,6 +1262,13 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
         cg.mul_(yd, G, ad, 0.3, -1.1)
         cg.set_option("toeplitz_colfft", 16)
         assert relerr(yd.cpu().numpy(), 0.3 * ref - 1.1 * y0) <= tol and relerr(yd.cpu().numpy(), out[1]) <= tol
+        # the symmetric matrix keeps the row kernel's spectrum copy as reals; a handle created with the complex copy agrees
+        cg.set_option("toeplitz_real_spectrum", 0)
+        Gc = cg.gramian(cg.Exp(), x)
+        cg.set_option("toeplitz_real_spectrum", 1)
+        yd = torch.from_numpy(y0.copy()).cuda()
+        cg.mul_(yd, Gc, ad, 0.3, -1.1)
+        assert relerr(yd.cpu().numpy(), 0.3 * ref - 1.1 * y0) <= tol and relerr(yd.cpu().numpy(), out[1]) <= tol
         b = (G @ ad).cpu().numpy()
         rows = rng.choice(n, 8, replace=False)
         dense_rows = np.array([np.dot(vc[np.abs(i - np.arange(n))], a.astype(np.float64)) for i in rows])
@@ -1273,6 +1280,7 @@ def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
     finally:
         cg.set_option("toeplitz_fused", 1)
         cg.set_option("toeplitz_colfft", 16)
+        cg.set_option("toeplitz_real_spectrum", 1)
 
 
 def test_matern_real_nu_golden(cg, oracle):
@@ -1460,3 +1468,34 @@ def test_isotropic_paths_are_translation_invariant(cg, oracle, shift):
         got = (cg.gramian(cg.ValueGradientKernel(kern), Xd) @ torch.from_numpy(Av).cuda().reshape(-1)).cpu().numpy()
         want = oracle.valgrad_mul(None, ok, X, X, Av.reshape(-1), dtype=np.float32)
         assert relerr(got, want) <= 1e-5, (shift, d, relerr(got, want))
+
+
+def test_fp64_exponential_entrywise(cg, oracle):
+    """The library's own fp64 exponential (csrc/profiles.hpp exp2_scaled_nonpos: EQ values everywhere, Matern / exponential /
+    gamma-exponential derivative profiles) ENTRY BY ENTRY against numpy over the whole range of its argument: Matrix(G) of EQ on
+    collinear points with squared distances from 0 to 3000 (exp(-s/2) down to the denormals and 0), and the gradient MVM of the
+    exponential profile on one pair per distance.  Relative error <= 2 ulp where the value is normal, absolute below."""
+    m = 6000
+    s = np.concatenate([np.linspace(0.0, 40.0, 2000), np.linspace(40.0, 1400.0, 2000), np.linspace(1400.0, 3000.0, 2000)])
+    y = np.zeros((m, 2)); y[:, 0] = np.sqrt(s)
+    x = np.zeros((1, 2))
+    G = cg.gramian(cg.EQ(), torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    got = G.to_dense().cpu().numpy()[0]
+    s_exact = y[:, 0] ** 2                                      # what the kernel sees (direct differences of these coordinates)
+    ref = np.exp(-0.5 * s_exact)
+    normal = ref > 1e-300
+    assert np.max(np.abs(got[normal] / ref[normal] - 1.0)) <= 4.5e-16, np.max(np.abs(got[normal] / ref[normal] - 1.0))
+    assert np.all(np.abs(got[~normal] - ref[~normal]) <= 1e-300) and got[-1] == 0.0
+    assert got[0] == 1.0 and not np.any(np.isnan(got))
+    # NaN in, NaN out; an infinite distance gives exactly 0
+    yb = y[:4].copy(); yb[1, 0] = np.nan; yb[2, 0] = np.inf
+    gb = cg.gramian(cg.EQ(), torch.from_numpy(x).cuda(), torch.from_numpy(yb).cuda()).to_dense().cpu().numpy()[0]
+    assert gb[0] == 1.0 and np.isnan(gb[1]) and gb[2] == 0.0
+    # exp(-r) of the exponential profile through the gradient kernel (d = 2, one row against every column, a = e_1 per column)
+    r = np.sqrt(s_exact[1:])                                    # r = 0 is singular for this profile (src/stationary.jl:56-60)
+    K = cg.gramian(cg.GradientKernel(cg.Exp()), torch.from_numpy(x).cuda(), torch.from_numpy(y[1:]).cuda())
+    a = np.zeros((m - 1, 2)); a[:, 1] = 1.0                     # picks column 2 of each block: r r^T has no (1,2) entry here
+    out = (K @ torch.from_numpy(a.reshape(-1)).cuda()).cpu().numpy()
+    ko = oracle.Kernel(oracle.EXP)
+    ref_g = oracle.grad_mul(np.zeros(2), ko, x, y[1:], a.reshape(-1), 1.0, 0.0, np.float64)
+    assert relerr(out, ref_g) <= 1e-14, relerr(out, ref_g)
