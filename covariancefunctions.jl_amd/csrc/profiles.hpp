@@ -99,7 +99,8 @@ struct Phi<COVGRAM_EQ, T, FOLDED> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         if constexpr (FOLDED) return cg_exp2(-s);       // one v_exp_f32 with a free neg modifier
         else if constexpr (sizeof(T) == 8) return eq_exp_neg_half(s);
-        else return cg_exp2(s * kp.c0);                 // c0 = -log2(e)/2
+        else return cg_exp2(s * (T)-0.72134752044448170368);   // -log2(e)/2 as a literal: kp.c0 holds the same value, but a kernarg field can be
+                                                                   // re-read inside a register-starved loop (grad_mvm.hpp)
     }
 };
 template <typename T, bool F>
@@ -366,7 +367,7 @@ template <typename T>
 struct DPhi<COVGRAM_EQ, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
         if constexpr (sizeof(T) == 8) v = eq_exp_neg_half(s);
-        else v = cg_exp2(s * kp.c0);
+        else v = cg_exp2(s * (T)-0.72134752044448170368);
         d1 = (T)-0.5 * v; d2 = (T)0.25 * v;
     }
 };
