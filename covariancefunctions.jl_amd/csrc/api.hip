@@ -1001,9 +1001,13 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         // expanded form (grad_mvm.hpp): fp64 isotropic simple profiles whose pre-scaled clouds lie within the radius gate
         const bool expd = iso && dtype == COVGRAM_F64 && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 &&
                           (ctx->grad_expand == 1 ||
-                           // measured (tools/c4_expand_ab.py, profiles/r02_c4_expand_ab.txt): pays from d = 8 on the cheap profiles (C4 0.87x,
-                           // d = 8 0.96x); d = 3 +5 % and MaternP(2) +3 % slower, so those keep direct differences
-                           (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERNP && hk.tu_family != COVGRAM_MATERN &&
+                           // measured (tools/c4_expand_ab.py, profiles/r02_c4_expand_ab.txt): pays from d = 8 (C4 0.86x, d = 8 0.95x,
+                           // d = 3 +4 %); MaternP(p >= 1) 0.89x since its exp(-r) is the library's own (it was +3 % with the
+                           // 34-instruction one).  Never by default for the profiles that are singular at s = 0 (exponential,
+                           // gamma-exponential, MaternP(0)): their diagonal blocks are NaN in the reference (inf * 0), which the
+                           // exact zero of a direct difference reproduces and the rounded zero of the expanded form would not
+                           (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
+                            hk.tu_family != COVGRAM_GAMMAEXP && !(hk.tu_family == COVGRAM_MATERNP && hk.k.p == 0) &&
                             hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
         rc = ws_reserve(ctx, 0, (size_t)(m + 1) * (2 * D + vg + (expd ? 2 : 0)) * ts, &P); if (rc) return rc;
         void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * 2 * D * ts) : nullptr;

@@ -162,7 +162,7 @@ def test_gradient_expanded_form_fp64(cg, oracle, d):
             for ex in (0, 1, -1):
                 cg.set_option("grad_expand", ex)
                 yd = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yd, G, torch.from_numpy(a).cuda(), 0.7, -1.1)
-                auto = d >= 7 and not isinstance(k, cg.Lengthscale)           # the automatic rule: padded d >= 8, not MaternP
+                auto = d >= 7                                                 # the automatic rule: padded d >= 8 (singular profiles: below)
                 assert cg.get_info("last_grad_expand") == (0 if ex == 0 else (1 if ex == 1 else int(auto))), (ex, d)
                 outs[ex] = yd.cpu().numpy()
                 assert relerr(outs[ex], ref) <= 1e-12, (type(k).__name__, d, ex, relerr(outs[ex], ref))
@@ -183,6 +183,12 @@ def test_gradient_expanded_form_fp64(cg, oracle, d):
         bs = (Gs @ torch.from_numpy(a).cuda()).cpu().numpy()
         assert cg.get_info("last_grad_expand") == (1 if d >= 7 else 0)
         assert relerr(bs, oracle.grad_mul(None, oracle.Kernel(oracle.EQ), X + 1.0e4, Y + 1.0e4, a)) <= 1e-11
+        # profiles that are singular at s = 0 keep direct differences: the NaN diagonal blocks of gramian(GradientKernel(Exp), x)
+        # (inf * 0 in the reference, src/gradient.jl:86-92 with ForwardDiff's derivatives of exp(-sqrt(s)) at 0) stay NaN
+        for ks in (cg.Exp(), cg.GammaExponential(1.3), cg.MaternP(0)):
+            Gx = cg.gramian(cg.GradientKernel(ks), Xd)
+            bx = (Gx @ torch.from_numpy(rng.standard_normal(n * d)).cuda()).cpu().numpy()
+            assert cg.get_info("last_grad_expand") == 0 and np.all(np.isnan(bx)), type(ks).__name__
         # fp32 and dot-product kernels never take it
         (cg.gramian(cg.GradientKernel(cg.EQ()), Xd.float(), Yd.float()) @ torch.from_numpy(a).cuda().float()); assert cg.get_info("last_grad_expand") == 0
         (cg.gramian(cg.GradientKernel(cg.Dot() ** 2), Xd, Yd) @ torch.from_numpy(a).cuda()); assert cg.get_info("last_grad_expand") == 0
