@@ -156,6 +156,9 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
     const T* __restrict__ exq = EXPD ? Ex + 2 * j0 : nullptr;
     [[maybe_unused]] T eny = (T)0, eya = (T)0, enyn = (T)0, eyan = (T)0;
     if constexpr (EXPD) { eny = exq[0]; eya = exq[1]; }
+    // the column loop as a generic lambda: MaternP kernels run it with the order fixed at compile time when it is 2 (nu = 5/2)
+    auto columns = [&](auto pfix_) {
+    constexpr int PFIX = decltype(pfix_)::value;
     for (int jj = 0; jj < cnt; ++jj, p += 2 * D, q += 2 * D) {
         T s = (T)0, t = (T)0;
         T r[(ISO && KEEP_R) ? D : 1];
@@ -199,11 +202,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
         T k1, k2, c2;
         if constexpr (VG) {
             T v;
-            phi_jet<FAM, T, POW>(s, kp, v, k1, k2);
+            phi_jet<FAM, T, POW, PFIX>(s, kp, v, k1, k2);
             c2 = cg_fma(vg_c * k1, a0, ISO ? (T)2 * k2 * t : k2 * t);
             b0 = cg_fma(v, a0, cg_fma(vg_b * k1, t, b0));
         } else {
-            phi_derivs<FAM, T, POW>(s, kp, k1, k2);
+            phi_derivs<FAM, T, POW, PFIX>(s, kp, k1, k2);
             if constexpr (FAM == COVGRAM_EQ && !POW) c2 = -k1 * t;       // EQ: 2 k2 = -k1 (both exact scalings of the same exponential)
             else c2 = ISO ? (T)2 * k2 * t : k2 * t;
         }
@@ -241,6 +244,13 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
         }
         if constexpr (VG) a0 = a0n;
         if constexpr (EXPD) { eny = enyn; eya = eyan; }
+    }
+    };
+    if constexpr (FAM == COVGRAM_MATERNP) {
+        if (kp.p == 2) columns(std::integral_constant<int, 2>());
+        else columns(std::integral_constant<int, -1>());
+    } else {
+        columns(std::integral_constant<int, -1>());
     }
     if constexpr (EXPD) {
 #pragma unroll

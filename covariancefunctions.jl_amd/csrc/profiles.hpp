@@ -418,8 +418,11 @@ struct DPhi<COVGRAM_IMQ, T> {
 };
 template <typename T>
 struct DPhi<COVGRAM_MATERNP, T> {
+    // PFIX >= 0: the order is a compile-time constant (the callers branch on kp.p ONCE, outside their column loops, so that the
+    // loop they run carries only that order's code and registers)
+    template <int PFIX = -1>
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
-        const int p = kp.p;
+        const int p = PFIX >= 0 ? PFIX : kp.p;
         T r = cg_sqrt(kp.mp_c * s);
         T e = cg_exp_neg(r);
         if (p == 0) {                                     // Exp profile (singular at 0)
@@ -647,15 +650,16 @@ struct DPhi<FAM_EXPR_DOT, T> {
 
 // POW = false compiles the Power chain rule away: the gradient kernel's software pipeline needs the derivative
 // evaluation to stay ONE basic block (a branch lets hipcc sink the prefetch loads past it, to their first use).
-template <int FAM, typename T, bool POW>
+template <int FAM, typename T, bool POW, int PFIX = -1>
 __device__ __forceinline__ void phi_jet(T s, const typename ParamsOf<FAM, T>::type& kp, T& v, T& d1, T& d2) {
-    DPhi<FAM, T>::eval(s, kp, v, d1, d2);
+    if constexpr (FAM == COVGRAM_MATERNP) DPhi<FAM, T>::template eval<PFIX>(s, kp, v, d1, d2);
+    else DPhi<FAM, T>::eval(s, kp, v, d1, d2);
     if constexpr (POW) power_jet(kp.power, v, d1, d2);
 }
-template <int FAM, typename T, bool POW>
+template <int FAM, typename T, bool POW, int PFIX = -1>
 __device__ __forceinline__ void phi_derivs(T s, const typename ParamsOf<FAM, T>::type& kp, T& d1, T& d2) {
     T v;
-    phi_jet<FAM, T, POW>(s, kp, v, d1, d2);
+    phi_jet<FAM, T, POW, PFIX>(s, kp, v, d1, d2);
 }
 
 }  // namespace covgram
