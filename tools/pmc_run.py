@@ -1,5 +1,5 @@
 """Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).
-usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
+usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32|c1 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -26,6 +26,11 @@ elif which == "grad":
     n, d = 16384, 32
     X = torch.from_numpy(rng.standard_normal((n, d))).cuda(); a = torch.from_numpy(rng.standard_normal(n * d)).cuda()
     G = cg.gramian(cg.GradientKernel(cg.EQ()), X); y = torch.empty(n * d, dtype=torch.float64, device="cuda")
+    for _ in range(K): G.mul_(y, a)
+elif which == "c1":
+    n = 4096
+    X = torch.from_numpy(rng.standard_normal((n, 3))).cuda(); a = torch.from_numpy(rng.standard_normal(n)).cuda()
+    G = cg.gramian(cg.MaternP(2), X); y = torch.empty(n, dtype=torch.float64, device="cuda")
     for _ in range(K): G.mul_(y, a)
 elif which == "toeplitz32":
     n = 1 << 22
