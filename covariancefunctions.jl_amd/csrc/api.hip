@@ -1038,6 +1038,8 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         const int64_t growwgs = (n + gthreads - 1) / gthreads;
         const int64_t gslots = (int64_t)ctx->num_cus * 4 * grad_waves_per_simd((int)ts, D, hk.tu_family) / (gthreads / 64);
         int64_t gsplit = std::max<int64_t>(1, ((int64_t)ctx->num_cus * 64 * 64 / gthreads + growwgs - 1) / growwgs);
+        gsplit = std::min(gsplit, std::max<int64_t>(1, m / 64));   // >= 64 columns per workgroup: below that its prologue and slab rows dominate
+                                                                    // (tools/c4_jsplit_sweep.py small: n = 4096, d = 8: 16-column chunks 0.109 ms, 64-column 0.059)
         const int64_t gcap = std::max<int64_t>(1, (int64_t)(256.0e6 / ((double)npad * (D + vg) * ts)));
         if (ctx->jsplit <= 0 && ctx->target_wgs <= 0 && gsplit > gcap) {
             gsplit = gcap;
