@@ -270,7 +270,13 @@ grad_launch_fn grad_launcher(int family);
 // ~1.7e-7 P per entry.  The bound is on EACH side, not on the product: the partial sums of |x~|^2 + |y~|^2 - 2 x~.y~ reach
 // the larger norm, and a far X cluster over a compact Y would otherwise pass.
 constexpr int MFMA_LDS_MIN_TILES = 64;
-constexpr int64_t MFMA_SYM_MIN_N = 24000;   // below: the general kernel is as fast (tools/mfma_sym_ab.py: 16384 loses, 24000 wins 7-16 %)
+// gramian(k, x) takes the symmetric (upper triangle once) kernels from these sizes on; below, the general kernel is as fast — the
+// symmetric launch has a floor of ~33 us (EQ) / ~90 us (MaternP) from its panel structure.  tools/sym_threshold_sweep.py, all
+// entries / symmetric in us: EQ d = 3: n = 16384 38.8 / 40.0, 20000 55.9 / 51.5; EQ d = 8: 16384 48.9 / 47.0, 20000 70.7 / 60.0;
+// MaternP(2): 12000 89.3 / 91.3, 16384 148 / 93.5; RQ: 12000 60.2 / 64.4, 16384 95.5 / 68.6.
+constexpr int64_t MFMA_SYM_MIN_N_EQ = 18000;        // EQ, d <= 4
+constexpr int64_t MFMA_SYM_MIN_N_EQ_WIDE = 15000;   // EQ, d > 4, and the cheap generic profiles (Cauchy, IMQ, Dot^p, ...)
+constexpr int64_t MFMA_SYM_MIN_N_HEAVY = 12500;     // MaternP, RQ, composites
 constexpr double MFMA_GATE = 126.0;
 constexpr double GRAD_EXPAND_GATE = 1000.0;   // gamma^2 R^2 up to which the fp64 gradient kernel expands |x - y|^2 (abs. error ~1e-16 R^2; grad_mvm.hpp)
 double gate_radius2(const covgram_points* X, const covgram_points* Y);

@@ -657,7 +657,7 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
     const int tpp = eq_k2_for(X->d) > MFMA_NARROW_MAXK2 ? 4 : 8;                    // row tiles per panel (dense_mfma_sym_wide_kernel: 4)
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;   // column-sum slab <= 16 GiB of the 288
-    return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
+    return ctx->mfma_sym == 1 || X->n >= (X->d <= 4 ? MFMA_SYM_MIN_N_EQ : MFMA_SYM_MIN_N_EQ_WIDE);
 }
 
 static int mfma_k2_for(int dims);
@@ -671,7 +671,8 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     const int tpp = k2 > MFMA_NARROW_MAXK2 ? 4 : 8;
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
-    return ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N;
+    const bool heavy = hk.tu_family == COVGRAM_MATERNP || hk.tu_family == COVGRAM_RQ || hk.tu_family >= COVGRAM_NFAMILY;   // profile costs several exponentials
+    return ctx->mfma_sym == 1 || X->n >= (heavy ? MFMA_SYM_MIN_N_HEAVY : MFMA_SYM_MIN_N_EQ_WIDE);
 }
 
 // y <- alpha * scale * G_part a + beta * y for the symmetric Gramian of ONE point set and one right-hand side, where G_part

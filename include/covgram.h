@@ -139,7 +139,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * matrix keeps the row kernel's spectrum copy as reals, 0 = always complex), "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
- * -1 = from n = 24000, 0 = never, 1 = always),
+ * -1 = from n = 12500 ... 18000 by the profile's cost, 0 = never, 1 = always),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
@@ -183,7 +183,7 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
  * gets the same share of the triangle — and returns in y (n scalars, device) the partial product of those entries AND their
  * mirror images; the partials of all ranks add up to G a, so ONE all-reduce (RCCL) completes b on every rank
  * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  Only where the symmetric
- * matrix-core kernels apply (fp32, EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm gate, n >= 24000 or option "mfma_sym" = 1): `*supported` of
+ * matrix-core kernels apply (fp32, EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm gate, n from 12500 ... 18000 by profile or option "mfma_sym" = 1): `*supported` of
  * covgram_mvm_sym_supported says so (identically on every rank: it depends on k and x only), and
  * covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED otherwise — callers then shard rows and all-gather (covgram_mvm). */
 int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported);

@@ -897,7 +897,7 @@ def test_generic_symmetric_matrix_core_kernels(cg, oracle, d):
 
 
 def test_eq_symmetric_kernel_at_size(cg, oracle):
-    """The size at which the library picks the symmetric kernel by itself (n >= 24000): sampled rows against the oracle."""
+    """The sizes at which the library picks the symmetric kernel by itself: sampled rows against the oracle."""
     rng = np.random.default_rng(77)
     n, d = 50021, 3
     X = rng.standard_normal((n, d)).astype(np.float32); a = rng.standard_normal(n).astype(np.float32)
@@ -907,6 +907,15 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
     rows = np.r_[0:50, n // 2:n // 2 + 50, n - 50:n]
     assert relerr(b[rows], oracle.mul(None, oracle.Kernel(oracle.EQ), X[rows], X, a, dtype=np.float32)) <= 1e-5
     assert np.isfinite(b).all()
+    # the thresholds by profile cost (csrc/common.hpp MFMA_SYM_MIN_N_*): EQ d <= 4 from 18000, wider EQ from 15000, MaternP / RQ from 12500
+    for kern, ko, nn, dd, want in ((cg.EQ(), oracle.Kernel(oracle.EQ), 17000, 3, 0), (cg.EQ(), oracle.Kernel(oracle.EQ), 19000, 3, 1),
+                                   (cg.EQ(), oracle.Kernel(oracle.EQ), 16000, 8, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 12000, 3, 0),
+                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 3, 1), (cg.RQ(1.5), oracle.Kernel(oracle.RQ, param=1.5), 13000, 3, 1)):
+        Xs = rng.standard_normal((nn, dd)).astype(np.float32); as_ = rng.standard_normal(nn).astype(np.float32)
+        bb = (cg.gramian(kern, torch.from_numpy(Xs).cuda()) @ torch.from_numpy(as_).cuda()).cpu().numpy()
+        assert cg.get_info("last_mfma_sym") == want, (type(kern).__name__, nn, dd)
+        rr = np.r_[0:40, nn - 40:nn]
+        assert relerr(bb[rr], oracle.mul(None, ko, Xs[rr], Xs, as_, dtype=np.float32)) <= 1e-5
 
 
 def test_eq_matrix_core_gate(cg, oracle):
