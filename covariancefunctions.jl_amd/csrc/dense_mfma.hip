@@ -554,7 +554,9 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // worth ~40 column tiles of work, so the split stops at 64 tiles per wave — as long as the grid still holds >= 2048 waves,
     // half of the chip's wave slots (tools/eq_small_sweep.py: d = 3, n = 16384 45.9 -> 37.9 us, n = 32768 118.8 -> 113.1;
     // d = 8, n = 16384 60.9 -> 47.4, n = 32768 175 -> 152; n = 8192 17.7 -> 16.9 / 25.3 -> 21.8 us)
-    if (ctx->jsplit <= 0) js = std::max<int64_t>((2048 + rowtiles - 1) / rowtiles, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 64)));
+    // (few rows — prediction shapes —: the 2048-wave floor itself stops at 16 tiles per wave: 256 x 65536, d = 3: 26.8 -> 22.2 us)
+    if (ctx->jsplit <= 0) js = std::max<int64_t>(std::min<int64_t>((2048 + rowtiles - 1) / rowtiles, std::max<int64_t>(1, ntile / 16)),
+                                                 std::min<int64_t>(js, std::max<int64_t>(1, ntile / 64)));
     js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));     // >= 8 tiles (256 columns) per wave
     const int64_t tchunk = (ntile + js - 1) / js;
     js = (ntile + tchunk - 1) / tchunk;
@@ -923,7 +925,8 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         const int64_t npad = rowtiles * 32 * ma.RT;
         int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
         int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
-        if (ctx->jsplit <= 0) js = std::max<int64_t>((2048 + rowtiles - 1) / rowtiles, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 64)));   // as mvm_eq_mfma
+        // (the 64-tiles-per-wave stop of mvm_eq_mfma does not carry over: these profiles cost several times EQ's per tile, so a wave's fixed
+        //  costs amortise over far fewer tiles — tools/rect_sweep.py, MaternP(2) 4096 x 65536: 32 splits 156 us, 128-256 splits 120-127 us)
         js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));
         const int64_t tchunk = (ntile + js - 1) / js;
         js = (ntile + tchunk - 1) / tchunk;
