@@ -230,9 +230,9 @@ __global__ __launch_bounds__(COLFFT_THREADS, 8) void colfft_kernel(const T* __re
     }
 }
 
-// position of the conjugate partner M-k of k = k1 + 1024 k' in the [k1][k'] layout
-__device__ __forceinline__ int64_t partner_pos(int k1, int64_t kp, int64_t Mp) {
-    const int k1p = (COLFFT_N1 - k1) & (COLFFT_N1 - 1);
+// position of the conjugate partner M-k of k = k1 + n1 k' in the [k1][k'] layout (n1 = column length: 512, 1024 or 2048)
+__device__ __forceinline__ int64_t partner_pos(int k1, int64_t kp, int64_t Mp, int n1) {
+    const int k1p = (n1 - k1) & (n1 - 1);
     const int64_t kpp = (k1 != 0) ? (Mp - 1 - kp) : ((Mp - kp) & (Mp - 1));
     return (int64_t)k1p * Mp + kpp;
 }
@@ -242,18 +242,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void half_spectrum_kernel(const typename V2T<T>::type* __restrict__ D, int64_t Mp,
                                                             const typename V2T<T>::type* __restrict__ tA,
                                                             const typename V2T<T>::type* __restrict__ tB,
-                                                            typename V2T<T>::type* __restrict__ S, T scale) {
+                                                            typename V2T<T>::type* __restrict__ S, T scale, int n1) {
     using V = typename V2T<T>::type;
     const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pos >= COLFFT_N1 * Mp) return;
+    if (pos >= n1 * Mp) return;
     const int k1 = (int)(pos / Mp);
     const int64_t kp = pos - (int64_t)k1 * Mp;
-    const V Z = D[pos], Zp = D[partner_pos(k1, kp, Mp)];
+    const V Z = D[pos], Zp = D[partner_pos(k1, kp, Mp, n1)];
     const V w = cmul(tA[k1], tB[kp]);                                   // exp(-i pi k / M)
     const V e = cadd(Z, cconj(Zp)), o = csub(Z, cconj(Zp));
     const V wo = cmul(w, o);
     V X{(T)0.5 * (e.x + wo.y), (T)0.5 * (e.y - wo.x)};                  // 0.5 e - 0.5 i (w o)
-    if (pos == 0) { X = V{Z.x + Z.y, (T)0}; S[(int64_t)COLFFT_N1 * Mp] = V{(Z.x - Z.y) * scale, (T)0}; }
+    if (pos == 0) { X = V{Z.x + Z.y, (T)0}; S[(int64_t)n1 * Mp] = V{(Z.x - Z.y) * scale, (T)0}; }
     S[pos] = V{X.x * scale, X.y * scale};
 }
 
@@ -262,18 +262,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void spectral_kernel(typename V2T<T>::type* __restrict__ D, int64_t Mp,
                                                        const typename V2T<T>::type* __restrict__ S,
                                                        const typename V2T<T>::type* __restrict__ tA,
-                                                       const typename V2T<T>::type* __restrict__ tB) {
+                                                       const typename V2T<T>::type* __restrict__ tB, int n1) {
     using V = typename V2T<T>::type;
-    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;        // rows k1 = 0 .. 512
-    if (pos >= (int64_t)(COLFFT_N1 / 2 + 1) * Mp) return;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;        // rows k1 = 0 .. n1 / 2
+    if (pos >= (int64_t)(n1 / 2 + 1) * Mp) return;
     const int k1 = (int)(pos / Mp);
     const int64_t kp = pos - (int64_t)k1 * Mp;
-    const int64_t ppos = partner_pos(k1, kp, Mp);
-    if ((k1 == 0 || k1 == COLFFT_N1 / 2) && ppos < pos) return;        // self-paired rows: the lower position owns the pair
+    const int64_t ppos = partner_pos(k1, kp, Mp, n1);
+    if ((k1 == 0 || k1 == n1 / 2) && ppos < pos) return;        // self-paired rows: the lower position owns the pair
     const V Z = D[pos];
     if (pos == 0) {                                                     // k = 0 and the Nyquist bin share Z[0]
         const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
-        const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+        const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)n1 * Mp].x;
         D[0] = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
         return;
     }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void 
                                                                           const typename V2T<T>::type* __restrict__ S,
                                                                           const typename V2T<T>::type* __restrict__ tA,
                                                                           const typename V2T<T>::type* __restrict__ tB,
-                                                                          const typename V2T<T>::type* __restrict__ twr) {
+                                                                          const typename V2T<T>::type* __restrict__ twr, int n1) {
     using V = typename V2T<T>::type;
     constexpr int Mp = 1 << (2 * L), Q = Mp / 4, NT = Q;
     // LDS rows are padded by one element per 16 (slot(i) = i + i/16): with 16-byte elements a quarter-wave then always
@@ -345,7 +345,7 @@ __global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void 
     __shared__ V stw[Q];
     const int tid = threadIdx.x;
     const int wg = blockIdx.x;
-    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? COLFFT_N1 / 2 : COLFFT_N1 - wg;
+    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? n1 / 2 : n1 - wg;
     V* __restrict__ gA = zbuf + (int64_t)kA * Mp;
     V* __restrict__ gB = zbuf + (int64_t)kB * Mp;
 #pragma unroll
@@ -382,7 +382,7 @@ __global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void 
         const V Z = zs;
         if (pos == 0) {                                  // k = 0 and the Nyquist bin share Z[0]
             const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
-            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)n1 * Mp].x;
             zs = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
             return;
         }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__((1 << (2 * L)) / 4, (sizeof(T) == 4 ? 8 : 4)) void 
             const int kr = Mp - 1 - kp;
             if (kp < kr) {
                 const int p = rev4<L>(kp);
-                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, COLFFT_N1 / 2, kp, (int64_t)(COLFFT_N1 / 2) * Mp + kp, (int64_t)(COLFFT_N1 / 2) * Mp + kr);
+                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, n1 / 2, kp, (int64_t)(n1 / 2) * Mp + kp, (int64_t)(n1 / 2) * Mp + kr);
             }
         }
     }
@@ -546,71 +546,97 @@ template <typename V, bool INV> __device__ __forceinline__ void dft4(V (&v)[4]) 
     v[0] = cadd(apc, bpd); v[1] = cadd(amc, ib); v[2] = csub(apc, bpd); v[3] = csub(amc, ib);
 }
 
-template <typename T, int TW, bool INV>
-__global__ __launch_bounds__(64 * TW, 2) void colfft16_kernel(const T* __restrict__ src, int64_t src_len,
+template <typename V, bool INV> __device__ __forceinline__ void dft2(V (&v)[2]) { const V a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b); }
+template <typename V, bool INV> __device__ __forceinline__ void dft8(V (&v)[8]) {
+    // two radix-4 transforms of the even / odd entries, combined with W_8^k (forward W_8 = (1 - i) / sqrt 2; INV: conjugate)
+    using T = decltype(v[0].x);
+    V e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft4<V, INV>(e); dft4<V, INV>(o);
+    constexpr double C = 0.70710678118654752440;
+    const T c = (T)C, sn = (T)(INV ? C : -C);
+    o[1] = V{o[1].x * c - o[1].y * sn, o[1].x * sn + o[1].y * c};                   // W_8^1
+    o[2] = INV ? cmuli(o[2]) : cmulmi(o[2]);                                        // W_8^2 = -i (forward)
+    o[3] = V{-o[3].x * c - o[3].y * sn, o[3].x * sn - o[3].y * c};                  // W_8^3 = (-1 - i) / sqrt 2 (forward)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+}
+template <typename V, bool INV, int R> __device__ __forceinline__ void dftR(V (&v)[R]) {
+    if constexpr (R == 2) dft2<V, INV>(v);
+    else if constexpr (R == 4) dft4<V, INV>(v);
+    else dft8<V, INV>(v);
+}
+
+// R = 2, 4, 8: column length N1 = 256 R = 512, 1024, 2048 as 16 x R x 16 (the middle stage is a radix-R butterfly over the span 16
+// inside each block of 16 R positions; block q' sits at LDS rows 17 R q' ...).  16 R TW threads; 35 / 70 / 139 KB of LDS.
+template <typename T, int TW, bool INV, int R>
+__global__ __launch_bounds__(16 * R * TW, (R == 8 ? 1 : 2)) void colfft16_kernel(const T* __restrict__ src, int64_t src_len,
                                                                typename V2T<T>::type* __restrict__ zbuf, int64_t Mp,
-                                                               const typename V2T<T>::type* __restrict__ tw1024,
+                                                               const typename V2T<T>::type* __restrict__ twN1,
                                                                const typename V2T<T>::type* __restrict__ tlo,
                                                                const typename V2T<T>::type* __restrict__ thi, T* __restrict__ y, int64_t n,
                                                                T alpha, T beta) {
     using V = typename V2T<T>::type;
-    constexpr int ROWS = COLFFT_N1 + COLFFT_N1 / 16;
+    constexpr int N1 = 256 * R, BLK = 16 * R, PBS = 17 * R;   // positions per stage-1 block, LDS rows per block
+    constexpr int ROWS = N1 + N1 / 16;
+    constexpr int NB = 16 / R;                                // radix-R butterflies per thread
     __shared__ V buf[ROWS * TW];
     const int tid = threadIdx.x;
     const unsigned bid = blockIdx.x;
     const unsigned tile = (gridDim.x % 16 == 0) ? (2 * (8 * (bid / 16) + (bid % 8)) + ((bid / 8) % 2)) : bid;   // as colfft_kernel
-    const int c = tid % TW, r = tid / TW;                  // r = 0..63: the butterfly of this thread in the radix-16 stages
+    const int c = tid % TW, r = tid / TW;                  // r = 0..16 R - 1: the butterfly of this thread in the radix-16 stages
     const int64_t np = (int64_t)tile * TW + c;             // column n'
     auto twM = [&](int64_t idx) { return cmul(thi[idx >> TWID_LB], tlo[idx & ((1 << TWID_LB) - 1)]); };   // W_M^idx
-    const int k0 = (r >> 2) + 16 * (r & 3);                // span-1 stage: butterfly r = 4 q' + m' owns the rows q' + 16 m' + 64 q''
-    const int j = r & 15, gw = r >> 4;                     // radix-4 stage: butterflies (g = 4 gw + i, j)
+    const int k0 = (r / R) + 16 * (r % R);                 // span-1 stage: butterfly r = R q' + m' owns the rows q' + 16 m' + 16 R q''
+    const int j = r & 15, gw = r >> 4;                     // radix-R stage: butterflies (g = NB gw + i, j)
     V x[16], w[16];
     if constexpr (!INV) {
-        // ---- rows b + 64 q of column n' (b = r): z_j = x[2j] + i x[2j+1], zero beyond src_len -------------------------------
+        // ---- rows b + 16 R q of column n' (b = r): z_j = x[2j] + i x[2j+1], zero beyond src_len ------------------------------
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int64_t e = 2 * ((int64_t)(r + 64 * q) * Mp + np);
+            const int64_t e = 2 * ((int64_t)(r + BLK * q) * Mp + np);
             x[q].x = (e < src_len) ? src[e] : (T)0;
             x[q].y = (e + 1 < src_len) ? src[e + 1] : (T)0;
         }
         dft16<V, false>(x);
-        pow_chain16(tw1024[r], w);
+        pow_chain16(twN1[r], w);
         const int p0 = (r + (r >> 4)) * TW + c;
         buf[p0] = x[0];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) buf[p0 + 68 * q * TW] = cmul(x[q], w[q]);
+        for (int q = 1; q < 16; ++q) buf[p0 + PBS * q * TW] = cmul(x[q], w[q]);
         __syncthreads();
         {
-            const V w1 = tw1024[16 * j], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            V wm[R];                                        // W_(16 R)^(j m') = W_N1^(16 j m')
+            wm[1] = twN1[16 * j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = (68 * (4 * gw + i) + j) * TW + c;
-                V v[4];
+            for (int m = 2; m < R; ++m) wm[m] = (m & 1) ? cmul(wm[m - 1], wm[1]) : cmul(wm[m / 2], wm[m / 2]);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = buf[p + 17 * m * TW];
-                dft4<V, false>(v);
+            for (int i = 0; i < NB; ++i) {
+                const int p = (PBS * (NB * gw + i) + j) * TW + c;
+                V v[R];
+#pragma unroll
+                for (int m = 0; m < R; ++m) v[m] = buf[p + 17 * m * TW];
+                dftR<V, false, R>(v);
                 buf[p] = v[0];
-                buf[p + 17 * TW] = cmul(v[1], w1);
-                buf[p + 34 * TW] = cmul(v[2], w2);
-                buf[p + 51 * TW] = cmul(v[3], w3);
+#pragma unroll
+                for (int m = 1; m < R; ++m) buf[p + 17 * m * TW] = cmul(v[m], wm[m]);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; ++q) x[q] = buf[(17 * r + q) * TW + c];
         dft16<V, false>(x);
-        // inter-step twiddle W_M^(n' (k0 + 64 q)) = W_M^(n' k0) (W_M^(64 n'))^q
-        pow_chain16(twM(64 * np), w);
+        // inter-step twiddle W_M^(n' (k0 + 16 R q)) = W_M^(n' k0) (W_M^(16 R n'))^q
+        pow_chain16(twM(BLK * np), w);
         const V wk = twM(np * k0);
         V* __restrict__ zo = zbuf + (int64_t)k0 * Mp + np;
         zo[0] = cmul(x[0], wk);
 #pragma unroll
-        for (int q = 1; q < 16; ++q) zo[(int64_t)64 * q * Mp] = cmul(x[q], cmul(wk, w[q]));
+        for (int q = 1; q < 16; ++q) zo[(int64_t)BLK * q * Mp] = cmul(x[q], cmul(wk, w[q]));
     } else {
         const V* __restrict__ zi = zbuf + (int64_t)k0 * Mp + np;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = zi[(int64_t)64 * q * Mp];
-        pow_chain16(cconj(twM(64 * np)), w);
+        for (int q = 0; q < 16; ++q) x[q] = zi[(int64_t)BLK * q * Mp];
+        pow_chain16(cconj(twM(BLK * np)), w);
         const V wk = cconj(twM(np * k0));
         x[0] = cmul(x[0], wk);
 #pragma unroll
@@ -620,30 +646,32 @@ __global__ __launch_bounds__(64 * TW, 2) void colfft16_kernel(const T* __restric
         for (int q = 0; q < 16; ++q) buf[(17 * r + q) * TW + c] = x[q];
         __syncthreads();
         {
-            const V w1 = cconj(tw1024[16 * j]), w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            V wm[R];
+            wm[1] = cconj(twN1[16 * j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = (68 * (4 * gw + i) + j) * TW + c;
-                V v[4];
+            for (int m = 2; m < R; ++m) wm[m] = (m & 1) ? cmul(wm[m - 1], wm[1]) : cmul(wm[m / 2], wm[m / 2]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int p = (PBS * (NB * gw + i) + j) * TW + c;
+                V v[R];
                 v[0] = buf[p];
-                v[1] = cmul(buf[p + 17 * TW], w1);
-                v[2] = cmul(buf[p + 34 * TW], w2);
-                v[3] = cmul(buf[p + 51 * TW], w3);
-                dft4<V, true>(v);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) buf[p + 17 * m * TW] = v[m];
+                for (int m = 1; m < R; ++m) v[m] = cmul(buf[p + 17 * m * TW], wm[m]);
+                dftR<V, true, R>(v);
+#pragma unroll
+                for (int m = 0; m < R; ++m) buf[p + 17 * m * TW] = v[m];
             }
         }
         __syncthreads();
-        pow_chain16(cconj(tw1024[r]), w);
+        pow_chain16(cconj(twN1[r]), w);
         const int p0 = (r + (r >> 4)) * TW + c;
         x[0] = buf[p0];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) x[q] = cmul(buf[p0 + 68 * q * TW], w[q]);
+        for (int q = 1; q < 16; ++q) x[q] = cmul(buf[p0 + PBS * q * TW], w[q]);
         dft16<V, true>(x);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int64_t e = 2 * ((int64_t)(r + 64 * q) * Mp + np);       // natural order: y[e], y[e + 1]
+            const int64_t e = 2 * ((int64_t)(r + BLK * q) * Mp + np);       // natural order: y[e], y[e + 1]
             if (e < n) {
                 T ov = alpha * x[q].x;
                 if (beta != (T)0) ov = __builtin_fma(beta, y[e], ov);
@@ -682,7 +710,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
                                                                           const typename V2T<T>::type* __restrict__ tB,
                                                                           const typename V2T<T>::type* __restrict__ twr,
                                                                           const void* __restrict__ S16v,
-                                                                          const typename V2T<T>::type* __restrict__ tB16) {
+                                                                          const typename V2T<T>::type* __restrict__ tB16, int n1) {
     using V = typename V2T<T>::type;
     constexpr int Mp = 4096, Q = Mp / 4, NT = 512;
     constexpr int MpP = Mp + Mp / 16;
@@ -692,7 +720,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
     __shared__ V stw[Q];
     const int tid = threadIdx.x;
     const int wg = blockIdx.x;
-    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? COLFFT_N1 / 2 : COLFFT_N1 - wg;
+    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? n1 / 2 : n1 - wg;
     V* __restrict__ gA = zbuf + (int64_t)kA * Mp;
     V* __restrict__ gB = zbuf + (int64_t)kB * Mp;
     V* __restrict__ xr = (tid >> 8) ? rowB : rowA;          // this thread's row
@@ -748,7 +776,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
         const V Z = zs;
         if (pos == 0) {
             const T X0 = Z.x + Z.y, XM = Z.x - Z.y;
-            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)COLFFT_N1 * Mp].x;
+            const T Y0 = X0 * S[0].x, YM = XM * S[(int64_t)n1 * Mp].x;
             zs = V{(T)0.5 * (Y0 + YM), (T)0.5 * (Y0 - YM)};
             return;
         }
@@ -794,7 +822,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
             const int kr = Mp - 1 - kp;
             if (kp < kr) {
                 const int p = rev16_3(kp);
-                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, COLFFT_N1 / 2, kp, (int64_t)(COLFFT_N1 / 2) * Mp + kp, (int64_t)(COLFFT_N1 / 2) * Mp + kr);
+                pair(rowB[P(p)], rowB[P(Mp - 1 - p)], false, n1 / 2, kp, (int64_t)(n1 / 2) * Mp + kp, (int64_t)(n1 / 2) * Mp + kr);
             }
         }
     }
@@ -851,6 +879,7 @@ struct covgram_toeplitz {
     rocfft_plan bfwd = nullptr, binv = nullptr;   // 1024 contiguous length-Mp complex transforms, in place
     void* zbuf = nullptr;    // M complex
     void* sperm = nullptr;   // M + 1 complex: permuted half spectrum of the embedding / M, Nyquist bin last
+    int n1 = 1024;             // column length of the four-step split: M = n1 x Mp (512, 1024 or 2048 — whichever makes Mp a power of four <= 4096)
     bool sperm16_real = false; // sperm16 holds real parts only (symmetric matrix)
     void* sperm16 = nullptr; // M' = 4096: the same rows with their entries at the base-16 digit-reversed index (rowfft16_fused_kernel)
     void* tables = nullptr;  // tw1024 | tlo(2048) | thi(M/2048) | tA(1024) | tB(Mp)   (complex)
@@ -866,16 +895,16 @@ template <typename T> constexpr int colfft_tw() { return sizeof(T) == 8 ? 4 : 8;
 
 // complex tables for the fast path, computed in long double on the host
 template <typename T>
-static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp) {
+static void fill_tables(std::vector<T>& h, int64_t M, int64_t Mp, int n1) {
     const long double PI = 3.14159265358979323846264338327950288L;
     const int64_t nhi = M >> TWID_LB;
-    h.resize(2 * (size_t)(COLFFT_N1 + (1 << TWID_LB) + nhi + COLFFT_N1 + Mp + Mp / 4 + Mp));
+    h.resize(2 * (size_t)(n1 + (1 << TWID_LB) + nhi + n1 + Mp + Mp / 4 + Mp));
     size_t o = 0;
     auto put = [&](long double ang) { h[o++] = (T)cosl(ang); h[o++] = (T)sinl(ang); };
-    for (int t = 0; t < COLFFT_N1; ++t) put(-2 * PI * t / COLFFT_N1);                 // tw1024[t] = W_1024^t
+    for (int t = 0; t < n1; ++t) put(-2 * PI * t / n1);                               // tw[t]     = W_n1^t (n1 = column length)
     for (int l = 0; l < (1 << TWID_LB); ++l) put(-2 * PI * l / (long double)M);        // tlo[l]    = W_M^l
     for (int64_t q = 0; q < nhi; ++q) put(-2 * PI * q / (long double)nhi);             // thi[q]    = W_M^(2048 q)
-    for (int k1 = 0; k1 < COLFFT_N1; ++k1) put(-PI * k1 / (long double)M);             // tA[k1]    = exp(-i pi k1 / M)
+    for (int k1 = 0; k1 < n1; ++k1) put(-PI * k1 / (long double)M);                    // tA[k1]    = exp(-i pi k1 / M)
     for (int64_t kp = 0; kp < Mp; ++kp) put(-PI * kp / (long double)Mp);               // tB[k']    = exp(-i pi 1024 k' / M)
     for (int64_t r = 0; r < Mp / 4; ++r) put(-2 * PI * r / (long double)Mp);           // twr[r]    = W_M'^r (quarter table)
     for (int64_t p = 0; p < Mp; ++p) {                                                 // tB16[p]   = tB[rev16(p)] (M' = 4096 only)
@@ -890,10 +919,10 @@ static FastTables table_ptrs(const covgram_toeplitz* Tz) {
     const char* b = (const char*)Tz->tables;
     const int64_t M = Tz->N / 2, nhi = M >> TWID_LB;
     FastTables t;
-    t.tw = b; b += cs * COLFFT_N1;
+    t.tw = b; b += cs * Tz->n1;
     t.tlo = b; b += cs * (1 << TWID_LB);
     t.thi = b; b += cs * nhi;
-    t.tA = b; b += cs * COLFFT_N1;
+    t.tA = b; b += cs * Tz->n1;
     t.tB = b; b += cs * Tz->Mp;
     t.twr = b; b += cs * (Tz->Mp / 4);
     t.tB16 = b;
@@ -907,12 +936,15 @@ static void launch_colfft(covgram_toeplitz* Tz, const FastTables& t, const T* sr
     constexpr int TW = colfft_tw<T>();
     hipStream_t st = Tz->ctx->stream;
     const dim3 grid((unsigned)(Tz->Mp / TW));
-    if (Tz->ctx->toeplitz_colfft != 4)
-        hipLaunchKernelGGL((colfft16_kernel<T, TW, INV>), grid, dim3(64 * TW), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
-                           (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, n, alpha, beta);
+#define CG_COL16(RR) hipLaunchKernelGGL((colfft16_kernel<T, TW, INV, RR>), grid, dim3(16 * RR * TW), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp, \
+                                        (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, n, alpha, beta)
+    if (Tz->n1 == 512) CG_COL16(2);
+    else if (Tz->n1 == 2048) CG_COL16(8);
+    else if (Tz->ctx->toeplitz_colfft != 4) CG_COL16(4);
     else
         hipLaunchKernelGGL((colfft_kernel<T, TW, INV>), grid, dim3(COLFFT_THREADS), 0, st, src, len, (V*)Tz->zbuf, Tz->Mp,
                            (const V*)t.tw, (const V*)t.tlo, (const V*)t.thi, y, n, alpha, beta);
+#undef CG_COL16
 }
 
 // zbuf <- permuted packed spectrum of the real signal src[0..len) (zero beyond), length N
@@ -939,17 +971,17 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
     if (L && Tz->ctx->toeplitz_fused) {
         // column FFT -> [row FFT, spectral step, inverse row FFT] in one kernel -> inverse column FFT: three passes over zbuf
         launch_colfft<T, false>(Tz, t, a, Tz->m, (T*)nullptr, (int64_t)0, (T)0, (T)0);
-        const dim3 fg(COLFFT_N1 / 2);
+        const dim3 fg(Tz->n1 / 2);
 #define CG_FUSED(LL) hipLaunchKernelGGL((rowfft_fused_kernel<T, LL>), fg, dim3((1 << (2 * LL)) / 4), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, \
-                                        (const V*)t.tA, (const V*)t.tB, (const V*)t.twr)
+                                        (const V*)t.tA, (const V*)t.tB, (const V*)t.twr, Tz->n1)
         if (L == 6 && Tz->ctx->toeplitz_fused != 2)   // M' = 4096: radix-16 stages (option toeplitz_fused = 2 keeps the radix-4 kernel: A/B)
         {
             if (Tz->sperm16_real)
                 hipLaunchKernelGGL((rowfft16_fused_kernel<T, true>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
-                                   (const void*)Tz->sperm16, (const V*)t.tB16);
+                                   (const void*)Tz->sperm16, (const V*)t.tB16, Tz->n1);
             else
                 hipLaunchKernelGGL((rowfft16_fused_kernel<T, false>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
-                                   (const void*)Tz->sperm16, (const V*)t.tB16);
+                                   (const void*)Tz->sperm16, (const V*)t.tB16, Tz->n1);
         }
         else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }
@@ -961,9 +993,9 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
     }
     int rc = fast_forward<T>(Tz, a, Tz->m);
     if (rc) return rc;
-    const int64_t pairs = (int64_t)(COLFFT_N1 / 2 + 1) * Tz->Mp;
+    const int64_t pairs = (int64_t)(Tz->n1 / 2 + 1) * Tz->Mp;
     hipLaunchKernelGGL(spectral_kernel<T>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (V*)Tz->zbuf, Tz->Mp, (const V*)Tz->sperm,
-                       (const V*)t.tA, (const V*)t.tB);
+                       (const V*)t.tA, (const V*)t.tB, Tz->n1);
     void* io[1] = {Tz->zbuf};
     CG_CHECK_FFT(rocfft_execute(Tz->binv, io, nullptr, Tz->info));
     launch_colfft<T, true>(Tz, t, (const T*)nullptr, (int64_t)0, y, Tz->n, (T)alpha, (T)beta);
@@ -1016,8 +1048,15 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
 #define TRY_HIP(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); return fail(COVGRAM_EHIP); } } while (0)
 #define TRY_FFT(e) do { rocfft_status _s = (e); if (_s != rocfft_status_success) { set_error("%s failed: rocfft_status %d", #e, (int)_s); return fail(COVGRAM_EHIP); } } while (0)
     const int64_t Mh = N / 2;
-    T->fast = !T->circulant && (Mh % COLFFT_N1 == 0) && (Mh / COLFFT_N1 >= (dtype == COVGRAM_F64 ? colfft_tw<double>() : colfft_tw<float>()));
-    T->Mp = T->fast ? Mh / COLFFT_N1 : 0;
+    // column length of the four-step split: 1024, or 512 / 2048 when that makes the row length a power of four <= 4096 (the sizes
+    // the fused row kernels exist for: N = 2^20, 2^22 take 512 x 1024, 512 x 4096; N = 2^24 takes 2048 x 4096)
+    const int64_t twmin = (dtype == COVGRAM_F64 ? colfft_tw<double>() : colfft_tw<float>());
+    auto fused_len = [](int64_t mp) { return mp == 64 || mp == 256 || mp == 1024 || mp == 4096; };
+    T->n1 = 1024;
+    for (int cand : {1024, 512, 2048})
+        if (Mh % cand == 0 && fused_len(Mh / cand)) { T->n1 = cand; break; }
+    T->fast = !T->circulant && (Mh % T->n1 == 0) && (Mh / T->n1 >= twmin);
+    T->Mp = T->fast ? Mh / T->n1 : 0;
     const rocfft_precision prec = (dtype == COVGRAM_F64) ? rocfft_precision_double : rocfft_precision_single;
     TRY_HIP(hipMalloc(&T->rbuf, (size_t)N * ts));
     size_t w1 = 0, w2 = 0;
@@ -1025,16 +1064,16 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
         TRY_HIP(hipMalloc(&T->zbuf, (size_t)Mh * 2 * ts));
         TRY_HIP(hipMalloc(&T->sperm, (size_t)(Mh + 1) * 2 * ts));
         size_t blen[1] = {(size_t)T->Mp};
-        TRY_FFT(rocfft_plan_create(&T->bfwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, blen, COLFFT_N1, nullptr));
-        TRY_FFT(rocfft_plan_create(&T->binv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, blen, COLFFT_N1, nullptr));
+        TRY_FFT(rocfft_plan_create(&T->bfwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 1, blen, (size_t)T->n1, nullptr));
+        TRY_FFT(rocfft_plan_create(&T->binv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 1, blen, (size_t)T->n1, nullptr));
         TRY_FFT(rocfft_plan_get_work_buffer_size(T->bfwd, &w1));
         TRY_FFT(rocfft_plan_get_work_buffer_size(T->binv, &w2));
         if (dtype == COVGRAM_F64) {
-            std::vector<double> h; fill_tables<double>(h, Mh, T->Mp);
+            std::vector<double> h; fill_tables<double>(h, Mh, T->Mp, T->n1);
             TRY_HIP(hipMalloc(&T->tables, h.size() * sizeof(double)));
             TRY_HIP(hipMemcpy(T->tables, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
         } else {
-            std::vector<float> h; fill_tables<float>(h, Mh, T->Mp);
+            std::vector<float> h; fill_tables<float>(h, Mh, T->Mp, T->n1);
             TRY_HIP(hipMalloc(&T->tables, h.size() * sizeof(float)));
             TRY_HIP(hipMemcpy(T->tables, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -1075,16 +1114,16 @@ int covgram_toeplitz_create(covgram_ctx* ctx, covgram_toeplitz** out, const void
     else hipLaunchKernelGGL(embed_kernel<double>, dim3(gN), dim3(256), 0, ctx->stream, (const double*)dvc, (const double*)dvr, n, me, N, (double*)T->rbuf);
     if (T->fast) {
         // permuted half spectrum of the embedding, pre-divided by M (the unnormalised inverse transforms return M * signal)
-        const int64_t tot = (int64_t)COLFFT_N1 * T->Mp;
+        const int64_t tot = (int64_t)T->n1 * T->Mp;
         const FastTables ft = table_ptrs(T);
         if (dtype == COVGRAM_F32) {
             if (fast_forward<float>(T, (const float*)T->rbuf, N)) return fail(COVGRAM_EHIP);
             hipLaunchKernelGGL(half_spectrum_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const float2*)T->zbuf, T->Mp,
-                               (const float2*)ft.tA, (const float2*)ft.tB, (float2*)T->sperm, 1.0f / (float)Mh);
+                               (const float2*)ft.tA, (const float2*)ft.tB, (float2*)T->sperm, 1.0f / (float)Mh, T->n1);
         } else {
             if (fast_forward<double>(T, (const double*)T->rbuf, N)) return fail(COVGRAM_EHIP);
             hipLaunchKernelGGL(half_spectrum_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)T->zbuf, T->Mp,
-                               (const double2*)ft.tA, (const double2*)ft.tB, (double2*)T->sperm, 1.0 / (double)Mh);
+                               (const double2*)ft.tA, (const double2*)ft.tB, (double2*)T->sperm, 1.0 / (double)Mh, T->n1);
         }
         if (T->Mp == 4096) {
             T->sperm16_real = (vr == nullptr) && ctx->toeplitz_real_spectrum != 0;       // c_j = c_(N-j): the spectrum has no imaginary part
