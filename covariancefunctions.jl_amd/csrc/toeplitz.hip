@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void toep_epilogue_kernel(const T* __restrict_
 // Five passes over HBM instead of fifteen.
 // Round 2: the defaults are colfft16_kernel (the same column FFT as 16 x 4 x 16 with register butterflies, below) and, for
 // M' = 4^L <= 4096, ONE fused kernel for the three middle passes (rowfft_fused_kernel; M' = 4096: rowfft16_fused_kernel) —
-// three passes over zbuf per MVM.  colfft_kernel / the rocFFT batches + spectral_kernel remain as the A/B arms
+// three passes over zbuf per MVM; the column length is 512 or 2048 instead of 1024 when that is what makes M' a power of four
+// <= 4096 (covgram_toeplitz::n1).  colfft_kernel / the rocFFT batches + spectral_kernel remain as the A/B arms
 // (options toeplitz_colfft = 4, toeplitz_fused = 0) and serve the M' the fused kernels do not cover.
 // ================================================================================================
 template <typename T> struct V2T;

@@ -1248,9 +1248,10 @@ def test_toeplitz_direct_solvers_durbin_levinson_trench(cg, oracle, n):
 
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 65536), (torch.float64, 250000), (torch.float64, 1000000), (torch.float64, 3000001),
                                      (torch.float32, 250000), (torch.float32, 4000000),
-                                     (torch.float64, 500000), (torch.float32, 100000)])     # M' = 512, 128: not 4^L, rocFFT row batches
+                                     (torch.float64, 500000), (torch.float32, 100000),      # N = 2^20, 2^18: column length 512 (x 1024, x 256)
+                                     (torch.float64, 2000000), (torch.float32, 6000000)])   # N = 2^22: 512 x 4096; N = 2^24: 2048 x 4096
 def test_toeplitz_fused_row_fft_kernel(cg, oracle, dtype, n):
-    """M' = N / 2048 in {64, 256, 1024, 4096}: the row FFT, spectral step and inverse row FFT run as ONE kernel
+    """Row length M' in {64, 256, 1024, 4096} with the column length (512, 1024 or 2048) that gives it: the row FFT, spectral step and inverse row FFT run as ONE kernel
     (rowfft_fused_kernel; M' = 4096: rowfft16_fused_kernel, radix-16 stages with global I/O in the outer stages) — against the numpy circulant-embedding oracle, explicit dense rows, and the rocFFT-batch path
     (option toeplitz_fused = 0), symmetric and non-symmetric, alpha / beta."""
     tol = 1e-5 if dtype == torch.float32 else 1e-10
