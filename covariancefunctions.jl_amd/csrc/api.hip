@@ -446,6 +446,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
     else if (!strcmp(key, "mfma_stamp")) ctx->mfma_stamp = value;
+    else if (!strcmp(key, "mfma_mrhs")) ctx->mfma_mrhs = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }

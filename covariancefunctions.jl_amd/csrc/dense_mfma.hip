@@ -335,6 +335,22 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
         for (int cr = 0; cr < NR; ++cr) W[(T * NR + cr) * 32 + l] = (j < m && c0 + cr < nrhs) ? A[j + (int64_t)(c0 + cr) * lda] : 0.0f;
 }
 
+// A operands of dense_mfma_mrhs_kernel: AP[((T * NB + b) * 64 + l) * 16 + v] = a[j][c0 + 32 b + (l & 31)] with
+// j = 32 T + 8 (v / 4) + 4 (l >> 5) + v % 4 (zero outside the matrix): lane l's sixteen values of one tile are contiguous
+__global__ __launch_bounds__(256) void mfma_pack_rhs_kernel(const float* __restrict__ A, int64_t lda, int32_t nrhs, int32_t c0, int64_t m,
+                                                            float* __restrict__ AP, int32_t NB) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, block, lane, v)
+    const int64_t ntile = (m + 31) / 32;
+    if (e >= ntile * NB * 64 * 16) return;
+    const int v = (int)(e & 15), l = (int)((e >> 4) & 63);
+    const int64_t q = e >> 10;
+    const int b = (int)(q % NB);
+    const int64_t T = q / NB;
+    const int64_t j = 32 * T + 8 * (v >> 2) + 4 * (l >> 5) + (v & 3);
+    const int c = c0 + 32 * b + (l & 31);
+    AP[e] = (j < m && c < nrhs) ? A[j + (int64_t)c * lda] : 0.0f;
+}
+
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
 template <typename T>
 __global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits,
@@ -903,7 +919,51 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
     const int64_t ntile = (m + 31) / 32;
     mfma_launch_fn launch = mfma_launcher(hk.tu_family);
     const double alpha_eff = alpha * hk.kp.scale;
-    for (int c0 = 0; c0 < nrhs; c0 += 4) {
+    int cdone = 0;
+    // many right-hand sides: blocks of up to 64 on the fp32 matrix cores (dense_mfma_mrhs_kernel), from 12 columns on —
+    // option "mfma_mrhs": -1 this rule, 0 never, 1 from 2 columns (tests)
+    while (nrhs - cdone >= (ctx->mfma_mrhs == 1 ? 2 : 12) && ctx->mfma_mrhs != 0) {
+        const int c0 = cdone;
+        const int nr = std::min(64, nrhs - c0);
+        const int NB = nr > 32 ? 2 : 1;
+        float* y_c = y + (size_t)c0 * ldy;
+        void* P;
+        const size_t fb = (size_t)ntile * K2 * 64 * sizeof(uint4), wb = (size_t)ntile * 32 * sizeof(float);
+        rc = ws_reserve(ctx, 0, fb + wb + (size_t)ntile * NB * 64 * 16 * sizeof(float), &P);
+        if (rc) return rc;
+        uint4* PB = (uint4*)P;
+        float* Wd = (float*)((char*)P + fb);                       // the pack kernel's weight output: unused here
+        float* AP = (float*)((char*)P + fb + wb);
+        const int64_t pe = ntile * K2 * 64;
+        hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
+                           lda, 0, 0, PB, Wd, K2, 1, (float)hk.kp.gamma, iso ? 1 : 0, (const float*)Y->center);
+        const int64_t ae = ntile * NB * 64 * 16;
+        hipLaunchKernelGGL(mfma_pack_rhs_kernel, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, ctx->stream, a, lda, c0 + nr, c0, m, AP, NB);
+        const int64_t rowtiles = (n + 31) / 32, npad = rowtiles * 32;
+        int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * 32;        // the fp32 MFMAs bound this kernel: 2 rounds of 4 waves per SIMD
+        int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
+        js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));
+        const int64_t tchunk = (ntile + js - 1) / js;
+        js = (ntile + tchunk - 1) / tchunk;
+        float* out = y_c;
+        if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * 32 * NB * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
+        MfmaArgs ma;
+        ma.K2 = K2; ma.NR = 32 * NB; ma.RT = 1; ma.mrhs = NB;
+        ma.hk = &hk; ma.stream = ctx->stream; ma.Cn = (const float*)Y->center;
+        ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PB; ma.W = AP; ma.ntile = ntile; ma.out = out; ma.npad = npad; ma.ldy = ldy;
+        ma.nrhs = nr; ma.tchunk = tchunk; ma.alpha = (float)alpha_eff; ma.beta = (float)beta; ma.final_store = js == 1 ? 1 : 0;
+        ma.grid = dim3((unsigned)rowtiles, (unsigned)js);
+        auto* tm = timer_next(ctx);
+        if (tm) (void)hipEventRecord(tm->first, ctx->stream);
+        rc = launch(ma, false);
+        if (rc) return rc;
+        if (tm) (void)hipEventRecord(tm->second, ctx->stream);
+        if (js > 1)
+            hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream, (const float*)out, npad,
+                               32 * NB, (int)js, y_c, n, ldy, nr, (float)alpha_eff, (float)beta);
+        cdone += nr;
+    }
+    for (int c0 = cdone; c0 < nrhs; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NR = nr == 1 ? 1 : 4;
         const float* a_c = a + (size_t)c0 * lda;

@@ -264,6 +264,126 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
     }
 }
 
+// ---- many right-hand sides: mul!(B, G, A) with A m x p, p >= 12 (src/gramian.jl:89-99) -----------------------------------------
+// The accumulation B[i, :] += E[i, j] A[j, :] is a GEMM with the freshly evaluated 32 x 32 tile E as one factor, so it runs on the
+// matrix cores too — in fp32, bit-for-bit the fmaf chain of the VALU form: v_mfma_f32_32x32x2_f32.  The first MFMA is issued with
+// its operands swapped (column fragments as A, row fragments as B), so the tile comes out TRANSPOSED: lane (i, h) holds, in
+// register v, the entry for row i and column j = 8 (v / 4) + 4 h + v % 4 — exactly the B operand E^T[k = h][n = i] of step v of
+//     acc[c][i] += sum_{k = 0, 1} A^T[c][j(v, k)] * E^T[j(v, k)][i]            (32 right-hand sides c per accumulator tile),
+// whose A operand — lane (c, h): a[j(v, h)][c] — is pre-packed per MVM in that order (mfma_pack_rhs_kernel: 16 floats per lane and
+// tile, contiguous).  16 fp32 MFMAs (64 cycles each) per column tile and 32 right-hand sides against 16 x 32 v_fma_f32 (64 cycles per
+// FOUR right-hand sides) in dense_mfma_gen_kernel<.., NR = 4>, which also re-evaluates the kernel once per four.
+// One wave per workgroup, one row tile, NB = 1 or 2 blocks of 32 right-hand sides per pass.
+template <int FAM, int K2, int NB>
+__global__ __launch_bounds__(64) void dense_mfma_mrhs_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+                                                             const uint4* __restrict__ PB, const float* __restrict__ AP, int64_t ntile,
+                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
+                                                             int64_t tchunk, float alpha, float beta, int32_t final_store,
+                                                             const float* __restrict__ Cn, const typename ParamsOf<FAM, float>::type kp) {
+    constexpr bool ISO = fam_is_iso<FAM>;
+    const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const float g = kp.gamma;
+    Frag a[K2];
+    {
+        int64_t row = i0 + t;
+        if (row >= n) row = n - 1;                               // clamp: computed, never stored
+        const float* __restrict__ xr = X + row * (int64_t)d;
+        float nx = 0.0f;
+        if constexpr (ISO)
+            for (int cc = 0; cc < d; ++cc) { const float xc = g * (xr[cc] - Cn[cc]); nx = __builtin_fmaf(xc, xc, nx); }
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) {
+            const int c = 2 * mm + h;
+            uint4 f = make_uint4(0, 0, 0, 0);
+            if (c < d) {
+                unsigned x1, x2, x3;
+                split3(ISO ? g * (xr[c] - Cn[c]) : g * xr[c], x1, x2, x3);
+                f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+            } else if (ISO && c == d) {
+                unsigned n1, n2, n3;
+                split3(nx, n1, n2, n3);
+                f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
+            }
+            a[mm].u = f;
+        }
+    }
+    const int64_t T0 = (int64_t)blockIdx.y * tchunk;
+    const int64_t T1 = (T0 + tchunk < ntile) ? (T0 + tchunk) : ntile;
+    const int nt = (int)(T1 - T0);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
+    const float4* __restrict__ abase = (const float4*)AP + (T0 * NB) * 64 * 4;      // [tile][block][lane][16 floats]
+    struct Tile { Frag f[K2]; float4 w[NB][4]; };
+    auto load_tile = [&](int ti, Tile& tl) {
+        const int tc = ti < nt ? ti : nt - 1;
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) tl.f[mm].u = pbase[(tc * K2 + mm) * 64 + l];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl.w[b][q] = abase[((tc * NB + b) * 64 + l) * 4 + q];
+    };
+    auto process = [&](const Tile& tl) {
+        f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl.f[mm].v, a[mm].v, D, 0, 0, 0);   // transposed tile
+        float kv[16];
+        if constexpr (fam_is_expr<FAM>) {
+            float sv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v];
+            expr_value_block<float, ISO, 16>(sv, kp, kv);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float s = D[v];
+                if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);
+                float k1 = Phi<FAM, float, mfma_folded<FAM>>::eval(s, kp);
+                if (kp.power != 1) k1 = ipow(k1, kp.power);
+                kv[v] = k1;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float4 wq = tl.w[b][v >> 2];
+                const float wv = (v & 3) == 0 ? wq.x : ((v & 3) == 1 ? wq.y : ((v & 3) == 2 ? wq.z : wq.w));
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, kv[v], acc[b], 0, 0, 0);
+            }
+    };
+    Tile t0, t1;
+    load_tile(0, t0);
+    for (int ti = 0; ti < nt; ti += 2) {
+        load_tile(ti + 1, t1);
+        process(t0);
+        load_tile(ti + 2, t0);
+        if (ti + 1 < nt) process(t1);
+    }
+    // acc[b][v]: lane (i = t, h), right-hand side c = 32 b + 8 (v / 4) + 4 h + v % 4
+    const int64_t i = i0 + t;
+    if (i >= n) return;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int c = 32 * b + 8 * (v >> 2) + 4 * h + (v & 3);
+            if (final_store) {
+                if (c < nrhs) {
+                    float* yp = out + i + (int64_t)c * ldy;
+                    float r = alpha * acc[b][v];
+                    if (beta != 0.0f) r = __builtin_fmaf(beta, *yp, r);
+                    *yp = r;
+                }
+            } else {
+                out[((int64_t)blockIdx.y * (32 * NB) + c) * npad + i] = acc[b][v];
+            }
+        }
+}
+
 // ---- symmetric Gramians: upper triangle once (design notes: dense_mfma.hip, "Symmetric Gramian") ----------------------------
 // FAM = FAM_EQFAST: the EQ form of dense_mfma.hip (exponent straight from the MFMA, norms in the weights); any other family:
 // the generic form above (the MFMA yields the profile argument s, the norms ride in a pseudo-coordinate, weights are a_j).
@@ -652,6 +772,7 @@ struct MfmaArgs {
     const float* Cn = nullptr;   // common centre of isotropic kernels (dense_mvm.hpp)
     // symmetric form (dense_mfma_sym_kernel): row-sum slab R, column-sum slab S, the explicit workgroup list
     int32_t lds = 0;             // 1: dense_mfma_gen_kernel<.., LDS = 2> (grid.x counts workgroups of 4 waves)
+    int32_t mrhs = 0;            // 1 / 2: dense_mfma_mrhs_kernel with that many blocks of 32 right-hand sides (W = the packed A operands)
     int32_t sym = 0;
     float* R = nullptr; float* S = nullptr;
     const int32_t* wgmap = nullptr;
@@ -691,9 +812,18 @@ static int mfma_sym_one(const MfmaArgs& a) {
     return COVGRAM_OK;
 }
 
+template <int FAM, int K2, int NB>
+static int mfma_mrhs_one(const MfmaArgs& a) {
+    hipLaunchKernelGGL((dense_mfma_mrhs_kernel<FAM, K2, NB>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out, a.npad,
+                       a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
+    return COVGRAM_OK;
+}
+
 template <int FAM, int K2>
 static int mfma_gen_K(const MfmaArgs& a, bool query) {
     if (a.sym) return mfma_sym_one<FAM, K2>(a);
+    if (a.mrhs == 1) return mfma_mrhs_one<FAM, K2, 1>(a);
+    if (a.mrhs == 2) return mfma_mrhs_one<FAM, K2, 2>(a);
     if (a.NR == 4) return mfma_gen_one<FAM, K2, 1, 4>(a, query);
     if constexpr (K2 <= 4) { if (a.RT == 2) return mfma_gen_one<FAM, K2, 2, 1>(a, query); }
     return mfma_gen_one<FAM, K2, 1, 1>(a, query);

@@ -49,8 +49,9 @@ def test_host_pointer_mvm_matrix_gradient(cg, oracle, ctx, dt):
     assert lib.covgram_points_info(hx, C.byref(nn), C.byref(dd), C.byref(tt)) == 0 and (nn.value, dd.value) == (n, d)
     spec = cg.device_spec(cg.Lengthscale(cg.MaternP(2), 0.8) * 1.7)
     ko = oracle.Kernel(oracle.MATERNP, p=2, lengthscale=0.8, scale=1.7)
-    # vector and 7-column matrix right-hand sides with leading dimensions larger than the extents
-    for nrhs in (1, 7):
+    # vector, 7-column and (fp32: fp32 matrix cores, dense_mfma_mrhs_kernel) 13- / 40- / 70-column right-hand sides, leading dimensions
+    # larger than the extents
+    for nrhs in (1, 7, 13, 40, 70):
         lda, ldy = m + 5, n + 3
         A = np.zeros((nrhs, lda), dtype=dt); A[:, :m] = rng.standard_normal((nrhs, m))          # column-major m x nrhs, lda
         Yo = np.zeros((nrhs, ldy), dtype=dt); Yo[:, :n] = rng.standard_normal((nrhs, n))

@@ -1516,3 +1516,30 @@ def test_fp64_exponential_entrywise(cg, oracle):
     ko = oracle.Kernel(oracle.EXP)
     ref_g = oracle.grad_mul(np.zeros(2), ko, x, y[1:], a.reshape(-1), 1.0, 0.0, np.float64)
     assert relerr(out, ref_g) <= 1e-14, relerr(out, ref_g)
+
+
+def test_many_right_hand_sides_on_the_matrix_cores(cg, oracle):
+    """mul!(B, G, A) with p >= 12 columns (src/gramian.jl:89-99) runs the accumulation as an fp32 GEMM on the matrix cores
+    (dense_mfma_mrhs_kernel: the evaluated tile, transposed, is the B operand of v_mfma_f32_32x32x2_f32): ragged n / m / p, several
+    profiles, alpha / beta, against the oracle column by column and against the four-at-a-time VALU form (option mfma_mrhs = 0)."""
+    rng = np.random.default_rng(31)
+    try:
+        for (kern, ko, n, m, d, p) in ((cg.EQ(), oracle.Kernel(oracle.EQ), 1000, 1537, 3, 13), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 777, 2050, 5, 40),
+                                       (cg.RQ(1.5), oracle.Kernel(oracle.RQ, param=1.5), 2049, 999, 8, 70), (cg.Dot() ** 2, oracle.Kernel(oracle.DOT, power=2), 515, 1025, 4, 33),
+                                       (cg.Lengthscale(cg.EQ(), 0.8) * cg.Cauchy(), None, 640, 700, 3, 12), (cg.EQ(), oracle.Kernel(oracle.EQ), 300, 4100, 20, 130)):
+            X = (rng.standard_normal((n, d)) * 0.7).astype(np.float32); Y = (rng.standard_normal((m, d)) * 0.7).astype(np.float32)
+            A = rng.standard_normal((m, p)).astype(np.float32); B0 = rng.standard_normal((n, p)).astype(np.float32)
+            G = cg.gramian(kern, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+            outs = {}
+            for opt in (0, -1):
+                cg.set_option("mfma_mrhs", opt)
+                Bd = torch.from_numpy(B0.copy()).cuda()
+                cg.mul_(Bd, G, torch.from_numpy(A).cuda(), 0.6, -1.2)
+                outs[opt] = Bd.cpu().numpy()
+            assert cg.get_info("last_dense_path") == 2
+            assert relerr(outs[-1], outs[0]) <= 1e-5, (type(kern).__name__, p, relerr(outs[-1], outs[0]))
+            if ko is not None:
+                ref = 0.6 * np.stack([oracle.mul(None, ko, X, Y, A[:, c], dtype=np.float32) for c in range(p)], 1) - 1.2 * B0
+                assert relerr(outs[-1], ref) <= 1e-5, (type(kern).__name__, p, relerr(outs[-1], ref))
+    finally:
+        cg.set_option("mfma_mrhs", -1)
