@@ -174,6 +174,7 @@ struct covgram_ctx {
     int64_t mfma_stamp = 0;      // 1: the general matrix-core EQ kernel runs its clock-stamping diagnostic build (info key "last_clock_khz")
     void* stamp_buf = nullptr;   // [workgroup][4]: s_memtime / s_memrealtime before and after the column loop
     size_t stamp_cap = 0, stamp_count = 0;
+    int64_t matrix_variant = 0;     // Matrix(G): 0 = rows in registers + 64-column strips (d <= 64), 1 = the generic entry-by-entry kernel
     int64_t mfma_mrhs = -1;         // matrix right-hand sides on the fp32 matrix cores (dense_mfma_mrhs_kernel): -1 from 12 columns, 0 never, 1 from 2
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
