@@ -1526,7 +1526,9 @@ def test_many_right_hand_sides_on_the_matrix_cores(cg, oracle):
     try:
         for (kern, ko, n, m, d, p) in ((cg.EQ(), oracle.Kernel(oracle.EQ), 1000, 1537, 3, 13), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 777, 2050, 5, 40),
                                        (cg.RQ(1.5), oracle.Kernel(oracle.RQ, param=1.5), 2049, 999, 8, 70), (cg.Dot() ** 2, oracle.Kernel(oracle.DOT, power=2), 515, 1025, 4, 33),
-                                       (cg.Lengthscale(cg.EQ(), 0.8) * cg.Cauchy(), None, 640, 700, 3, 12), (cg.EQ(), oracle.Kernel(oracle.EQ), 300, 4100, 20, 130)):
+                                       (cg.Lengthscale(cg.EQ(), 0.8) * cg.Cauchy(), None, 640, 700, 3, 12), (cg.EQ(), oracle.Kernel(oracle.EQ), 300, 4100, 20, 130),
+                                       (cg.EQ(), oracle.Kernel(oracle.EQ), 5, 7, 3, 13), (cg.EQ(), oracle.Kernel(oracle.EQ), 1, 1, 1, 12), (cg.EQ(), oracle.Kernel(oracle.EQ), 33, 1000, 8, 75),
+                                       (cg.EQ(), oracle.Kernel(oracle.EQ), 64, 64, 3, 65)):
             X = (rng.standard_normal((n, d)) * 0.7).astype(np.float32); Y = (rng.standard_normal((m, d)) * 0.7).astype(np.float32)
             A = rng.standard_normal((m, p)).astype(np.float32); B0 = rng.standard_normal((n, p)).astype(np.float32)
             G = cg.gramian(kern, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
