@@ -175,7 +175,7 @@ struct covgram_ctx {
     void* stamp_buf = nullptr;   // [workgroup][4]: s_memtime / s_memrealtime before and after the column loop
     size_t stamp_cap = 0, stamp_count = 0;
     int64_t matrix_variant = 0;     // Matrix(G): 0 = rows in registers + 64-column strips (d <= 64), 1 = the generic entry-by-entry kernel
-    int64_t mfma_mrhs = -1;         // matrix right-hand sides on the fp32 matrix cores (dense_mfma_mrhs_kernel): -1 from 12 columns, 0 never, 1 from 2
+    int64_t mfma_mrhs = -1;         // matrix right-hand sides on the fp32 matrix cores (dense_mfma_mrhs_kernel): -1 from 5 (9: cheap profiles, d <= 3) columns, 0 never, 1 from 2
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches

@@ -920,9 +920,14 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
     mfma_launch_fn launch = mfma_launcher(hk.tu_family);
     const double alpha_eff = alpha * hk.kp.scale;
     int cdone = 0;
-    // many right-hand sides: blocks of up to 64 on the fp32 matrix cores (dense_mfma_mrhs_kernel), from 12 columns on —
+    // many right-hand sides: blocks of up to 64 on the fp32 matrix cores (dense_mfma_mrhs_kernel).  Its time is flat up to 32 columns
+    // (n = 32768: 0.76 ms EQ, 0.86 ms MaternP(2)); the VALU form steps up every four columns (EQ d = 3: 0.29 / 0.56 / 0.81 ms at 4 / 8 /
+    // 12; MaternP(2): 0.48 / 0.94 / 1.40): the crossover is 9 columns for the cheap profiles at d <= 3, 5 otherwise —
     // option "mfma_mrhs": -1 this rule, 0 never, 1 from 2 columns (tests)
-    while (nrhs - cdone >= (ctx->mfma_mrhs == 1 ? 2 : 12) && ctx->mfma_mrhs != 0) {
+    const bool cheap = K2 <= 2 && (hk.tu_family == COVGRAM_EQ || hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ ||
+                                   hk.tu_family == COVGRAM_DOT || hk.tu_family == COVGRAM_EXPDOT);
+    const int mrhs_min = ctx->mfma_mrhs == 1 ? 2 : (cheap ? 9 : 5);
+    while (nrhs - cdone >= mrhs_min && ctx->mfma_mrhs != 0) {
         const int c0 = cdone;
         const int nr = std::min(64, nrhs - c0);
         const int NB = nr > 32 ? 2 : 1;

@@ -139,7 +139,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * matrix keeps the row kernel's spectrum copy as reals, 0 = always complex), "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
  * "matrix_variant" (covgram_matrix: 0 = rows in registers, 64-column strips — d <= 64 —, 1 = the generic entry-by-entry kernel),
- * "mfma_mrhs" (matrix right-hand sides on the fp32 matrix cores, dense_mfma_mrhs_kernel: -1 = from 12 columns, 0 = never — four
+ * "mfma_mrhs" (matrix right-hand sides on the fp32 matrix cores, dense_mfma_mrhs_kernel: -1 = from 5 columns (9 for the cheap profiles at d <= 3), 0 = never — four
  * columns at a time on the VALU —, 1 = from 2 columns),
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
  * -1 = from n = 12500 ... 18000 by the profile's cost, 0 = never, 1 = always),
