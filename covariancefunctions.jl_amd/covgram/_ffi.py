@@ -103,6 +103,7 @@ PROTOTYPES = {
     "covgram_toeplitz_create": (C.c_int, [_P, C.POINTER(_P), _P, _P, _I64, _I64, _I32, _I32, _I32]),
     "covgram_toeplitz_mvm": (C.c_int, [_P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_destroy": (C.c_int, [_P]),
+    "covgram_cg_step": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
     "covgram_toeplitz_durbin": (C.c_int, [_P, _P, _I64, _P, _I32, _I32]),
     "covgram_toeplitz_levinson": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32]),
     "covgram_toeplitz_trench": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32]),

@@ -1,0 +1,88 @@
+// covgram — the vector recurrences of one conjugate-gradient iteration in three launches.
+//
+// The reference solves G \ b with IterativeSolvers.cg! (src/gramian.jl:229-238, src/lazy_linear_algebra.jl:135-144); the package
+// is a dependency (Manifest.toml: IterativeSolvers 0.9.2), not part of /root/reference.  Its published iteration, restated:
+//     alpha = rho / (p . A p);   x += alpha p;   r -= alpha A p;   rho' = r . r;   p = r + (rho' / rho) p
+// (no preconditioner).  Done with library vector operations that is eleven small launches per iteration — 45 us on a GPU, next to
+// a 40 us MVM at n = 16384 (tools/cg_rate.py).  Here: three launches, every scalar stays on the device, sums in a fixed order.
+#include "profiles.hpp"
+
+namespace covgram {
+
+constexpr int CG_BLOCKS = 256, CG_THREADS = 256;
+
+template <typename T>
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < CG_THREADS / 64; ++i) t += sh[i];          // every thread: the same fixed-order total
+    __syncthreads();
+    return t;
+}
+
+// scal[0] <- scal[1] (the rho committed by the previous step);  partA[b] = sum over block b's elements of p . Ap
+template <typename T>
+__global__ __launch_bounds__(CG_THREADS) void cg_dot_kernel(int64_t n, const T* __restrict__ p, const T* __restrict__ Ap, T* __restrict__ scal) {
+    __shared__ double sh[CG_THREADS / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = scal[1];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) s += (double)p[i] * (double)Ap[i];
+    const double t = block_sum<T>(s, sh);
+    if (threadIdx.x == 0) scal[2 + blockIdx.x] = (T)t;
+}
+
+// alpha = scal[0] / sum(partA);  x += alpha p;  r -= alpha Ap;  partB[b] = sum of r^2 over block b's elements
+template <typename T>
+__global__ __launch_bounds__(CG_THREADS) void cg_update_kernel(int64_t n, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                                                               const T* __restrict__ Ap, T* __restrict__ scal, int nblocks) {
+    __shared__ double sh[CG_THREADS / 64];
+    const double pAp = block_sum<T>(threadIdx.x < nblocks ? (double)scal[2 + threadIdx.x] : 0.0, sh);
+    const T alpha = (T)((double)scal[0] / pAp);
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) {
+        x[i] = cg_fma(alpha, p[i], x[i]);
+        const T ri = cg_fma(-alpha, Ap[i], r[i]);
+        r[i] = ri;
+        s += (double)ri * (double)ri;
+    }
+    const double t = block_sum<T>(s, sh);
+    if (threadIdx.x == 0) scal[2 + CG_BLOCKS + blockIdx.x] = (T)t;
+}
+
+// rho' = sum(partB);  p = r + (rho' / scal[0]) p;  scal[1] <- rho'
+template <typename T>
+__global__ __launch_bounds__(CG_THREADS) void cg_direction_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ r, T* __restrict__ scal, int nblocks) {
+    __shared__ double sh[CG_THREADS / 64];
+    const double rho = block_sum<T>(threadIdx.x < nblocks ? (double)scal[2 + CG_BLOCKS + threadIdx.x] : 0.0, sh);
+    const T beta = (T)(rho / (double)scal[0]);
+    for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) p[i] = cg_fma(beta, p[i], r[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = (T)rho;
+}
+
+template <typename T>
+static void cg_step_T(hipStream_t st, int64_t n, T* x, T* r, T* p, const T* Ap, T* scal) {
+    const int nb = (int)std::min<int64_t>(CG_BLOCKS, std::max<int64_t>(1, (n + 4 * CG_THREADS - 1) / (4 * CG_THREADS)));
+    hipLaunchKernelGGL(cg_dot_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, (const T*)p, Ap, scal);
+    hipLaunchKernelGGL(cg_update_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, x, r, (const T*)p, Ap, scal, nb);
+    hipLaunchKernelGGL(cg_direction_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, p, (const T*)r, scal, nb);
+}
+
+}  // namespace covgram
+
+using namespace covgram;
+
+extern "C" int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal) {
+    CG_REQUIRE(ctx != nullptr, COVGRAM_EINVAL, "ctx is NULL");
+    CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "dtype must be COVGRAM_F32 or COVGRAM_F64");
+    CG_REQUIRE(n >= 0, COVGRAM_EINVAL, "n must be >= 0");
+    if (n == 0) return COVGRAM_OK;
+    CG_REQUIRE(x && r && p && Ap && scal, COVGRAM_EINVAL, "NULL vector");
+    CG_DEVICE(ctx);
+    if (dtype == COVGRAM_F32) cg_step_T<float>(ctx->stream, n, (float*)x, (float*)r, (float*)p, (const float*)Ap, (float*)scal);
+    else cg_step_T<double>(ctx->stream, n, (double*)x, (double*)r, (double*)p, (const double*)Ap, (double*)scal);
+    CG_CHECK_HIP(hipGetLastError());
+    return COVGRAM_OK;
+}

@@ -224,6 +224,14 @@ int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y,
 int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, int64_t n, void* x, int32_t dtype, int32_t loc);
 int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B, int64_t ldb, int32_t dtype, int32_t loc);
 
+/* The vector work of ONE conjugate-gradient iteration, after the caller's Ap = A p (covgram_mvm & co.) — the recurrences of
+ * IterativeSolvers.cg! 0.9.2, the reference's caller of mul! for `G \ b` (src/gramian.jl:229-238, src/lazy_linear_algebra.jl:135-144),
+ * without preconditioner:   alpha = rho / (p . Ap);  x += alpha p;  r -= alpha Ap;  rho' = r . r;  p = r + (rho' / rho) p.
+ * Three launches, all scalars on the device, sums in a fixed order.  Device pointers only.  scal: 2 + 512 elements of the vectors'
+ * type; the caller sets scal[1] = r . r before the first step; after a step scal[1] = rho' (= |r|^2: the residual test) and
+ * scal[0] = the rho it divided by.  The rest of scal is scratch. */
+int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal);
+
 /* y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) a + beta * y, standard Kronecker order (F_1 = slowest index).
  * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc). */
 int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols,

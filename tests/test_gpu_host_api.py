@@ -179,3 +179,39 @@ def test_empty_and_degenerate_inputs(cg, oracle):
     assert relerr((Gm @ At).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.CAUCHY), X, X, A)) <= 1e-12
     one = torch.randn(1, 3, device=dev, dtype=torch.float32)
     assert abs(float((cg.gramian(cg.EQ(), one) @ torch.ones(1, device=dev))[0]) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_cg_step_is_the_cg_recurrence(cg, ctx, dt):
+    """covgram_cg_step against the recurrences of IterativeSolvers.cg! written out in numpy (src/gramian.jl:229-238 calls it):
+    alpha = rho / (p . Ap); x += alpha p; r -= alpha Ap; rho' = r . r; p = r + (rho' / rho) p — two consecutive steps (the
+    second divides by the rho the first committed), ragged n, and n = 0."""
+    lib, f = cg._ffi.lib(), cg._ffi
+    DP = lambda t: f._P(t.data_ptr())                      # device pointers (this entry point takes no host memory)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    tol = 2e-6 if dt == np.float32 else 1e-14
+    rng = np.random.default_rng(17)
+    for n in (1, 777, 70001):
+        x, r, p = (rng.standard_normal(n).astype(dt) for _ in range(3))
+        xd, rd, pd = (torch.from_numpy(v.copy()).cuda() for v in (x, r, p))
+        scal = torch.zeros(2 + 512, dtype=tdt, device="cuda")
+        scal[1] = torch.dot(rd, rd)
+        x64, r64, p64 = (v.astype(np.float64) for v in (x, r, p))
+        rho = float(r64 @ r64)
+        for step in range(2):
+            Ap = rng.standard_normal(n).astype(dt)
+            Apd = torch.from_numpy(Ap).cuda()
+            torch.cuda.synchronize()
+            f.check(lib.covgram_cg_step(ctx, n, f.F32 if dt == np.float32 else f.F64, DP(xd), DP(rd), DP(pd), DP(Apd), DP(scal)))
+            torch.cuda.synchronize()
+            Ap64 = Ap.astype(np.float64)
+            alpha = rho / float(p64 @ Ap64)
+            x64 = x64 + alpha * p64; r64 = r64 - alpha * Ap64
+            rho_new = float(r64 @ r64)
+            p64 = r64 + (rho_new / rho) * p64
+            assert abs(float(scal[0]) - rho) <= tol * abs(rho) * 10 and abs(float(scal[1]) - rho_new) <= tol * abs(rho_new) * 10
+            rho = rho_new
+            for got, want in ((xd, x64), (rd, r64), (pd, p64)):
+                assert relerr(got.cpu().numpy(), want) <= tol * 50, (n, step, relerr(got.cpu().numpy(), want))
+    f.check(lib.covgram_cg_step(ctx, 0, f.F64, None, None, None, None, None))
+    assert lib.covgram_cg_step(ctx, 5, 7, None, None, None, None, None) == f.EINVAL
