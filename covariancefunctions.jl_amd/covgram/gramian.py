@@ -720,6 +720,12 @@ class LazyMatrixSum(LazyOperator):
                 A.mul_(y, a, alpha, b)
             else:   # Diagonal given as a 1-D tensor, or a dense matrix
                 A = torch.as_tensor(A, dtype=self.dtype, device=self.device)
+                if A.dim() == 1 and b != 0:                   # the noise term of G + sigma^2 I inside a Krylov loop: ONE launch
+                    if b != 1:
+                        y.mul_(b)
+                    y.addcmul_(A if a.dim() == 1 else A[:, None], a, value=alpha)
+                    first = False
+                    continue
                 t = (A * a if a.dim() == 1 else A[:, None] * a) if A.dim() == 1 else A @ a
                 if b == 0:
                     y.copy_(alpha * t)
