@@ -951,10 +951,7 @@ static void launch_colfft(covgram_toeplitz* Tz, const FastTables& t, const T* sr
 // zbuf <- permuted packed spectrum of the real signal src[0..len) (zero beyond), length N
 template <typename T>
 static int fast_forward(covgram_toeplitz* Tz, const T* src, int64_t len) {
-    using V = typename V2T<T>::type;
-    constexpr int TW = colfft_tw<T>();
     const FastTables t = table_ptrs(Tz);
-    hipStream_t st = Tz->ctx->stream;
     launch_colfft<T, false>(Tz, t, src, len, (T*)nullptr, (int64_t)0, (T)0, (T)0);
     void* io[1] = {Tz->zbuf};
     CG_CHECK_FFT(rocfft_execute(Tz->bfwd, io, nullptr, Tz->info));
