@@ -986,11 +986,11 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     rc = make_host_kernel(k, dtype, true, &hk);
     if (rc) return rc;
     // lane-owned rows up to d = 64 (fp32) / 48 (fp64) (grad_mvm.hpp); wider rows take the two-kernel panel path (grad_wide.hpp)
-    // composites take the panel path as well: its coefficient kernel evaluates their jets per block of column groups
-    // (factor-outer) where the lane-per-row kernel interprets them once per pair — C4-shaped EQ*RQ: 8.9 vs 16.1 ms
-    // (tools/gradcomp_bench.py); option grad_keep_r = 0 / 1 keeps them on the lane-per-row kernel
-    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2 ||
-                      (hk.tu_family >= COVGRAM_NFAMILY && ctx->grad_keep_r < 0 && d >= 8);
+    // (Round 1 sent composites with d >= 8 to the panel path too: the lane-per-row kernel, interpreting their jets once per pair
+    // at 3 waves per SIMD, spilled — C4-shaped EQ*RQ 16.1 ms against 8.9.  With the registers the interpreter needs — two waves per
+    // SIMD for fp64, grad_temp_regs — it is the faster one at every d it reaches: tools/compgrad_ab.py, panel / lane-per-row:
+    // fp64 EQ*RQ d = 32 12.2 / 10.5 ms, d = 48 17.9 / 13.1, MaternP(2)*EQ d = 8 10.1 / 4.1; fp32 d = 32 3.9 / 1.7, d = 8 3.5 / 1.2.)
+    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(hk.tu_family);
     CG_DEVICE(ctx);

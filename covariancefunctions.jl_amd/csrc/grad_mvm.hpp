@@ -44,13 +44,13 @@ constexpr int GRAD_THREADS = 256;   // largest workgroup; rows are padded to thi
 // (tools/c4_lib_ab.py, profiles/r02_c4_exp_ab.txt).
 inline int grad_waves_per_simd(int elem_size, int D, int fam) {
     const int state = 2 * D * (elem_size / 4);
-    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP)) ? 110 : 40;
+    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP || fam >= COVGRAM_NFAMILY)) ? 110 : 40;
     const int w = 512 / (state + temps);
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 inline int grad_block_threads(int elem_size, int D, int fam) {
     const int state = 2 * D * (elem_size / 4);
-    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP)) ? 110 : 40;
+    const int temps = (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP || fam >= COVGRAM_NFAMILY)) ? 110 : 40;
     return (512 / (state + temps) >= 3) ? GRAD_THREADS : 64;
 }
 
@@ -66,7 +66,7 @@ struct GradChunk {
 // registers of temporaries they spilled to scratch inside the column loop (RQ at the C4 shape: 6.0 ms, 40 VGPRs spilled,
 // every reload a serial vmcnt(0) wait) — those families get 110, i.e. one wave per SIMD less and no spills.
 template <typename T, int FAM> constexpr int grad_temp_regs() {
-    return (sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP)) ? 110 : 40;
+    return (sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP || fam_is_expr<FAM>)) ? 110 : 40;
 }
 template <typename T, int D, bool KEEP_R, int FAM = COVGRAM_EQ>
 constexpr int grad_min_waves() {
@@ -349,6 +349,9 @@ static int launch_grad_one(const GradArgs& a) {
     // measured (profiles/r01_gradbench_sweep_v3.txt): keeping r wins only while it costs no occupancy that matters —
     // fp32 d <= 32 and fp64 d <= 16; beyond that the recomputing variant's extra wave per SIMD is worth more than a flop per dim
     bool keep = CAN_KEEP && (W3 <= 100);
+    // composites (per-pair interpreter): keeping r pays only in fp32 at small d (tools/compgrad_ab.py: fp64 d = 8 7.35 ms with r kept,
+    // 4.08 without; fp32 d = 32 2.06 / 1.69, d = 8 1.07 / 1.17)
+    if constexpr (fam_is_expr<FAM>) keep = keep && sizeof(T) == 4 && D <= 16;
     if (a.keep_r == 0) keep = false;
     if (a.keep_r == 1) keep = CAN_KEEP;
     const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
