@@ -990,7 +990,13 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     // at 3 waves per SIMD, spilled — C4-shaped EQ*RQ 16.1 ms against 8.9.  With the registers the interpreter needs — two waves per
     // SIMD for fp64, grad_temp_regs — it is the faster one at every d it reaches: tools/compgrad_ab.py, panel / lane-per-row:
     // fp64 EQ*RQ d = 32 12.2 / 10.5 ms, d = 48 17.9 / 13.1, MaternP(2)*EQ d = 8 10.1 / 4.1; fp32 d = 32 3.9 / 1.7, d = 8 3.5 / 1.2.)
-    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2;
+    bool heavy_factor = false;                                       // a composite with a Matern(nu) factor: the lane-per-row interpreter is built without it
+    if (hk.tu_family >= COVGRAM_NFAMILY) {
+        int nf = 0;
+        for (int t = 0; t < hk.nterms; ++t) nf += hk.nfac[t];
+        for (int f = 0; f < nf; ++f) heavy_factor = heavy_factor || hk.ffam[f] == COVGRAM_MATERN;
+    }
+    const bool wide = d > (dtype == COVGRAM_F64 ? 48 : 64) || ctx->grad_keep_r == 2 || heavy_factor;
     const int D = wide ? ((d + 31) / 32) * 32 : pad_dim(d);
     grad_launch_fn launch = grad_launcher(hk.tu_family);
     CG_DEVICE(ctx);

@@ -508,7 +508,9 @@ __device__ __forceinline__ void power_jet(int q, T& v, T& d1, T& d2) {
     v = vq1 * v;
 }
 
-template <typename T>
+// LIGHT: without Matern(nu) — its Bessel series, inlined into the per-pair interpreter loop of the lane-per-row gradient kernel, costs
+// every composite registers and instruction cache; composites that do contain it take the panel path (api.hip)
+template <typename T, bool LIGHT = false>
 __device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
     switch (family) {
         case COVGRAM_EQ: DPhi<COVGRAM_EQ, T>::eval(s, kp, v, d1, d2); break;
@@ -520,7 +522,7 @@ __device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T
         case COVGRAM_MATERNP: DPhi<COVGRAM_MATERNP, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_DOT: DPhi<COVGRAM_DOT, T>::eval(s, kp, v, d1, d2); break;
         case COVGRAM_EXPDOT: DPhi<COVGRAM_EXPDOT, T>::eval(s, kp, v, d1, d2); break;
-        case COVGRAM_MATERN: DPhi<COVGRAM_MATERN, T>::eval(s, kp, v, d1, d2); break;
+        case COVGRAM_MATERN: if constexpr (!LIGHT) { DPhi<COVGRAM_MATERN, T>::eval(s, kp, v, d1, d2); } else { v = (T)1; d1 = (T)0; d2 = (T)0; } break;
         case COVGRAM_ASINDOT: DPhi<COVGRAM_ASINDOT, T>::eval(s, kp, v, d1, d2); break;
         default: v = (T)1; d1 = (T)0; d2 = (T)0; break;   // COVGRAM_CONSTANT
     }
@@ -528,7 +530,7 @@ __device__ __forceinline__ void jet_any(int family, T s, const KParams<T>& kp, T
 }
 
 // composite jet w.r.t. the raw s: chain rule through each factor's 1/l^2, product rule within a term, sum over terms
-template <typename T, bool ISO>
+template <typename T, bool ISO, bool LIGHT = false>
 __device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) {
     v = (T)0; d1 = (T)0; d2 = (T)0;
     int fi = 0;
@@ -538,7 +540,7 @@ __device__ __forceinline__ void expr_jet(T s, const ExprParams<T>& ep, T& v, T& 
             const KParams<T>& q = ep.f[fi];
             const T g2 = ISO ? q.gamma2 : (T)1;
             T fv, f1, f2;
-            jet_any<T>(ep.fam[fi], s * g2, q, fv, f1, f2);
+            jet_any<T, LIGHT>(ep.fam[fi], s * g2, q, fv, f1, f2);
             f1 *= g2; f2 *= g2 * g2;
             p2 = p2 * fv + (T)2 * p1 * f1 + p0 * f2;
             p1 = p1 * fv + p0 * f1;
@@ -641,11 +643,11 @@ __device__ __forceinline__ void expr_jet_block(const typename Pk<T>::V (&s)[BG],
 
 template <typename T>
 struct DPhi<FAM_EXPR_ISO, T> {
-    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, true>(s, ep, v, d1, d2); }
+    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, true, true>(s, ep, v, d1, d2); }
 };
 template <typename T>
 struct DPhi<FAM_EXPR_DOT, T> {
-    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, false>(s, ep, v, d1, d2); }
+    static __device__ __forceinline__ void eval(T s, const ExprParams<T>& ep, T& v, T& d1, T& d2) { expr_jet<T, false, true>(s, ep, v, d1, d2); }
 };
 
 // POW = false compiles the Power chain rule away: the gradient kernel's software pipeline needs the derivative
