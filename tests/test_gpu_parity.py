@@ -1545,3 +1545,31 @@ def test_many_right_hand_sides_on_the_matrix_cores(cg, oracle):
                 assert relerr(outs[-1], ref) <= 1e-5, (type(kern).__name__, p, relerr(outs[-1], ref))
     finally:
         cg.set_option("mfma_mrhs", -1)
+
+
+def test_fp64_rational_quadratic_entrywise(cg, oracle):
+    """The library's own fp64 power for the rational-quadratic profile (csrc/profiles.hpp rq_pow: log2 by frexp + atanh series, then
+    the library's exp2) ENTRY BY ENTRY against mpmath-free numpy over the range of its argument and several alpha: Matrix(G) on collinear
+    points, relative error <= (4 + alpha log2 u) ulp, u = 1 exactly 1, NaN / inf; and the gradient MVM against the oracle."""
+    m = 4000
+    s = np.concatenate([np.linspace(0.0, 1e-6, 500), np.linspace(1e-6, 50.0, 2000), np.geomspace(50.0, 1e12, 1500)])
+    y = np.zeros((m, 1)); y[:, 0] = np.sqrt(s)
+    x = np.zeros((1, 1))
+    s_exact = y[:, 0] ** 2
+    for alpha in (0.37, 1.0, 2.5, 30.0):
+        got = cg.gramian(cg.RQ(alpha), torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()).to_dense().cpu().numpy()[0]
+        u = 1.0 + s_exact / (2.0 * alpha)
+        ref = np.exp(-alpha * np.log(u))                          # numpy's log / exp are correctly rounded to < 1 ulp each
+        ok = ref > 1e-300
+        err = np.max(np.abs(got[ok] / ref[ok] - 1.0))
+        # u^(-alpha) = exp2(-x), x = alpha log2 u: one rounding of x costs ln(2) |x| eps in the result (|x| <= ~1000 over the normal range)
+        assert err <= 2.3e-16 * (4 + alpha * np.max(np.log2(u[ok]))), (alpha, err, alpha * np.max(np.log2(u[ok])))
+        assert got[0] == 1.0 and not np.any(np.isnan(got))
+    yb = np.array([[0.0], [np.nan], [np.inf]])
+    gb = cg.gramian(cg.RQ(1.5), torch.from_numpy(x).cuda(), torch.from_numpy(yb).cuda()).to_dense().cpu().numpy()[0]
+    assert gb[0] == 1.0 and np.isnan(gb[1]) and gb[2] == 0.0
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((300, 5)); Y = rng.standard_normal((211, 5)) * 3.0; a = rng.standard_normal(211 * 5)
+    K = cg.gramian(cg.GradientKernel(cg.RQ(0.8)), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+    out = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
+    assert relerr(out, oracle.grad_mul(None, oracle.Kernel(oracle.RQ, param=0.8), X, Y, a, 1.0, 0.0, np.float64)) <= 1e-13
