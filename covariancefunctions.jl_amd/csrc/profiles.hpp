@@ -118,6 +118,13 @@ __device__ __forceinline__ double rq_pow(double u, double a) {
     return u <= 1.7e308 ? v : (u > 1.7e308 ? 0.0 : u);            // u = inf: 0; NaN: NaN
 }
 __device__ __forceinline__ float rq_pow(float u, float a) { return cg_pow(u, -a); }
+// s^g in fp64 for s >= 0, g > 0 (gamma-exponential profile: s^(gamma/2)); 0^g = 0, NaN propagates, inf^g = inf.  log2_ge1's
+// reduction is valid for every positive normal or denormal argument; exp2_scaled_nonpos takes either sign of the exponent.
+__device__ __forceinline__ double pow_pos(double s, double g) {
+    const double v = exp2_scaled_nonpos(log2_ge1(s), g, 0.0);
+    return (s > 0.0 && s <= 1.7e308) ? v : (s == 0.0 ? 0.0 : s);  // 0 -> 0, inf -> inf, NaN -> NaN
+}
+__device__ __forceinline__ float pow_pos(float s, float g) { return cg_pow(s, g); }
 
 __device__ __forceinline__ double eq_exp_neg_half(double s) { return exp2_scaled_nonpos(s, -0x1.71547652b82fep-1, -0x1.777d0ffda0d24p-57); }   // -log2(e)/2
 // exp(-t/2), t >= 0
@@ -151,7 +158,7 @@ template <typename T, bool F>
 struct Phi<COVGRAM_GAMMAEXP, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
         // s^(gamma/2); s == 0 -> 0 (gamma > 0) — log2(0) = -inf, exp2(-inf) = 0
-        T t = (kp.param == (T)0) ? (T)1 : cg_pow(s, kp.param);
+        T t = (kp.param == (T)0) ? (T)1 : pow_pos(s, kp.param);
         return cg_exp_neg_half(t);
     }
 };
@@ -428,7 +435,7 @@ template <typename T>
 struct DPhi<COVGRAM_GAMMAEXP, T> {
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
         T g = kp.param;                                   // gamma / 2
-        T sg = (g == (T)0) ? (T)1 : cg_pow(s, g);
+        T sg = (g == (T)0) ? (T)1 : pow_pos(s, g);
         T is = cg_rcp(s);
         v = cg_exp_neg_half(sg);
         T hg = (T)0.5 * g;

@@ -1573,3 +1573,38 @@ def test_fp64_rational_quadratic_entrywise(cg, oracle):
     K = cg.gramian(cg.GradientKernel(cg.RQ(0.8)), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
     out = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
     assert relerr(out, oracle.grad_mul(None, oracle.Kernel(oracle.RQ, param=0.8), X, Y, a, 1.0, 0.0, np.float64)) <= 1e-13
+
+
+def test_fp64_gamma_exponential_entrywise(cg, oracle):
+    """The library's own fp64 power for the gamma-exponential profile (csrc/profiles.hpp pow_pos: s^(gamma/2) by log2_ge1 + the
+    library's exp2, either sign of log2 s) ENTRY BY ENTRY against numpy over tiny, moderate and large s and several gamma: Matrix(G) on
+    collinear points; k(0) = 1 exactly, NaN propagates, inf gives 0; and the gradient MVM against the oracle
+    (src/stationary.jl:96-111: exp(-r^gamma / 2))."""
+    s = np.concatenate([[0.0], np.geomspace(1e-300, 1e-6, 800), np.linspace(1e-6, 40.0, 2000), np.geomspace(40.0, 1e6, 1200)])
+    m = len(s)
+    y = np.zeros((m, 1)); y[:, 0] = np.sqrt(s)
+    x = np.zeros((1, 1))
+    s_exact = y[:, 0] ** 2
+    for gamma in (0.3, 1.0, 1.3, 1.999, 2.0):
+        got = cg.gramian(cg.GammaExp(gamma), torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()).to_dense().cpu().numpy()[0]
+        with np.errstate(divide="ignore", over="ignore"):
+            t = np.where(s_exact > 0, np.exp(0.5 * gamma * np.log(np.where(s_exact > 0, s_exact, 1.0))), 0.0)
+        ref = np.exp(-0.5 * t)
+        ok = ref > 1e-300
+        lg = np.abs(0.5 * gamma * np.log2(np.where(s_exact > 0, s_exact, 1.0)))
+        # t = exp2(x), x = (gamma/2) log2 s rounded once: relative error ln(2) |x| eps in t, times t/2 in exp(-t/2)
+        bound = 2.3e-16 * (4 + (4 + lg) * np.maximum(0.5 * t, 1.0))
+        err = np.abs(got[ok] / ref[ok] - 1.0)
+        assert np.all(err <= bound[ok]), (gamma, float(np.max(err / bound[ok])))
+        assert got[0] == 1.0 and not np.any(np.isnan(got))
+    yb = np.array([[0.0], [np.nan], [np.inf]])
+    gb = cg.gramian(cg.GammaExp(1.5), torch.from_numpy(x).cuda(), torch.from_numpy(yb).cuda()).to_dense().cpu().numpy()[0]
+    assert gb[0] == 1.0 and np.isnan(gb[1]) and gb[2] == 0.0
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((300, 5)); Y = rng.standard_normal((211, 5)) * 2.0; a = rng.standard_normal(211 * 5)
+    K = cg.gramian(cg.GradientKernel(cg.GammaExp(1.4)), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+    out = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
+    assert relerr(out, oracle.grad_mul(None, oracle.Kernel(oracle.GAMMAEXP, param=1.4), X, Y, a, 1.0, 0.0, np.float64)) <= 1e-13
+    av = rng.standard_normal(211)
+    G = cg.gramian(cg.GammaExp(1.4), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+    assert relerr((G @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.GAMMAEXP, param=1.4), X, Y, av, dtype=np.float64)) <= 1e-13
