@@ -20,11 +20,34 @@ __device__ __forceinline__ double cg_exp(double x) { return exp(x); }
 __device__ __forceinline__ float cg_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ double cg_log2(double x) { return log2(x); }
 __device__ __forceinline__ float cg_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double cg_sqrt(double x) { return sqrt(x); }
+// fp64 square root, reciprocal and reciprocal square root WITHOUT the library's range scaling and correct-rounding steps (hipcc's
+// sqrt is 18 instructions: scale test + two ldexp around v_rsq_f64 and three refinements; 1.0 / x is the IEEE division sequence): the
+// hardware seed (v_rsq_f64 / v_rcp_f64, ~2^-23 relative, denormal arguments accepted) and a coupled Goldschmidt / cubic Newton
+// refinement to <= 1 ulp + one rounding, then ONE class test that hands back the seed's own answer where the refinement cannot be
+// formed (0, inf, NaN; a reciprocal that overflowed).  Arguments are squared distances / radii here: >= 0 or NaN.
+__device__ __forceinline__ double cg_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);                       // x = 0: inf, x = inf: 0, x < 0 or NaN: NaN
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);                                    // sqrt(x) to ~2^-45
+    h = __builtin_fma(h, r, h);                                    // 1 / (2 sqrt(x))
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return __builtin_amdgcn_class(y, 0x264) ? x : g;               // seed inf (x = 0) or 0 (x = inf): the argument itself (g is NaN there)
+}
 __device__ __forceinline__ float cg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double cg_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double cg_rcp(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);                    // 2^-23
+    const double r = __builtin_fma(y, __builtin_fma(e, e, e), y);  // y (1 + e + e^2): error e^3
+    return __builtin_amdgcn_class(y, 0x267) ? y : r;               // seed 0 / inf / NaN (x = inf, 0, a denormal whose reciprocal overflows, NaN)
+}
 __device__ __forceinline__ float cg_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double cg_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double cg_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);              // 1 - x y^2, 2^-22
+    const double r = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);   // y (1 + e/2 + 3 e^2 / 8): error ~e^3
+    return __builtin_amdgcn_class(y, 0x267) ? y : r;
+}
 // u^e for u > 0 (u == 0 handled by callers where it can occur)
 __device__ __forceinline__ float cg_pow(float u, float e) { return cg_exp2(e * cg_log2(u)); }
 __device__ __forceinline__ double cg_pow(double u, double e) { return pow(u, e); }

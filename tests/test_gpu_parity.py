@@ -1608,3 +1608,52 @@ def test_fp64_gamma_exponential_entrywise(cg, oracle):
     av = rng.standard_normal(211)
     G = cg.gramian(cg.GammaExp(1.4), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
     assert relerr((G @ torch.from_numpy(av).cuda()).cpu().numpy(), oracle.mul(None, oracle.Kernel(oracle.GAMMAEXP, param=1.4), X, Y, av, dtype=np.float64)) <= 1e-13
+
+
+def test_fp64_sqrt_rcp_rsqrt_profiles_entrywise(cg, oracle):
+    """The library's own fp64 square root / reciprocal / reciprocal square root (csrc/profiles.hpp cg_sqrt, cg_rcp, cg_rsqrt: hardware
+    seed + Goldschmidt / cubic Newton refinement, no range scaling) through the profiles that use them, ENTRY BY ENTRY against numpy:
+    Exponential exp(-sqrt s) (src/stationary.jl:60), MaternP (:117-158), Cauchy 1/(1+s) (:224), InverseMultiQuadratic 1/sqrt(s + c^2)
+    (:235) over denormal, tiny, moderate, huge and special s; then the gradient MVMs of the same profiles against the oracle."""
+    r = np.concatenate([[0.0], np.geomspace(1e-160, 1e-6, 700), np.linspace(1e-6, 30.0, 2500), np.geomspace(30.0, 1e150, 800)])
+    y = r.reshape(-1, 1).copy()
+    x = np.zeros((1, 1))
+    s = y[:, 0] ** 2
+    eps = 2.3e-16
+
+    def dense_row(k, pts=y):
+        return cg.gramian(k, torch.from_numpy(x).cuda(), torch.from_numpy(pts).cuda()).to_dense().cpu().numpy()[0]
+
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        got = dense_row(cg.Exp())
+        ref = np.exp(-np.sqrt(s)); ok = ref > 1e-300
+        # one rounding of r = sqrt(s) costs r eps in exp(-r)
+        assert np.all(np.abs(got[ok] / ref[ok] - 1.0) <= eps * (4 + 2 * np.sqrt(s[ok]))), float(np.max(np.abs(got[ok] / ref[ok] - 1.0)))
+        assert got[0] == 1.0 and np.all(got[~ok] <= 1e-300) and not np.any(np.isnan(got))
+        for p in (1, 2, 3):
+            got = dense_row(cg.MaternP(p))
+            ref = oracle.matrix(oracle.Kernel(oracle.MATERNP, p=p), x, y)[0]; ok = ref > 1e-300
+            rr = np.sqrt((2 * p + 1) * s[ok])
+            assert np.all(np.abs(got[ok] / ref[ok] - 1.0) <= eps * (8 + 2 * rr)), (p, float(np.max(np.abs(got[ok] / ref[ok] - 1.0))))
+            assert got[0] == 1.0
+        got = dense_row(cg.Cauchy())
+        ref = 1.0 / (1.0 + s); ok = ref > 1e-300
+        assert np.all(np.abs(got[ok] / ref[ok] - 1.0) <= 3 * eps), float(np.max(np.abs(got[ok] / ref[ok] - 1.0)))
+        assert got[0] == 1.0 and not np.any(np.isnan(got))
+        for c in (1.0, 0.37, 1e-3):
+            got = dense_row(cg.InverseMultiQuadratic(c))
+            ref = 1.0 / np.sqrt(s + c * c); ok = ref > 1e-300
+            assert np.all(np.abs(got[ok] / ref[ok] - 1.0) <= 4 * eps), (c, float(np.max(np.abs(got[ok] / ref[ok] - 1.0))))
+    yb = np.array([[0.0], [np.nan], [np.inf], [5e-324], [1e-162]])
+    for k, at_inf in ((cg.Exp(), 0.0), (cg.Cauchy(), 0.0), (cg.InverseMultiQuadratic(1.0), 0.0)):
+        gb = dense_row(k, yb)
+        assert gb[0] == 1.0 and np.isnan(gb[1]) and gb[2] == at_inf and gb[3] == 1.0 and gb[4] == 1.0, (type(k).__name__, gb)
+    gm = dense_row(cg.MaternP(2), yb)
+    assert gm[0] == 1.0 and np.isnan(gm[1]) and gm[3] == 1.0 and gm[4] == 1.0
+    rng = np.random.default_rng(10)
+    X = rng.standard_normal((260, 4)); Y = rng.standard_normal((190, 4)) * 1.5; a = rng.standard_normal(190 * 4)
+    for kg, ko in ((cg.Exp(), oracle.Kernel(oracle.EXP)), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2)), (cg.Cauchy(), oracle.Kernel(oracle.CAUCHY)),
+                   (cg.InverseMultiQuadratic(0.8), oracle.Kernel(oracle.IMQ, param=0.8)), (cg.RQ(1.2), oracle.Kernel(oracle.RQ, param=1.2))):
+        K = cg.gramian(cg.GradientKernel(kg), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+        out = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
+        assert relerr(out, oracle.grad_mul(None, ko, X, Y, a, 1.0, 0.0, np.float64)) <= 1e-13, type(kg).__name__
