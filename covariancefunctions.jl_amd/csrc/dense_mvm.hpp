@@ -159,6 +159,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
 #pragma unroll
         for (int c = 0; c < NR; ++c) tot[r][c] = (T)0;
 
+    // The column sweep as a lambda over the parameter block: MaternP orders p <= 3 (every order the reference's users reach in
+    // practice) run it on a copy whose p the compiler can bound (p & 3), which folds the profile's per-pair "fixed-degree or looped
+    // Horner" branch away — two scalar branches per pair in the fp64 loop otherwise.
+    auto sweep = [&](const typename ParamsOf<FAM, T>::type& kp) {
     for (int64_t gb = g0; gb < g1; gb += GINNER) {
         const int cnt = (int)(((gb + GINNER < g1) ? (gb + GINNER) : g1) - gb);
         V acc[R][NR];
@@ -182,6 +186,18 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int c = 0; c < NR; ++c) tot[r][c] += PK::hsum(acc[r][c]);
+    }
+    };
+    if constexpr (FAM == COVGRAM_MATERNP) {
+        if (kp.p <= 3) {
+            typename ParamsOf<FAM, T>::type kq = kp;
+            kq.p = kp.p & 3;
+            sweep(kq);
+        } else {
+            sweep(kp);
+        }
+    } else {
+        sweep(kp);
     }
 
     // epilogue ------------------------------------------------------------------------------

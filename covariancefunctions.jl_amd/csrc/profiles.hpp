@@ -109,6 +109,30 @@ __device__ __forceinline__ double exp2_scaled_nonpos(double s, double chi, doubl
     const double e = __builtin_ldexp(p, (int)n);
     return x < -1100.0 ? 0.0 : e;
 }
+// exp2(-t) in fp64 for t >= 0 in the dense kernels' Matern profile, whose polynomial factor carries NaN and inf (q(NaN) exp2(..) = NaN,
+// q(inf) * 0 = NaN as in the reference's (1 + r + ...) exp(-r)): the argument is CLAMPED at 1100 (one v_min_f64; a NaN t gives 0 here)
+// instead of the library's compare + two selects on the result, ln 2 is one constant (|f| <= 1/2 is exact, so the product's rounding is
+// 2^-54 absolute), and the Horner steps are plain fmas so that the coefficients stay in SGPRs in kernels that have them to spare:
+// 17 instructions against the library's 21.  Same polynomial as exp2_scaled_nonpos.
+__device__ __forceinline__ double exp2_neg_clamped(double t) {
+    const double tc = __builtin_fmin(t, 1100.0);
+    const double n = __builtin_rint(-tc);
+    const double y = (-tc - n) * 0.69314718055994530942;
+    double p = 0x1.af631d0059becp-26;
+    p = __builtin_fma(p, y, 0x1.28b4057f44145p-22);
+    p = __builtin_fma(p, y, 0x1.71ddf5749d126p-19);
+    p = __builtin_fma(p, y, 0x1.a01991ac8730ap-16);
+    p = __builtin_fma(p, y, 0x1.a01a01b14378fp-13);
+    p = __builtin_fma(p, y, 0x1.6c16c187fbe02p-10);
+    p = __builtin_fma(p, y, 0x1.111111110f225p-7);
+    p = __builtin_fma(p, y, 0x1.555555554f0cfp-5);
+    p = __builtin_fma(p, y, 0x1.555555555555ap-3);
+    p = __builtin_fma(p, y, 0x1.0000000000011p-1);
+    p = __builtin_fma(p, y, 1.0);
+    p = __builtin_fma(p, y, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+__device__ __forceinline__ float exp2_neg_clamped(float t) { return __builtin_amdgcn_exp2f(-t); }
 // u^(-a) in fp64 for u >= 1, a > 0 (the rational-quadratic profile: u = 1 + s / (2 alpha); NaN propagates, u = inf gives 0).  The
 // library pow is a general function (sign / zero / infinity cases, ~150 instructions with hipcc's mov + fmac Horner steps); here
 // log2(u) = e + 2 z q(z^2) / ln 2 with u = m 2^e, m in [1/sqrt 2, sqrt 2), z = (m - 1) / (m + 1) (|z| <= 0.1716; no cancellation as
@@ -203,7 +227,7 @@ struct Phi<COVGRAM_MATERNP, T, true> {
         // q(r) exp(-r) has no cancellation there and agrees with the truncated series to << eps at the bound (the first term
         // the series drops is r^(2p+1) <= eps^(1 + 1/(2p))), so the value-only kernels skip it: s is a sum of squares >= 0.
         T rr = cg_sqrt(s);
-        T e = cg_exp2(-rr);
+        T e = exp2_neg_clamped(rr);
         T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
         return q * e;
     }
