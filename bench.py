@@ -133,7 +133,7 @@ def other_configs(cg, dev):
     out["C1"] = {"what": "MaternP(2) dense Gramian mul!, d=3 n=4096 fp64", "ms": ms, "mvm_per_s": 1e3 / ms,
                  "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), Xh, Xh, ah)),
                  "roofline": {"bound": "valu_fp64", "achieved": fl / (ms * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) * 1e-12 / 78.6,
-                              "note": "1.7e7 pairs = 4096 waves of 64 rows x 64 columns, half of the chip's wave slots for ONE round: the kernel is ~33 of the 40 us (its floor at the large-n rate of this profile is 24 us), pack + reduction launches the rest"}}
+                              "note": "1.7e7 pairs = 4096 waves of 64 rows x 64 columns, half of the chip's wave slots for ONE round: the kernel is ~25 of the 32 us (its floor at the large-n rate of this profile, 0.85e12 pairs/s, is 20 us), pack + reduction launches the rest"}}
     # C3: EQ, d=8, n=524288, fp32 — what ONE of the 8 ranks computes (the 8-GPU run itself is the driver's)
     n, d, world = 524288, 8, 8
     rng = np.random.default_rng(0xC0F + 2)
