@@ -506,6 +506,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
+    else if (!strcmp(key, "dense_sym")) ctx->dense_sym = value;
     else if (!strcmp(key, "mfma_stamp")) ctx->mfma_stamp = value;
     else if (!strcmp(key, "matrix_variant")) ctx->matrix_variant = value;
     else if (!strcmp(key, "mfma_mrhs")) ctx->mfma_mrhs = value;
@@ -520,6 +521,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
+    else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
@@ -828,6 +830,16 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         }
     }
     if (m > 0 && !dotfac) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
+    // fp64 gramian(k, x) * a on the direct-difference path: the upper triangle once (dense_sym_kernel, dense_mvm.hpp).  The same point
+    // set on both sides, one right-hand side, a single (non-composite) profile without a Power wrapper, d <= 64; from n = 8192 (16384 for
+    // the profiles that cost a reciprocal or less: below that the launch is latency and the triangle's imbalance, not arithmetic —
+    // tools/fp64_sym_sweep.py: break-even at n ~ 6000, x1.1-1.25 at 8192, x1.3-1.5 at 16384, x1.5-1.75 from 32768) while the column-sum
+    // slab n^2 / 8 bytes stays within 2 GiB (n <= 131072).
+    const bool cheap_profile = hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ || hk.tu_family == COVGRAM_DOT;
+    const bool dsym = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && ctx->dense_sym != 0 && X->dptr == Y->dptr && n == m &&
+                      hk.tu_family < COVGRAM_NFAMILY && hk.k.power == 1 && (ctx->dense_sym == 1 || n >= (cheap_profile ? 16384 : 8192)) &&
+                      (size_t)rowblocks * (size_t)npad * ts <= ((size_t)2 << 30);
+    ctx->last_dense_sym = dsym ? 1 : 0;
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NRpad = (nr == 1) ? 1 : 4;
@@ -874,6 +886,25 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
         da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;
         da.variant = (int)ctx->dense_variant; da.lds_pad = (int)ctx->lds_pad; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
+        if (dsym) {
+            // chunks of whole 64-column blocks; about twice the workgroups of the all-entries launch, half of them (left of the
+            // diagonal) leave at once
+            int64_t blocks = (m + 63) / 64;
+            int64_t want = std::max<int64_t>(1, std::min<int64_t>(blocks, 2 * (int64_t)jsplit));
+            int64_t per = (blocks + want - 1) / want;
+            da.jchunk = jchunk = per * 64;
+            da.jsplit = jsplit = (int)((blocks + per - 1) / per);
+            da.sym = 1;
+            rc = ws_reserve(ctx, 1, (size_t)jsplit * npad * ts, &da.out); if (rc) return rc;
+            rc = ws_reserve(ctx, 4, (size_t)rowblocks * npad * ts, &da.colslab); if (rc) return rc;
+            auto* tms = timer_next(ctx);
+            if (tms) (void)hipEventRecord(tms->first, ctx->stream);
+            rc = launch(da, dtype); if (rc) return rc;
+            if (tms) (void)hipEventRecord(tms->second, ctx->stream);
+            hipLaunchKernelGGL(dense_sym_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)da.out,
+                               (const double*)da.colslab, npad, jsplit, (double*)y_c, n, alpha_eff, beta);
+            continue;
+        }
         if (jsplit == 1) da.out = y_c;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
         auto* tm = timer_next(ctx);

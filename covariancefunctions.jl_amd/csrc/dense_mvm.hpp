@@ -247,6 +247,189 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const T* __restrict__
     *yp = v;
 }
 
+// -------------------------------------------------------------------------------------------------
+// gramian(k, x) in fp64 (the reference's default element type): the Gramian is symmetric and the reference does not use that
+// (src/gramian.jl:78-87 loops over all n*m entries).  dense_sym_kernel keeps the lane-per-row layout and the scalar column stream,
+// but a workgroup (one wave = one 64-row block rb) only walks the columns j >= 64 rb of its chunk: its own diagonal block in full
+// (row sums only), and to the right of it every entry k_ij ONCE for both the row sum b_i += a_j k_ij and the column sum
+// b_j += a_i k_ij.  A column sum is a reduction over the wave's 64 rows; done column by column it costs as much as the pair body
+// (6 dependent DPP steps of two dword moves + an add: ~30 instructions against 27...46), so four columns are reduced TOGETHER by
+// lane swaps (wave_sum4_f64 below: 21 instructions per four columns) and four lanes store the four totals to colslab[rb][j].  dense_sym_reduce_kernel then adds, per output row, the split-J partials of its row block and the
+// column sums of all row blocks above it — fixed order, no float atomics.  Half the profile evaluations of dense_mvm_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);   // lanes without a source (or in masked rows) add 0.0
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+// sum over the 64 lanes, delivered in lane 63 (the other lanes hold partial prefixes): an inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 — 6 x (2 v_mov_dpp + v_add_f64),
+// no v_readlane, no select.  Fixed order: deterministic.
+__device__ __forceinline__ double wave_sum_lane63_f64(double v) {
+    v = dpp_add_f64<0x111, 0xF>(v);
+    v = dpp_add_f64<0x112, 0xF>(v);
+    v = dpp_add_f64<0x114, 0xF>(v);
+    v = dpp_add_f64<0x118, 0xF>(v);
+    v = dpp_add_f64<0x142, 0xA>(v);
+    v = dpp_add_f64<0x143, 0xC>(v);
+    return v;
+}
+
+// Four columns at once (gfx950's lane-swap instructions; semantics checked on the device with tools/swap_probe.hip):
+// v_permlane32_swap(a, b) leaves {a[0:31], b[0:31]} and {a[32:63], b[32:63]}, so their sum holds a's lane pairs (l, l + 32) in the lower
+// half of the wave and b's in the upper half — ONE add reduces two columns by a factor two; v_permlane16_swap does the same between
+// odd and even rows of 16 lanes.  After both, row r of the wave holds column (c0, c2, c1, c3)[r] summed over the four rows, and the
+// in-row scan finishes all four columns together: 21 instructions per FOUR columns (6 swaps of two dwords... + 3 adds + 4 x 3 DPP).
+__device__ __forceinline__ double swap32_add_f64(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap16_add_f64(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double row_shr_add_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);        // bound_ctrl: lanes without a source read 0
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+// totals of four columns' per-lane terms: lane 15 / 31 / 47 / 63 returns the wave total of c0 / c2 / c1 / c3
+__device__ __forceinline__ double wave_sum4_f64(double c0, double c1, double c2, double c3) {
+    double m = swap16_add_f64(swap32_add_f64(c0, c1), swap32_add_f64(c2, c3));
+    m = row_shr_add_f64<0x111>(m);
+    m = row_shr_add_f64<0x112>(m);
+    m = row_shr_add_f64<0x114>(m);
+    m = row_shr_add_f64<0x118>(m);
+    return m;
+}
+
+template <int FAM, int D>
+__global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
+    const double* __restrict__ X, int64_t n, int32_t d, const double* __restrict__ P, double* __restrict__ out,
+    double* __restrict__ colslab, int64_t npad, int64_t jchunk, const double* __restrict__ Cn,
+    const typename ParamsOf<FAM, double>::type kp0) {
+    using T = double;
+    constexpr bool ISO = fam_is_iso<FAM>;
+    using Body = DenseBody<T, FAM, D, 1, 1, false, ISO>;
+    constexpr int S = D + 1;
+    const int lane = threadIdx.x;
+    const int64_t row_lo = (int64_t)blockIdx.x * 64;
+    const int64_t j0 = (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < n) ? (j0 + jchunk) : n;
+    const int64_t row = row_lo + lane;
+    if (j1 <= row_lo) {                                    // the whole chunk lies left of the diagonal block: another row block's column sums
+        out[(int64_t)blockIdx.y * npad + row] = 0.0;
+        return;
+    }
+    const int64_t rowc = (row < n) ? row : n - 1;          // clamp: computed, weighted 0 in the column sums, never stored as a row
+    T x[1][D];
+    {
+        const T* xr = X + rowc * (int64_t)d;
+#pragma unroll
+        for (int l = 0; l < D; ++l) x[0][l] = (l < d) ? (ISO ? xr[l] - Cn[l] : xr[l]) * kp0.gamma : (T)0;
+    }
+    const T ai = (row < n) ? P[rowc * S + D] : (T)0;       // the row's own weight (the stream holds a_j beside the scaled y_j)
+    T tot = (T)0;
+
+    auto sweep = [&](const typename ParamsOf<FAM, T>::type& kp) {
+        const int64_t jstart = (j0 > row_lo) ? j0 : row_lo;          // both multiples of 64
+        for (int64_t jb = jstart; jb < j1; jb += 64) {
+            const int cnt = (int)((jb + 64 < j1) ? 64 : (j1 - jb));
+            const T* __restrict__ p = P + jb * S;                    // uniform address -> s_load
+            T acc = (T)0;
+            if (jb == row_lo) {                                      // diagonal block: all 64 x cnt entries, row sums only
+                for (int u = 0; u < cnt; ++u, p += S) {
+                    T sv[1];
+                    Body::dist(p, x, sv);
+                    const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                    acc = cg_fma(p[D], kv, acc);
+                }
+            } else {
+                T* __restrict__ cdst = colslab + (int64_t)blockIdx.x * npad + jb;
+                auto column = [&](const T* __restrict__ pc, int u) {
+                    T sv[1];
+                    Body::dist(pc, x, sv);
+                    const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                    acc = cg_fma(pc[D], kv, acc);
+                    const T c = wave_sum_lane63_f64(ai * kv);
+                    if (lane == 63) cdst[u] = c;                     // one 8-byte store per column; the 64 of a block merge in L2
+                };
+                if (cnt == 64) {
+                    const int cmap = ((lane >> 4) & 1) * 2 + (lane >> 5);       // which of the four columns this lane's row ends up holding
+                    for (int u = 0; u < 64; u += 4, p += 4 * S) {
+                        T c[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            T sv[1];
+                            Body::dist(p + q * S, x, sv);
+                            const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                            acc = cg_fma(p[q * S + D], kv, acc);
+                            c[q] = ai * kv;
+                        }
+                        const T tsum = wave_sum4_f64(c[0], c[1], c[2], c[3]);
+                        if ((lane & 15) == 15) cdst[u + cmap] = tsum;
+                    }
+                } else {
+                    for (int u = 0; u < cnt; ++u, p += S) column(p, u);
+                }
+            }
+            tot += acc;
+        }
+    };
+    if constexpr (FAM == COVGRAM_MATERNP) {
+        if (kp0.p <= 3) {
+            typename ParamsOf<FAM, T>::type kq = kp0;
+            kq.p = kp0.p & 3;
+            sweep(kq);
+        } else {
+            sweep(kp0);
+        }
+    } else {
+        sweep(kp0);
+    }
+    out[(int64_t)blockIdx.y * npad + row] = tot;
+}
+
+// y[i] = alpha * (sum_sp out[sp][i] + sum_{rb < i / 64} colslab[rb][i]) + beta * y[i]   (fixed order: deterministic)
+template <typename T /* double */>
+__global__ __launch_bounds__(256) void dense_sym_reduce_kernel(const double* __restrict__ out, const double* __restrict__ colslab,
+                                                               int64_t npad, int32_t jsplit, double* __restrict__ y, int64_t n,
+                                                               double alpha, double beta) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ double red[4][64];
+    double s = 0.0;
+    if (i < n) {
+        for (int sp = part; sp < jsplit; sp += 4) s += out[(int64_t)sp * npad + i];
+        const int64_t nb = blockIdx.x;                                 // row blocks above this one hold column sums for these rows
+        for (int64_t rb = part; rb < nb; rb += 4) s += colslab[rb * npad + i];
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    double v = alpha * s;
+    if (beta != 0.0) v = cg_fma(beta, y[i], v);
+    y[i] = v;
+}
+
+template <int FAM, int D>
+static int launch_dense_sym_one(const DenseArgs& a) {
+    const typename ParamsOf<FAM, double>::type kp = make_params<FAM, double>(*a.hk);
+    dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)a.jsplit);
+    hipLaunchKernelGGL((dense_sym_kernel<FAM, D>), grid, dim3(DENSE_THREADS), 0, a.stream, (const double*)a.X, a.n, a.d,
+                       (const double*)a.P, (double*)a.out, (double*)a.colslab, a.npad, a.jchunk, (const double*)a.C, kp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+    return COVGRAM_OK;
+}
+
 // Column stream, PK columns per group g:  P[(g*(D+NR) + l)*PK + h] = gamma * Y[g*PK+h][l]   (l < D, zero padded in l)
 //                                         P[(g*(D+NR) + D + c)*PK + h] = A[g*PK+h + (c0+c)*lda]
 // A column beyond m (odd m, fp32) duplicates the last point with weight 0, so it adds exactly 0 * phi(finite).
@@ -292,6 +475,8 @@ inline int rows_per_lane_for(int) { return 1; }
 template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {
     constexpr int R = RowsFor<D>::value;
+    if constexpr (sizeof(T) == 8 && NR == 1 && !fam_is_expr<FAM>)
+        if (a.sym) return launch_dense_sym_one<FAM, D>(a);
     const bool pow = a.hk->k.power != 1;
     if constexpr (!fam_is_expr<FAM>)   // composites apply Power per factor
         if (pow) return launch_dense_one<T, FAM, D, NR, R, true>(a);

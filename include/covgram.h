@@ -143,6 +143,9 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * columns at a time on the VALU —, 1 = from 2 columns),
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
  * -1 = from n = 12500 ... 18000 by the profile's cost, 0 = never, 1 = always),
+ * "dense_sym" (the same for fp64 on the direct-difference path — the reference's default element type: gramian(k, x) with one
+ * right-hand side evaluates every entry on or above the diagonal blocks once, dense_sym_kernel; -1 = from n = 8192 (16384 for
+ * Cauchy / IMQ / Dot), 0 = never, 1 = always),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
@@ -152,7 +155,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran the fp64 direct-difference symmetric kernel), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);

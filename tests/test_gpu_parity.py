@@ -1657,3 +1657,61 @@ def test_fp64_sqrt_rcp_rsqrt_profiles_entrywise(cg, oracle):
         K = cg.gramian(cg.GradientKernel(kg), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
         out = (K @ torch.from_numpy(a).cuda()).cpu().numpy()
         assert relerr(out, oracle.grad_mul(None, ko, X, Y, a, 1.0, 0.0, np.float64)) <= 1e-13, type(kg).__name__
+
+
+def test_fp64_symmetric_direct_kernel(cg, oracle):
+    """gramian(k, x) * a in fp64 on the direct-difference path evaluates the upper triangle once (csrc/dense_mvm.hpp dense_sym_kernel; the
+    reference loops over all n*n entries, src/gramian.jl:78-87): against the fp64 oracle and against the all-entries kernel, for sizes that
+    are and are not multiples of the 64-row blocks / column chunks, every single-profile family, alpha / beta (beta = 0 must not read y:
+    NaN-filled), a Lengthscale, and forced on at a size below the automatic threshold."""
+    rng = np.random.default_rng(11)
+    fams = [(cg.EQ(), oracle.Kernel(oracle.EQ)), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2)), (cg.Exp(), oracle.Kernel(oracle.EXP)),
+            (cg.RQ(1.3), oracle.Kernel(oracle.RQ, param=1.3)), (cg.Cauchy(), oracle.Kernel(oracle.CAUCHY)),
+            (cg.GammaExp(1.5), oracle.Kernel(oracle.GAMMAEXP, param=1.5)), (cg.InverseMultiQuadratic(0.9), oracle.Kernel(oracle.IMQ, param=0.9)),
+            (cg.MaternP(5), oracle.Kernel(oracle.MATERNP, p=5)), (cg.ExponentialDot(), oracle.Kernel(oracle.EXPDOT)),
+            (cg.Lengthscale(cg.MaternP(1), 0.6), oracle.Kernel(oracle.MATERNP, p=1, lengthscale=0.6))]
+    try:
+        for n, d in ((1, 2), (63, 3), (64, 3), (65, 1), (777, 3), (1000, 8), (2049, 5)):
+            X = rng.standard_normal((n, d)) * (0.4 if d > 3 else 1.0); a = rng.standard_normal(n)
+            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+            for kg, ko in fams if n in (777, 1000) else fams[:2]:
+                G = cg.gramian(kg, Xd)
+                cg.set_option("dense_sym", 1)
+                ys = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                G.mul_(ys, ad)
+                assert cg.get_info("last_dense_sym") == 1, (n, d, type(kg).__name__)
+                cg.set_option("dense_sym", 0)
+                yg = (G @ ad); assert cg.get_info("last_dense_sym") == 0
+                ref = oracle.mul(None, ko, X, X, a, dtype=np.float64)
+                assert relerr(ys.cpu().numpy(), ref) <= 1e-13, (n, d, type(kg).__name__, relerr(ys.cpu().numpy(), ref))
+                assert relerr(ys.cpu().numpy(), yg.cpu().numpy()) <= 1e-13
+        # alpha / beta, and the automatic rule (n >= 8192, same point set, one right-hand side, fp64)
+        n, d = 8300, 3
+        X = rng.standard_normal((n, d)); a = rng.standard_normal(n); y0 = rng.standard_normal(n)
+        Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+        cg.set_option("dense_sym", -1)
+        G = cg.gramian(cg.MaternP(2), Xd)
+        yd = torch.from_numpy(y0).cuda()
+        G.mul_(yd, ad, -0.7, 1.3)
+        assert cg.get_info("last_dense_sym") == 1
+        ref = oracle.mul(y0.copy(), oracle.Kernel(oracle.MATERNP, p=2), X, X, a, -0.7, 1.3, np.float64)
+        assert relerr(yd.cpu().numpy(), ref) <= 1e-13
+        G2 = cg.gramian(cg.MaternP(2), Xd, torch.from_numpy(X.copy()).cuda())      # equal values, different handles: not the symmetric path
+        G2 @ ad; assert cg.get_info("last_dense_sym") == 0
+        (G @ torch.from_numpy(rng.standard_normal((n, 2))).cuda()); assert cg.get_info("last_dense_sym") == 0      # matrix right-hand side
+        Gf = cg.gramian(cg.Exp(), Xd.float()); Gf @ ad.float(); assert cg.get_info("last_dense_sym") == 0             # fp32
+        # symmetric result is symmetric in the bilinear form: a' (G b) == b' (G a)
+        b = torch.from_numpy(rng.standard_normal(n)).cuda()
+        assert abs(float(ad @ (G @ b)) - float(b @ (G @ ad))) <= 1e-10 * n
+        # the Krylov caller on top (src/gramian.jl:229-238): (G + sigma^2 I) \ b eagerly and as a replayed HIP graph, every MVM on the
+        # symmetric kernel; the two agree and the residual through the ALL-entries kernel confirms the solution
+        S = G + 0.5 * torch.ones(n, device="cuda", dtype=torch.float64)
+        xe, ie = cg.cg(S, b, reltol=1e-9)
+        xg, ig = cg.cg(S, b, reltol=1e-9, graph=True, check_every=4)
+        assert ie["converged"] and ig["converged"] and ig["graph"] and cg.get_info("last_dense_sym") == 1
+        assert relerr(xg.cpu().numpy(), xe.cpu().numpy()) <= 1e-7
+        cg.set_option("dense_sym", 0)
+        res = (G @ xe) + 0.5 * xe - b
+        assert cg.get_info("last_dense_sym") == 0 and float(res.norm() / b.norm()) <= 1e-8
+    finally:
+        cg.set_option("dense_sym", -1)
