@@ -49,7 +49,7 @@ def test_random_dense_cases(cg, oracle, seed):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_random_symmetric_cases(cg, oracle, seed):
-    """gramian(k, x) with the symmetric upper-triangle kernels forced on (mfma_sym = 1, dense_variant = 2 where the shape allows):
+    """gramian(k, x) with the symmetric upper-triangle kernels forced on (mfma_sym = 1, dense_sym = 1, dense_variant = 2 where the shape allows):
     every kernel case, random n around the 32-row tiles / 256-row panels / 64-tile chunks, random chunk splits, alpha / beta, the
     multi-GPU partial form for a random world size — whatever path the library ends up taking must match the fp64 oracle."""
     rng = np.random.default_rng(5000 + seed)
@@ -64,6 +64,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
             X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt)
             a = rng.standard_normal(n).astype(dt); y0 = rng.standard_normal(n).astype(dt)
             cg.set_option("mfma_sym", 1); cg.set_option("dense_variant", int(rng.choice([0, 2]))); cg.set_option("jsplit", int(rng.choice([0, 0, 2, 5])))
+            cg.set_option("dense_sym", 1)                     # fp64: the direct-difference symmetric kernel wherever it is eligible
             Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
             G = cg.gramian(k, Xd)
             yd = torch.from_numpy(y0.copy()).cuda()
@@ -82,7 +83,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
                 e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))
                 assert e <= tol, (name, d, n, world, e)
     finally:
-        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0)
+        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1)
 
 
 @pytest.mark.parametrize("seed", range(4))
