@@ -901,7 +901,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             if (tms) (void)hipEventRecord(tms->first, ctx->stream);
             rc = launch(da, dtype); if (rc) return rc;
             if (tms) (void)hipEventRecord(tms->second, ctx->stream);
-            hipLaunchKernelGGL(dense_sym_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(256), 0, ctx->stream, (const double*)da.out,
+            hipLaunchKernelGGL(dense_sym_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(1024), 0, ctx->stream, (const double*)da.out,
                                (const double*)da.colslab, npad, jsplit, (double*)y_c, n, alpha_eff, beta);
             continue;
         }
