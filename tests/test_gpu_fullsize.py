@@ -117,3 +117,33 @@ def test_config5_exponential_toeplitz_n4194304_f64(cg, oracle):
     idx = np.random.default_rng(5).choice(n, 64, replace=False)
     direct = np.array([np.dot(vc[np.abs(i - np.arange(n))], ah) for i in idx])
     assert relerr(y[idx], direct) <= 1e-10
+
+
+def test_fp64_symmetric_direct_kernel_at_readme_and_large_sizes(cg, oracle):
+    """The reference README's own dense case (MaternP(2), d = 3, n = 16384, Float64: README.md:26-38) and a larger one (d = 8, n = 40000,
+    not a multiple of the 64-row blocks) as gramian(k, x) * a — the library's default path there is the fp64 symmetric direct-difference
+    kernel (upper triangle once) — against the C oracle on a fixed row subset over ALL columns, norm-wise and row by row, and against
+    the all-entries kernel on every row."""
+    import c_oracle
+    for idx, (n, d, scale) in enumerate(((16384, 3, 1.0), (40000, 8, 0.35))):
+        rng = np.random.default_rng(SEED0 + 40 + idx)
+        X = rng.standard_normal((n, d)) * scale; a = rng.standard_normal(n)
+        Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
+        G = cg.gramian(cg.MaternP(2), Xd)
+        b = (G @ ad)
+        assert cg.get_info("last_dense_sym") == 1 and cg.get_info("last_dense_path") == 1
+        rows = np.sort(np.random.default_rng(3).choice(n, 512, replace=False))
+        rows[:3] = (0, n // 2, n - 1)                     # first / middle / last row block (only column sums / both / only row sums)
+        ko = oracle.Kernel(oracle.MATERNP, p=2)
+        ref = c_oracle.mvm(ko, X[rows], X, a)
+        absref = c_oracle.mvm(ko, X[rows], X, np.abs(a))
+        got = b.cpu().numpy()
+        assert relerr(got[rows], ref) <= 1e-12, relerr(got[rows], ref)
+        assert float(np.max(np.abs(got[rows] - ref) / absref)) <= 1e-12
+        try:
+            cg.set_option("dense_sym", 0)
+            ball = (G @ ad).cpu().numpy()
+            assert cg.get_info("last_dense_sym") == 0
+        finally:
+            cg.set_option("dense_sym", -1)
+        assert relerr(got, ball) <= 1e-13
