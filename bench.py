@@ -134,6 +134,31 @@ def other_configs(cg, dev):
                  "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), Xh, Xh, ah)),
                  "roofline": {"bound": "valu_fp64", "achieved": fl / (ms * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) * 1e-12 / 78.6,
                               "note": "1.7e7 pairs = 4096 waves of 64 rows x 64 columns, half of the chip's wave slots for ONE round: the kernel is ~25 of the 32 us (its floor at the large-n rate of this profile, 0.85e12 pairs/s, is 20 us), pack + reduction launches the rest"}}
+    # The reference README's own dense case (lazy dense mul!, MaternP(2), d=3, n=16384, Float64: 0.584813 s on its unstated
+    # CPU, README.md:26-38), not one of BASELINE.json's configs: all n^2 entries (dense_sym = 0) and the library's default for
+    # gramian(k, x) in fp64, the symmetric direct-difference kernel (upper triangle once, exact differences).  Reporting only.
+    try:
+        n, d = 16384, 3
+        rng = np.random.default_rng(0xC0F + 5)
+        Xh = rng.standard_normal((n, d)); ah = rng.standard_normal(n)
+        G = cg.gramian(cg.MaternP(2), torch.from_numpy(Xh).to(dev)); a = torch.from_numpy(ah).to(dev); y = torch.empty_like(a)
+        cg.set_option("dense_sym", 0)
+        ms_all = _timed(lambda: G.mul_(y, a))
+        cg.set_option("dense_sym", -1)
+        ms_sym = _timed(lambda: G.mul_(y, a))
+        used = cg.get_info("last_dense_sym") == 1
+        rows = np.sort(np.random.default_rng(4).choice(n, 512, replace=False))
+        ref = c_oracle.mvm(o.Kernel(o.MATERNP, p=2), Xh[rows], Xh, ah)
+        out["README_MaternP2_n16384_f64"] = {
+            "what": "the reference README's dense case: MaternP(2) Gramian mul!, d=3 n=16384 fp64, gramian(k, x)", "ms": ms_sym, "ms_all_entries": ms_all,
+            "used_symmetric_direct_kernel": bool(used), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref), "checked_rows": 512,
+            "reference_published_s": 0.584813, "reference_source": "README.md:26-38 (CPU unstated)",
+            "roofline": {"bound": "valu_fp64", "achieved": float(n) * n * (3 * d + 3) / (ms_all * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": float(n) * n * (3 * d + 3) / (ms_all * 1e-3) * 1e-12 / 78.6,
+                         "note": "frac prices the ALL-entries time with the reference's 3d+3 flops per pair; the fp64 MaternP pair body is 41 instructions (sqrt 11, exp2 17), DESIGN.md 3.1"}}
+    except Exception as e:   # reporting only: never fail the contract line for it
+        cg.set_option("dense_sym", -1)
+        out["README_MaternP2_n16384_f64"] = {"what": "failed", "error": str(e)[:200]}
     # C3: EQ, d=8, n=524288, fp32 — what ONE of the 8 ranks computes (the 8-GPU run itself is the driver's)
     n, d, world = 524288, 8, 8
     rng = np.random.default_rng(0xC0F + 2)
