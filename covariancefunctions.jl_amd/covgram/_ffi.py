@@ -22,6 +22,7 @@ F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE, ENOMEM = 0, -1, -2, -3, -4, -5
 MATERNP_MAX_P = 8
+ABI_VERSION = 110   # COVGRAM_VERSION of the include/covgram.h these prototypes mirror
 
 
 class covgram_kernel(C.Structure):
@@ -108,7 +109,7 @@ PROTOTYPES = {
     "covgram_toeplitz_levinson": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32]),
     "covgram_toeplitz_trench": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32]),
     "covgram_kron_mvm": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _I32, _I32,
-                                   _P, _P, _D, _D, _I32]),
+                                   _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_lowrank_mvm": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_debug_kernel_params": (C.c_int, [_KP, _I32, _I32, C.POINTER(_D)]),
 }
@@ -129,6 +130,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = l.covgram_version()
+        if got != ABI_VERSION:   # e.g. COVGRAM_LIB pointing at another build: its argument lists differ (covgram.h history)
+            raise RuntimeError(f"{LIB_PATH} is ABI version {got}, this binding is {ABI_VERSION}: rebuild the library")
         _lib = l
     return _lib
 

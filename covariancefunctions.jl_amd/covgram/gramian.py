@@ -502,13 +502,7 @@ class KroneckerProduct(LazyOperator):
 
     def mul_(self, y, a, alpha=1.0, beta=0.0):
         a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
-        if a.dim() != 1:
-            for c in range(a.shape[1]):
-                yc = y[:, c].contiguous()
-                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
-                y[:, c] = yc
-            return y
-        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype or y.dim() != a.dim() or (a.dim() == 2 and y.shape[1] != a.shape[1]):
             raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
         fs = self._dense_factors()
         q = len(fs)
@@ -516,12 +510,19 @@ class KroneckerProduct(LazyOperator):
         rows = (C.c_int64 * q)(*[f.shape[1] for f in fs])
         cols = (C.c_int64 * q)(*[f.shape[0] for f in fs])
         lds = (C.c_int64 * q)(*[f.shape[1] for f in fs])
-        a_c = a.contiguous()
-        y_c = y if y.is_contiguous() else y.contiguous()
+        # right-hand sides: column-major n x p (a torch matrix is row-major: its transpose's storage)
+        nrhs = 1 if a.dim() == 1 else a.shape[1]
+        a_c = a.contiguous() if a.dim() == 1 else a.t().contiguous()
+        if a.dim() == 1:
+            y_c = y if y.is_contiguous() else y.contiguous()
+        else:
+            y_c = y.t().contiguous() if beta != 0.0 else torch.empty((nrhs, self.shape[0]), dtype=self.dtype, device=self.device)
         ctx = get_ctx(self.device).bind_stream()
-        _ffi.check(_ffi.lib().covgram_kron_mvm(ctx, ptrs, rows, cols, lds, q, _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()),
-                                               _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
-        if y_c is not y:
+        _ffi.check(_ffi.lib().covgram_kron_mvm(ctx, ptrs, rows, cols, lds, q, _dtype_code(self.dtype), _ffi._P(a_c.data_ptr()), self.shape[1],
+                                               _ffi._P(y_c.data_ptr()), self.shape[0], nrhs, float(alpha), float(beta), _ffi.DEVICE))
+        if a.dim() == 2:
+            y.copy_(y_c.t())
+        elif y_c is not y:
             y.copy_(y_c)
         return y
 

@@ -331,7 +331,7 @@ device_levinson(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = device_levinson(
 device_trench(A::DeviceToeplitz) = Symmetric(parent(device_trench(A.vc[2:end] ./ A.vc[1])) ./ A.vc[1])
 LinearAlgebra.:\(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = issymmetric(A) ? device_levinson(A, b) : error("only symmetric Toeplitz solves are served")
 
-# --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, one strided-batched GEMM per mode ----------
+# --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, mode products on the matrix cores (csrc/kron.hip) --
 struct DeviceKronecker{T} <: AbstractMatrix{T}
     factors::Vector{Matrix{T}}          # F_1 ⊗ F_2 ⊗ … ⊗ F_q in the reference's order (kronecker(G_1, …, G_q))
 end
@@ -343,13 +343,16 @@ function Base.getindex(K::DeviceKronecker, i::Integer, j::Integer)
     end
     v
 end
-function LinearAlgebra.mul!(y::StridedVector{T}, K::DeviceKronecker{T}, a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+function LinearAlgebra.mul!(y::StridedVecOrMat{T}, K::DeviceKronecker{T}, a::StridedVecOrMat{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
     q = length(K.factors)
+    n, m = size(K)
+    size(a, 1) == m && size(y, 1) == n && size(y, 2) == size(a, 2) || throw(DimensionMismatch("mul!: size mismatch"))
     ptrs = Ptr{Cvoid}[pointer(F) for F in K.factors]
     rows = Int64[size(F, 1) for F in K.factors]; cols = Int64[size(F, 2) for F in K.factors]
     GC.@preserve K check(ccall((:covgram_kron_mvm, libcovgram), Cint,
-        (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
-        ctx(), ptrs, rows, cols, rows, Int32(q), dtype_code(T), a, y, Float64(α), Float64(β), HOST))
+        (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int32, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
+        ctx(), ptrs, rows, cols, rows, Int32(q), dtype_code(T), a, max(stride(a, 2), m), y, max(stride(y, 2), n), Int32(size(a, 2)),
+        Float64(α), Float64(β), HOST))
     y
 end
 function gramian(k::SeparableProduct, X::LazyGrid{T}, Y::LazyGrid{T}) where {T <: DevFloat}

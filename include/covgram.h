@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define COVGRAM_VERSION 100 /* 0.1.0 */
+#define COVGRAM_VERSION 110 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); a binding checks
+                               covgram_version() against the header it mirrors at load time */
 
 typedef enum covgram_status {
     COVGRAM_OK = 0,
@@ -235,11 +236,14 @@ int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B,
  * scal[0] = the rho it divided by.  The rest of scal is scratch. */
 int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal);
 
-/* y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) a + beta * y, standard Kronecker order (F_1 = slowest index).
- * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc). */
+/* Y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) A + beta * Y, standard Kronecker order (F_1 = slowest index).
+ * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc).
+ * A: (prod cols)×nrhs (lda), Y: (prod rows)×nrhs (ldy), column-major; a vector is nrhs = 1.  Hand-written mode-product kernels on the
+ * matrix cores of the data's own precision (csrc/kron.hip): the last two modes in ONE pass when cols[q-1] <= 128, so q = 3 costs two
+ * passes over the tensor; a mode whose factor has a side >= 1024 (a compute-bound dense GEMM) goes to rocBLAS. */
 int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols,
-                     const int64_t* lds, int32_t q, int32_t dtype, const void* a, void* y, double alpha,
-                     double beta, int32_t loc);
+                     const int64_t* lds, int32_t q, int32_t dtype, const void* a, int64_t lda, void* y, int64_t ldy,
+                     int32_t nrhs, double alpha, double beta, int32_t loc);
 
 /* Y <- alpha * U (V' A) + beta * Y;  U: n×r (ldu), V: m×r (ldv), A: m×nrhs (lda >= m), Y: n×nrhs (ldy >= n), column-major.
  * nrhs >= 8: both tall-skinny products run on the matrix cores in the data's own precision (v_mfma_f32_32x32x2_f32 /

@@ -133,7 +133,7 @@ def test_host_pointer_toeplitz_kron_lowrank(cg, oracle, ctx):
     ptrs = (f._P * 3)(*[P(b) for b in bufs])
     rows = (C.c_int64 * 3)(*[s[0] for s in shapes]); cols = (C.c_int64 * 3)(*[s[1] for s in shapes]); ldarr = (C.c_int64 * 3)(*lds)
     av = rng.standard_normal(5 * 2 * 6); yv = rng.standard_normal(3 * 4 * 2); yv0 = yv.copy()
-    f.check(lib.covgram_kron_mvm(ctx, ptrs, rows, cols, ldarr, 3, f.F64, P(av), P(yv), 1.5, -0.5, f.HOST))
+    f.check(lib.covgram_kron_mvm(ctx, ptrs, rows, cols, ldarr, 3, f.F64, P(av), av.size, P(yv), yv.size, 1, 1.5, -0.5, f.HOST))
     assert relerr(yv, 1.5 * np.kron(np.kron(Fs[0], Fs[1]), Fs[2]) @ av - 0.5 * yv0) <= 1e-12
     # low rank
     n, m, r = 500, 300, 5
