@@ -73,7 +73,9 @@ static int run_blas(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t l
     return COVGRAM_OK;
 }
 
-constexpr int64_t BLAS_MIN_SIDE = 1024;
+constexpr int64_t BLAS_MIN_SIDE = 1024;       // a factor side from which a mode is always a library GEMM
+constexpr int64_t BLAS_MID_SIDE = 256;        // ... and from this side on when the mode has BLAS_MID_FLOPS of work: compute-bound, where a
+constexpr double BLAS_MID_FLOPS = 2.0e9;      // register-blocked GEMM wins (256^3 fp64: 547 us on the kernels here, 471 us on rocBLAS)
 
 // (F_1 (x) ... (x) F_q) applied to `batch` tensors that lie one after the other (the right-hand sides)
 template <typename T>
@@ -85,7 +87,12 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
     T* dst = bufA;
     auto next_out = [&](bool final) -> T* { return final ? y_dev : dst; };
     auto advance = [&]() { src = dst; dst = (dst == bufA) ? bufB : bufA; };
-    auto big = [&](int k) { return rows[k] >= BLAS_MIN_SIDE || cols[k] >= BLAS_MIN_SIDE; };
+    double total_in = (double)batch;
+    for (int i = 0; i < q; ++i) total_in *= (double)cols[i];
+    auto big = [&](int k) {
+        const int64_t side = std::max(rows[k], cols[k]);
+        return side >= BLAS_MIN_SIDE || (side >= BLAS_MID_SIDE && 2.0 * total_in * (double)rows[k] >= BLAS_MID_FLOPS);
+    };
     // the last two modes fused when the slab's rows fit the accumulators and there are enough slabs to fill the chip
     int64_t pre2 = batch;
     for (int i = 0; i + 2 < q; ++i) pre2 *= rows[i];     // leading extent once the other modes are done
@@ -97,6 +104,8 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
     if (pair) {
         const int64_t units = (pair_first ? pre2_first : pre2) * ((rows[q - 2] + 63) / 64);   // workgroups of the fused pass
         if (units < ctx->num_cus / 2) pair = false;   // a handful of slabs: the two modes one after the other spread wider
+        // small slabs leave most of the fused pass's eight waves idle (16^5: 104 us fused against 2 x 7 us mode by mode)
+        if (rows[q - 2] < PAIR_MIN_SIDE || cols[q - 1] < PAIR_MIN_SIDE) pair = false;
     }
     const int nsingle = pair ? q - 2 : q;
     int rc;

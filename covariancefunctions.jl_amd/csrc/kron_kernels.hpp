@@ -36,8 +36,12 @@ namespace kron {
 
 #ifdef KRON_DIAG
 #define KRON_DIAG_ON(p, bit) (((p).diag & (bit)) != 0)
+#define KRON_STAMP(p, idx) do { if ((p).stamps && (threadIdx.x & 63) == 0 && (idx) < 32) (p).stamps[((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define KRON_RSTAMP(p, idx) do { if ((p).stamps && (threadIdx.x & 63) == 0) (p).stamps[((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (idx)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define KRON_DIAG_ON(p, bit) false
+#define KRON_STAMP(p, idx) do { } while (0)
+#define KRON_RSTAMP(p, idx) do { } while (0)
 #endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -67,55 +71,72 @@ __host__ __device__ constexpr int lds_stride(int C) { return C + ((C % 32 == 0) 
 
 // A [ROWS][COLS] tile, contiguous along the columns, staged global -> registers -> LDS by NT threads, VB bytes per access.
 // Rows come in 16-row segments: row r is row (r & 15) of segment r >> 4, segments `seg` elements apart (16 * rs: plain rows).
+// TileGeo holds what a thread needs per access slot and never changes: tile coordinates and LDS offsets.  Moving a chunk then costs
+// one v_min per load (the clamp) and a handful of selects per LDS store — the kernels' MFMA partner wave pays for every VALU
+// instruction of this bookkeeping.
 template <typename T, int ROWS, int COLS, int NT, int VB = 16>
-struct Tile {
+struct TileGeo {
     static constexpr int VW = VB / (int)sizeof(T);
     static constexpr int CV = COLS / VW;
     static constexpr int NV = ROWS * CV;
     static constexpr int PER = (NV + NT - 1) / NT;
+    int r[PER], c[PER];       // tile row / first column of slot i
+    int lo[PER], lop[PER];    // LDS element offset of slot i: rows as they are / permuted inside their 16-row block (MM<T>::krow)
+    __device__ __forceinline__ void init(int tid, int stride) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = (NV % NT == 0) ? tid + i * NT : min(tid + i * NT, NV - 1);
+            r[i] = e / CV; c[i] = (e % CV) * VW;
+            lo[i] = r[i] * stride + c[i];
+            lop[i] = ((r[i] & ~15) | MM<T>::krow(r[i] & 15)) * stride + c[i];
+        }
+    }
+    // element offsets of the slots in a source with row stride rs and segment stride seg
+    __device__ __forceinline__ void offsets(uint32_t (&off)[PER], uint32_t rs, uint32_t seg) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) off[i] = (uint32_t)(r[i] >> 4) * seg + (uint32_t)(r[i] & 15) * rs + (uint32_t)c[i];
+    }
+};
+// offset of the last element of an nr x nc tile: every clamped access stays inside [src, src + that]
+__device__ __forceinline__ uint32_t tile_last(uint32_t rs, uint32_t seg, int nr, int nc) {
+    return (uint32_t)((nr - 1) >> 4) * seg + (uint32_t)((nr - 1) & 15) * rs + (uint32_t)(nc - 1);
+}
+
+template <typename T, int ROWS, int COLS, int NT, int VB = 16>
+struct Tile {
+    using Geo = TileGeo<T, ROWS, COLS, NT, VB>;
+    static constexpr int VW = Geo::VW, NV = Geo::NV, PER = Geo::PER;
     static constexpr int REGS = PER * VB / 4;     // VGPRs one in-flight tile takes
     using Vec = T __attribute__((ext_vector_type(VW)));
     Vec v[PER];
     int nr_, nc_;   // extents of the loaded part (wave-uniform): the rest is zeroed on the way to LDS
 
-    // element (r, c) = src[(r >> 4) * seg + (r & 15) * rs + c] for r < nr, c < nc (nr, nc >= 1), zero elsewhere.  VEC: every row start
-    // is VB-aligned and nc % VW == 0.  Every lane loads unconditionally from an offset clamped into the tile (32-bit offsets from
-    // the wave-uniform src: the launchers check the span) — straight-line code, no branch and no register copy behind a load, so
-    // the loads of several tiles stay in flight; store() replaces what lay outside by zeros.
+    // element (r, c) = src[off(r, c)] for r < nr, c < nc (nr, nc >= 1), zero elsewhere; `last` = tile_last(...) of this tile.
+    // VEC: every row start is VB-aligned and nc % VW == 0.  Every lane loads unconditionally from an offset clamped into the tile
+    // (32-bit offsets from the wave-uniform src: the launchers check the span) — straight-line code, no branch and no register
+    // copy behind a load, so the loads of several tiles stay in flight; store() replaces what lay outside by zeros.
     template <bool VEC>
-    __device__ __forceinline__ void load(const T* __restrict__ src, uint32_t rs, uint32_t seg, int nr, int nc, int tid) {
+    __device__ __forceinline__ void load(const T* __restrict__ src, const uint32_t (&off)[PER], uint32_t last, int nr, int nc) {
         nr_ = nr; nc_ = nc;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int e = (NV % NT == 0) ? tid + i * NT : min(tid + i * NT, NV - 1);
-            const int r = min(e / CV, nr - 1);
-            const uint32_t ro = (uint32_t)(r >> 4) * seg + (uint32_t)(r & 15) * rs;
             if constexpr (VEC) {
-                const int c = min((e % CV) * VW, nc - VW);
-                v[i] = *(const Vec*)(src + (ro + (uint32_t)c));
+                v[i] = *(const Vec*)(src + min(off[i], last - (uint32_t)(VW - 1)));
             } else {
-                const int c = (e % CV) * VW;
 #pragma unroll
-                for (int u = 0; u < VW; ++u) v[i][u] = src[ro + (uint32_t)min(c + u, nc - 1)];
+                for (int u = 0; u < VW; ++u) v[i][u] = src[min(off[i] + (uint32_t)u, last)];
             }
         }
     }
-    // perm: rows go to MM<T>::krow inside their 16-row block (stage 2 of the pair kernel)
-    __device__ __forceinline__ void store(T* lds, int stride, int tid, bool perm) const {
-        const bool full = (nr_ == ROWS) && (nc_ == COLS);
+    __device__ __forceinline__ void store(T* lds, const Geo& g, int tid, bool perm) const {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * NT;
-            if (NV % NT == 0 || e < NV) {
-                int r = e / CV;
-                const int c = (e % CV) * VW;
+            if (NV % NT == 0 || tid + i * NT < NV) {
                 Vec x = v[i];
-                if (!full) {
+                const bool rin = g.r[i] < nr_;
 #pragma unroll
-                    for (int u = 0; u < VW; ++u) x[u] = (r < nr_ && c + u < nc_) ? x[u] : (T)0;
-                }
-                if (perm) r = (r & ~15) | MM<T>::krow(r & 15);
-                *(Vec*)(lds + r * stride + c) = x;
+                for (int u = 0; u < VW; ++u) x[u] = (rin && g.c[i] + u < nc_) ? x[u] : (T)0;
+                *(Vec*)(lds + (perm ? g.lop[i] : g.lo[i])) = x;
             }
         }
     }
@@ -124,13 +145,15 @@ struct Tile {
 // chunks in flight by the registers one of them takes (a power of two, 2 ... 8)
 __host__ __device__ constexpr int depth_for(int regs_per_tile) { return regs_per_tile <= 12 ? 8 : (regs_per_tile <= 24 ? 4 : 2); }
 
-// fragment of a column-major factor F (ld): element s = F[row0 + (lane & 15)][k0 + 4 s + (lane >> 4)], from addresses clamped into
-// M x K (unconditional loads, no select behind them: they stay in flight until the fragment is used, chunks later).  Rows past M
-// only reach outputs that are never stored; columns past K are zeroed where the fragment is used (frag_at).
+// fragment of a column-major factor F (ld): element s = F[row0 + (lane & 15)][k0 + 4 s + (lane >> 4)].  `lane_off` = the lane's own
+// part of the element offset, min(row0 + lane % 16, M - 1) + (lane / 16) ld, and `lane_last` = its offset in column K - 1: the loads
+// are unconditional from offsets clamped into M x K (no select behind them: they stay in flight until the fragment is used, chunks
+// later).  Rows past M only reach outputs that are never stored; columns past K are zeroed where the fragment is used (frag_at).
 template <typename T, int NS>
-__device__ __forceinline__ void load_frag(T (&f)[NS], const T* __restrict__ Fm, uint32_t ld, int k0, int K, int lane) {
+__device__ __forceinline__ void load_frag(T (&f)[NS], const T* __restrict__ F, uint32_t lane_off, uint32_t lane_last, uint32_t ld, int k0) {
+    const uint32_t base = lane_off + (uint32_t)k0 * ld;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) f[s] = Fm[(uint32_t)min(k0 + 4 * s + (lane >> 4), K - 1) * ld];
+    for (int s = 0; s < NS; ++s) f[s] = F[min(base + (uint32_t)(4 * s) * ld, lane_last)];
 }
 template <typename T>
 __device__ __forceinline__ T frag_at(T x, int k0, int s, int K, int lane) { return (k0 + 4 * s + (lane >> 4) < K) ? x : (T)0; }
@@ -160,6 +183,7 @@ struct PairArgs {
     const T* F3; int64_t ld3;     // N2 x K2: mode q
     int32_t pre, K1, K2, M1, N2, groups;
     int32_t diag;                 // KRON_DIAG builds only (tools/kron_diag.sh): 1 = no MFMAs, 2 = no stores, 4 = no tile loads after the prologue
+    long long* stamps;            // KRON_DIAG builds only: [workgroup][wave][32] s_memtime stamps (tools/kron_stamps.py), or NULL
     T alpha, beta;
 };
 
@@ -169,105 +193,125 @@ struct PairArgs {
 //   stage 2  its accumulator blocks are the k-range of its half: partial Out[o2 strip][all o3 of the chunk]; a stage-2 LDS tile
 //            holds F3 block c of BOTH halves (rows 0-15: block c, rows 16-31: block NB1/2 + c), so both waves work in every step;
 //   the two partial sums meet in LDS, each wave adds and stores half of the chunk's o3 blocks.
+// The two halves run two copies of the body (H is a template parameter: straight-line code per half, no join inside the loops that
+// the wait-count insertion would have to be conservative about): half 1 moves the next chunk BEFORE its MFMAs, half 0 after, so
+// the two waves of a SIMD are out of phase and the matrix pipe always has one of them.
 // VEC: 16-byte accesses to the slab and to F3 (aligned bases, K2, ld3 and N2 multiples of the vector width).
 template <typename T, int NB1, int NB2, bool VEC>
-__global__ __launch_bounds__(512) void kron_pair_kernel(const PairArgs<T> p) {
-    using V4 = typename MM<T>::V4;
-    constexpr int NT = 512, KP = 32;
-    constexpr int HB1 = NB1 / 2, HB2 = NB2 / 2;
-    constexpr int C1 = 16 * NB1, C2 = 16 * NB2;
-    constexpr int CM = C1 > C2 ? C1 : C2;
-    constexpr int ST = lds_stride(CM);
+struct PairCfg {
+    static constexpr int NT = 512, KP = 32;
+    static constexpr int HB1 = NB1 / 2, HB2 = NB2 / 2;
+    static constexpr int C1 = 16 * NB1, C2 = 16 * NB2;
+    static constexpr int CM = C1 > C2 ? C1 : C2;
+    static constexpr int ST = lds_stride(CM);
     using TileT = Tile<T, KP, CM, NT>;
-    constexpr int D0 = depth_for(TileT::REGS) > 4 ? 4 : depth_for(TileT::REGS);
-    constexpr int D = D0 < HB1 ? D0 : HB1;          // divides HB1: every stage-2 round starts on register set 0
-    constexpr int DF = D < 2 ? D : 2;               // fragment sets (F2 comes out of L2)
-    __shared__ __attribute__((aligned(16))) T lds[2][KP * ST];
-    __shared__ __attribute__((aligned(16))) T xch[8][HB2 * 256];
+    static constexpr int D0 = depth_for(TileT::REGS) > 4 ? 4 : depth_for(TileT::REGS);
+    static constexpr int D = D0 < HB1 ? D0 : HB1;   // divides HB1: every stage-2 round starts on register set 0
+    static constexpr int DF = D < 2 ? D : 2;        // fragment sets (F2 comes out of L2)
+};
 
-    // blocks b and b + 8 share an XCD (and its L2): the strip groups of one slab are placed there
-    const int bid = blockIdx.x;
-    const int j0 = bid >> 3;
-    const int g = j0 % p.groups;
-    const int slab = (j0 / p.groups) * 8 + (bid & 7);
-    if (slab >= p.pre) return;
+template <typename T, int NB1, int NB2, bool VEC, int H>
+__device__ __forceinline__ void pair_body(const PairArgs<T>& p, T* __restrict__ lds0, T* __restrict__ lds1, T* __restrict__ xch, int slab, int g) {
+    using C = PairCfg<T, NB1, NB2, VEC>;
+    using V4 = typename MM<T>::V4;
+    using TileT = typename C::TileT;
+    constexpr int KP = C::KP, HB1 = C::HB1, HB2 = C::HB2, C2 = C::C2, ST = C::ST, D = C::D, DF = C::DF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = wave >> 2;                        // half of the i3 blocks (stage 1) / of the k-range and the stored o3 blocks (stage 2)
     const int row0 = (g * 4 + (wave & 3)) * 16;
     const bool live = row0 < p.M1;                  // idle waves of a ragged group still load and meet the barriers
     const T* S = p.in + (int64_t)slab * p.K1 * p.K2;
     T* O = p.out + (int64_t)slab * p.M1 * p.N2;
-    const int nb1 = (p.K2 + 15) >> 4;               // 16-row blocks of i3 that exist
     const int n1 = (p.K1 + KP - 1) / KP;
     const int n1p = (n1 + D - 1) / D * D;           // stage 1 padded to whole rounds of the register sets
     const int noc = (p.N2 + C2 - 1) / C2;
     const int njobs = n1p + noc * HB1;
     const int rdoff = (lane >> 4) * ST + (lane & 15);   // operand read: row 4 s + lane / 16, column 16 b + lane % 16
-    const T* F2m = p.F2 + min(row0 + (lane & 15), p.M1 - 1);
     const uint32_t ld2 = (uint32_t)p.ld2, ld3 = (uint32_t)p.ld3, K2u = (uint32_t)p.K2;
+    const uint32_t f2_lane = (uint32_t)min(row0 + (lane & 15), p.M1 - 1) + (uint32_t)(lane >> 4) * ld2;
+    const uint32_t f2_last = (uint32_t)min(row0 + (lane & 15), p.M1 - 1) + (uint32_t)(p.K1 - 1) * ld2;
+    auto ldsbuf = [&](int G) -> T* { return (G & 1) ? lds1 : lds0; };
 
     V4 acc1[HB1];
 #pragma unroll
     for (int b = 0; b < HB1; ++b) acc1[b] = V4{0, 0, 0, 0};
 
+    typename TileT::Geo geo;
+    geo.init(tid, ST);
+    uint32_t offS[TileT::PER], offF[TileT::PER], offF1[TileT::PER];   // slab chunks / F3 tiles with and without a second segment
+    geo.offsets(offS, K2u, 16 * K2u);
+    geo.offsets(offF, ld3, (uint32_t)(HB1 * 16) * ld3);
+    geo.offsets(offF1, ld3, 0u);
     TileT t[D];
     T frag[DF][8];
     // job G: stage 1 chunk G of the slab (G < n1; n1 <= G < n1p: nothing), then F3 blocks (c, HB1 + c) of output chunk oc,
     // (oc, c) = divmod(G - n1p, HB1)
     auto job_real = [&](int G) -> bool {
-        if (G < n1p) return G < n1;
-        return G < njobs && ((G - n1p) % HB1) * 16 < p.K2;
+        const int J = G - n1p;
+        return G < n1p ? G < n1 : (G < njobs && (J % HB1) * 16 < p.K2);
     };
-    // a job that does not exist loads chunk 0 of its stage again (valid addresses, never stored): no branch around a load
+    // One load sequence whatever the job is (its parameters are scalar selects): a job that does not exist loads chunk 0 of its
+    // stage again (valid addresses, never stored), so there is no branch around a load.
     auto issue = [&](int G, TileT& tt) {
         if (KRON_DIAG_ON(p, 4) && G >= D) return;
-        if (G < n1p) {
-            const int k0 = (G < n1 ? G : 0) * KP;
-            tt.template load<VEC>(S + (int64_t)k0 * p.K2, K2u, 16 * K2u, min(KP, p.K1 - k0), p.K2, tid);
-        } else {
-            const int J = G - n1p;
-            const bool real = G < njobs && (J % HB1) * 16 < p.K2;
-            const int oc = real ? J / HB1 : 0, c = real ? J % HB1 : 0;
-            const int o30 = oc * C2;
-            // rows of the second segment that exist: block HB1 + c of F3
-            const int nrb = min(16, p.K2 - (HB1 + c) * 16);
-            const int nr = nrb > 0 ? 16 + nrb : min(16, p.K2 - c * 16);
-            tt.template load<VEC>(p.F3 + (int64_t)(c * 16) * p.ld3 + o30, ld3, nrb > 0 ? (uint32_t)(HB1 * 16) * ld3 : 0u, nr, min(C2, p.N2 - o30), tid);
-        }
+        const bool st1 = G < n1p;
+        const int k0 = (G < n1 ? G : 0) * KP;
+        const int J = G - n1p;
+        const bool real2 = !st1 && G < njobs && (J % HB1) * 16 < p.K2;
+        const int oc = real2 ? J / HB1 : 0, c = real2 ? J % HB1 : 0;
+        const int o30 = oc * C2;
+        const int nrb = min(16, p.K2 - (HB1 + c) * 16);       // rows of the second segment that exist: block HB1 + c of F3
+        const int nr = st1 ? min(KP, p.K1 - k0) : (nrb > 0 ? 16 + nrb : min(16, p.K2 - c * 16));
+        const int nc = st1 ? p.K2 : min(C2, p.N2 - o30);
+        const T* src = st1 ? S + (int64_t)k0 * p.K2 : p.F3 + (int64_t)(c * 16) * p.ld3 + o30;
+        const uint32_t rs = st1 ? K2u : ld3;
+        const uint32_t seg = st1 ? 16 * K2u : (nrb > 0 ? (uint32_t)(HB1 * 16) * ld3 : 0u);
+        uint32_t off[TileT::PER];
+#pragma unroll
+        for (int i = 0; i < TileT::PER; ++i) off[i] = st1 ? offS[i] : (nrb > 0 ? offF[i] : offF1[i]);
+        tt.template load<VEC>(src, off, tile_last(rs, seg, nr, nc), nr, nc);
     };
-    auto issue_frag = [&](int G, T (&fr)[8]) { load_frag<T, 8>(fr, F2m, ld2, (G < n1 ? G : 0) * KP, p.K1, lane); };
+    auto issue_frag = [&](int G, T (&fr)[8]) { load_frag<T, 8>(fr, p.F2, f2_lane, f2_last, ld2, (G < n1 ? G : 0) * KP); };
+    // operands of k-step s + 1 are read from LDS before the MFMAs of k-step s issue
     auto mma1 = [&](int G, const T (&fr)[8]) {
-        const T* L = lds[G & 1] + rdoff + h * (HB1 * 16);
+        const T* L = ldsbuf(G) + rdoff + H * (HB1 * 16);
+        T a[2][HB1];
+#pragma unroll
+        for (int b = 0; b < HB1; ++b) a[0][b] = L[b * 16];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) {
+#pragma unroll
+                for (int b = 0; b < HB1; ++b) a[(s + 1) & 1][b] = L[(s + 1) * 4 * ST + b * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the reads of k-step s + 1 stay ahead of the MFMAs of k-step s
             const T fs = frag_at<T>(fr[s], G * KP, s, p.K1, lane);
 #pragma unroll
-            for (int b = 0; b < HB1; ++b) acc1[b] = MM<T>::mma(L[s * 4 * ST + b * 16], fs, acc1[b]);   // blocks past K2 multiply LDS zeros
+            for (int b = 0; b < HB1; ++b) acc1[b] = MM<T>::mma(a[s & 1][b], fs, acc1[b]);   // blocks past K2 multiply LDS zeros
         }
     };
 #pragma unroll
     for (int k = 0; k < D; ++k) issue(k, t[k]);
 #pragma unroll
     for (int k = 0; k < DF; ++k) issue_frag(k, frag[k]);
-    t[0].store(lds[0], ST, tid, false);
+    KRON_STAMP(p, 0);
+    KRON_RSTAMP(p, 28);
+    t[0].store(lds0, geo, tid, false);
     __syncthreads();
-    // ---- stage 1: T1^T[i3][o2] += S[i2][i3] F2[o2][i2] over chunks of i2.  Half 1 moves the next chunk before its MFMAs, half 0
-    // after: the two waves of a SIMD are out of phase and the matrix pipe always has one of them.
+    KRON_STAMP(p, 1);
+    // ---- stage 1: T1^T[i3][o2] += S[i2][i3] F2[o2][i2] over chunks of i2
     for (int c0 = 0; c0 < n1p; c0 += D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const int G = c0 + k;
-            if (h) {
-                issue(G + D, t[k]);      // the chunk this register set held is in LDS since the previous step
-                if (job_real(G + 1)) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, G + 1 >= n1p);
-                if (G < n1 && live && !KRON_DIAG_ON(p, 1)) mma1(G, frag[k % DF]);
-            } else {
-                if (G < n1 && live && !KRON_DIAG_ON(p, 1)) mma1(G, frag[k % DF]);
-                issue(G + D, t[k]);
-                if (job_real(G + 1)) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, G + 1 >= n1p);
-            }
+            const bool work = G < n1 && live && !KRON_DIAG_ON(p, 1);
+            if (H == 0) { if (work) mma1(G, frag[k % DF]); }
+            issue(G + D, t[k]);      // the chunk this register set held is in LDS since the previous step
+            if (job_real(G + 1)) t[(k + 1) % D].store(ldsbuf(G + 1), geo, tid, G + 1 >= n1p);
+            if (H == 1) { if (work) mma1(G, frag[k % DF]); }
             issue_frag(G + DF, frag[k % DF]);
+            KRON_STAMP(p, 2 + 2 * G);
             __syncthreads();
+            KRON_STAMP(p, 3 + 2 * G);
         }
     }
     // ---- stage 2: Out[o2][o3] = sum_{i3} T1^T[i3][o2] F3[o3][i3]; accumulator register r of block c is the A operand of k-step r
@@ -281,45 +325,67 @@ __global__ __launch_bounds__(512) void kron_pair_kernel(const PairArgs<T> p) {
             const int k = c % D;
             const int G = n1p + oc * HB1 + c;
             auto mma2 = [&]() {
-                const T* L = lds[G & 1] + rdoff + h * (16 * ST);
+                const T* L = ldsbuf(G) + rdoff + H * (16 * ST);
+                T bq[2][NB2];
+#pragma unroll
+                for (int b = 0; b < NB2; ++b) bq[0][b] = L[b * 16];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (r + 1 < 4) {
 #pragma unroll
-                    for (int b = 0; b < NB2; ++b) acc2[b] = MM<T>::mma(acc1[c][r], L[r * 4 * ST + b * 16], acc2[b]);
+                        for (int b = 0; b < NB2; ++b) bq[(r + 1) & 1][b] = L[(r + 1) * 4 * ST + b * 16];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b) acc2[b] = MM<T>::mma(acc1[c][r], bq[r & 1][b], acc2[b]);
                 }
             };
-            const bool work = live && (h * HB1 + c) * 16 < p.K2 && !KRON_DIAG_ON(p, 1);
-            if (h) {
-                issue(G + D, t[k]);
-                if (job_real(G + 1)) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, true);
-                if (work) mma2();
-            } else {
-                if (work) mma2();
-                issue(G + D, t[k]);
-                if (job_real(G + 1)) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, true);
-            }
+            const bool work = live && (H * HB1 + c) * 16 < p.K2 && !KRON_DIAG_ON(p, 1);
+            if (H == 0) { if (work) mma2(); }
+            issue(G + D, t[k]);
+            if (job_real(G + 1)) t[(k + 1) % D].store(ldsbuf(G + 1), geo, tid, true);
+            if (H == 1) { if (work) mma2(); }
+            KRON_STAMP(p, 2 + 2 * G);
             __syncthreads();
+            KRON_STAMP(p, 3 + 2 * G);
         }
         // the two halves' partial sums: each wave hands the partner the blocks the partner stores
         {
-            T* X = xch[wave];
+            T* X = xch + wave * (HB2 * 256);
 #pragma unroll
             for (int b = 0; b < HB2; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) X[(b * 4 + r) * 64 + lane] = h ? acc2[b][r] : acc2[HB2 + b][r];
+                for (int r = 0; r < 4; ++r) X[(b * 4 + r) * 64 + lane] = H ? acc2[b][r] : acc2[HB2 + b][r];
             __syncthreads();
-            const T* Y = xch[wave ^ 4];
+            const T* Y = xch + (wave ^ 4) * (HB2 * 256);
             if (live && !KRON_DIAG_ON(p, 2)) {
 #pragma unroll
                 for (int b = 0; b < HB2; ++b) {
-                    V4 v = h ? acc2[HB2 + b] : acc2[b];
+                    V4 v = H ? acc2[HB2 + b] : acc2[b];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += Y[(b * 4 + r) * 64 + lane];
-                    store_tile<T>(v, O, p.N2, row0, p.M1, o30 + (h * HB2 + b) * 16, p.N2, p.alpha, p.beta, lane);
+                    store_tile<T>(v, O, p.N2, row0, p.M1, o30 + (H * HB2 + b) * 16, p.N2, p.alpha, p.beta, lane);
                 }
             }
+            KRON_STAMP(p, 30);
+            KRON_RSTAMP(p, 29);
         }
     }
+}
+
+template <typename T, int NB1, int NB2, bool VEC>
+__global__ __launch_bounds__(512) void kron_pair_kernel(const PairArgs<T> p) {
+    using C = PairCfg<T, NB1, NB2, VEC>;
+    __shared__ __attribute__((aligned(16))) T lds[2][C::KP * C::ST];
+    __shared__ __attribute__((aligned(16))) T xch[8 * C::HB2 * 256];
+    // blocks b and b + 8 share an XCD (and its L2): the strip groups of one slab are placed there
+    const int bid = blockIdx.x;
+    const int j0 = bid >> 3;
+    const int g = j0 % p.groups;
+    const int slab = (j0 / p.groups) * 8 + (bid & 7);
+    if (slab >= p.pre) return;
+    if (threadIdx.x < 256) pair_body<T, NB1, NB2, VEC, 0>(p, lds[0], lds[1], xch, slab, g);
+    else pair_body<T, NB1, NB2, VEC, 1>(p, lds[0], lds[1], xch, slab, g);
 }
 
 template <typename T>
@@ -357,43 +423,59 @@ __global__ __launch_bounds__(64 * NW) void kron_mode_kernel(const ModeArgs<T> p)
     const int nbp = (nc + 15) >> 4;
     const int n1 = (p.K + KC - 1) / KC;
     const int n1p = (n1 + D - 1) / D * D;           // whole rounds of the register sets: no branch around a load
-    const T* Fm = p.F + min(row0 + (lane & 15), p.M - 1);
     const uint32_t ldf = (uint32_t)p.ld, postu = (uint32_t)p.post;
+    const uint32_t f_lane = (uint32_t)min(row0 + (lane & 15), p.M - 1) + (uint32_t)(lane >> 4) * ldf;
+    const uint32_t f_last = (uint32_t)min(row0 + (lane & 15), p.M - 1) + (uint32_t)(p.K - 1) * ldf;
 
     V4 acc[NBP];
 #pragma unroll
     for (int q = 0; q < NBP; ++q) acc[q] = V4{0, 0, 0, 0};
+    typename TileT::Geo geo;
+    geo.init(tid, ST);
+    uint32_t off[TileT::PER];
+    geo.offsets(off, postu, 16 * postu);
     TileT t[D];
     T frag[D][4];
     auto issue = [&](int G, TileT& tt) {          // past the end: chunk 0 again, never stored
         if (KRON_DIAG_ON(p, 4) && G >= D) return;
         const int k0 = (G < n1 ? G : 0) * KC;
-        tt.template load<VEC>(In + (int64_t)k0 * p.post, postu, 16 * postu, min(KC, p.K - k0), nc, tid);
+        const int nr = min(KC, p.K - k0);
+        tt.template load<VEC>(In + (int64_t)k0 * p.post, off, tile_last(postu, 16 * postu, nr, nc), nr, nc);
     };
-    auto issue_frag = [&](int G, T (&fr)[4]) { load_frag<T, 4>(fr, Fm, ldf, (G < n1 ? G : 0) * KC, p.K, lane); };
+    auto issue_frag = [&](int G, T (&fr)[4]) { load_frag<T, 4>(fr, p.F, f_lane, f_last, ldf, (G < n1 ? G : 0) * KC); };
 #pragma unroll
     for (int k = 0; k < D; ++k) { issue(k, t[k]); issue_frag(k, frag[k]); }
-    t[0].store(lds[0], ST, tid, false);
+    t[0].store(lds[0], geo, tid, false);
     __syncthreads();
     for (int c0 = 0; c0 < n1p; c0 += D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const int G = c0 + k;
+            if (G >= n1) goto done;      // a short K does not walk the rest of the round
             issue(G + D, t[k]);
-            if (G < n1 && live && !KRON_DIAG_ON(p, 1)) {
+            if (live && !KRON_DIAG_ON(p, 1)) {
                 const T* L = lds[G & 1] + (lane >> 4) * ST + (lane & 15);
+                T bq[2][NBP];
+#pragma unroll
+                for (int q = 0; q < NBP; ++q) bq[0][q] = L[q * 16];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
+                    if (s + 1 < 4) {
+#pragma unroll
+                        for (int q = 0; q < NBP; ++q) bq[(s + 1) & 1][q] = L[(s + 1) * 4 * ST + q * 16];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     const T fs = frag_at<T>(frag[k][s], G * KC, s, p.K, lane);
 #pragma unroll
-                    for (int q = 0; q < NBP; ++q) acc[q] = MM<T>::mma(fs, L[s * 4 * ST + q * 16], acc[q]);
+                    for (int q = 0; q < NBP; ++q) acc[q] = MM<T>::mma(fs, bq[s & 1][q], acc[q]);
                 }
             }
             issue_frag(G + D, frag[k]);
-            if (G + 1 < n1) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, false);
+            if (G + 1 < n1) t[(k + 1) % D].store(lds[(G + 1) & 1], geo, tid, false);
             __syncthreads();
         }
     }
+done:
     if (live && !KRON_DIAG_ON(p, 2)) {
 #pragma unroll
         for (int q = 0; q < NBP; ++q)
@@ -425,29 +507,36 @@ __global__ __launch_bounds__(64 * NW) void kron_modet_kernel(const ModeArgs<T> p
     const int nbb = (nr + 15) >> 4;
     const int n1 = (p.K + KT - 1) / KT;
     const int n1p = (n1 + D - 1) / D * D;
-    const T* Fm = p.F + min(col0 + (lane & 15), p.M - 1);
     const uint32_t ldf = (uint32_t)p.ld, Ku = (uint32_t)p.K;
+    const uint32_t f_lane = (uint32_t)min(col0 + (lane & 15), p.M - 1) + (uint32_t)(lane >> 4) * ldf;
+    const uint32_t f_last = (uint32_t)min(col0 + (lane & 15), p.M - 1) + (uint32_t)(p.K - 1) * ldf;
 
     V4 acc[NBB];
 #pragma unroll
     for (int q = 0; q < NBB; ++q) acc[q] = V4{0, 0, 0, 0};
+    typename TileT::Geo geo;
+    geo.init(tid, ST);
+    uint32_t off[TileT::PER];
+    geo.offsets(off, Ku, 16 * Ku);
     TileT t[D];
     T frag[D][8];
     auto issue = [&](int G, TileT& tt) {
         const int k0 = (G < n1 ? G : 0) * KT;
-        tt.template load<VEC>(In + k0, Ku, 16 * Ku, nr, min(KT, p.K - k0), tid);
+        const int ncols = min(KT, p.K - k0);
+        tt.template load<VEC>(In + k0, off, tile_last(Ku, 16 * Ku, nr, ncols), nr, ncols);
     };
-    auto issue_frag = [&](int G, T (&fr)[8]) { load_frag<T, 8>(fr, Fm, ldf, (G < n1 ? G : 0) * KT, p.K, lane); };
+    auto issue_frag = [&](int G, T (&fr)[8]) { load_frag<T, 8>(fr, p.F, f_lane, f_last, ldf, (G < n1 ? G : 0) * KT); };
 #pragma unroll
     for (int k = 0; k < D; ++k) { issue(k, t[k]); issue_frag(k, frag[k]); }
-    t[0].store(lds[0], ST, tid, false);
+    t[0].store(lds[0], geo, tid, false);
     __syncthreads();
     for (int c0 = 0; c0 < n1p; c0 += D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const int G = c0 + k;
+            if (G >= n1) goto done;
             issue(G + D, t[k]);
-            if (G < n1 && live) {
+            if (live) {
                 const T* L = lds[G & 1] + (lane & 15) * ST + (lane >> 4);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -457,10 +546,11 @@ __global__ __launch_bounds__(64 * NW) void kron_modet_kernel(const ModeArgs<T> p
                 }
             }
             issue_frag(G + D, frag[k]);
-            if (G + 1 < n1) t[(k + 1) % D].store(lds[(G + 1) & 1], ST, tid, false);
+            if (G + 1 < n1) t[(k + 1) % D].store(lds[(G + 1) & 1], geo, tid, false);
             __syncthreads();
         }
     }
+done:
     if (live) {
         T* O = p.out + (int64_t)b0 * p.M;
 #pragma unroll
@@ -473,7 +563,11 @@ __global__ __launch_bounds__(64 * NW) void kron_modet_kernel(const ModeArgs<T> p
 // launchers (each explicitly instantiated in its own translation unit: kron_inst.hip with KRON_T / KRON_PART)
 // ---------------------------------------------------------------------------------------------------------------------------
 static inline bool aligned_to(const void* p, int bytes) { return ((uintptr_t)p & (uintptr_t)(bytes - 1)) == 0; }
-static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#ifdef KRON_DIAG
+static inline int diag_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static inline int diag_env(const char*) { return 0; }   // the product build reads no environment
+#endif
 
 // waves per workgroup for `strips` 16-row strips when `units` independent workgroup positions exist: all strips in one
 // workgroup read the tensor chunk once; fewer waves per workgroup when that would leave CUs idle
@@ -497,7 +591,7 @@ int run_pair(covgram_ctx* ctx, const T* in, T* out, const T* F2, int64_t ld2, in
     PairArgs<T> a;
     a.in = in; a.out = out; a.F2 = F2; a.ld2 = ld2; a.F3 = F3; a.ld3 = ld3;
     a.pre = (int32_t)pre; a.K1 = (int32_t)K1; a.K2 = (int32_t)K2; a.M1 = (int32_t)M1; a.N2 = (int32_t)N2;
-    a.alpha = alpha; a.beta = beta; a.diag = env_int("COVGRAM_KRON_DIAG", 0);
+    a.alpha = alpha; a.beta = beta; a.diag = diag_env("COVGRAM_KRON_DIAG"); a.stamps = nullptr;
     CG_REQUIRE(pair_ok(K1, K2, ld2, ld3), COVGRAM_EUNSUPPORTED, "kron: factor too large for the fused pass");
     const bool vec = aligned_to(in, 16) && (K2 % VW == 0) && aligned_to(F3, 16) && (ld3 % VW == 0) && (N2 % VW == 0);
     const int strips = (int)((M1 + 15) / 16);
@@ -505,11 +599,28 @@ int run_pair(covgram_ctx* ctx, const T* in, T* out, const T* F2, int64_t ld2, in
     const int64_t nblocks = ((pre + 7) / 8) * 8 * a.groups;
     CG_REQUIRE(nblocks < ((int64_t)1 << 31), COVGRAM_EUNSUPPORTED, "kron: too many slabs (%lld)", (long long)pre);
     const dim3 grid((unsigned)nblocks);
+#ifdef KRON_DIAG
+    static long long* stamp_buf = nullptr;
+    const char* stamp_path = getenv("COVGRAM_KRON_STAMPS");
+    const size_t stamp_bytes = (size_t)nblocks * 8 * 32 * sizeof(long long);
+    if (stamp_path) {
+        if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)1 << 26);
+        (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, ctx->stream);
+        a.stamps = stamp_buf;
+    }
+#endif
     const int nb1 = (int)((K2 + 15) / 16);
     const bool wide = N2 > 64;      // output chunks of 128 columns, 64 for narrow last factors
-    if (nb1 <= 2) { if (wide) launch_pair<T, 2, 8>(a, vec, grid, ctx->stream); else launch_pair<T, 2, 4>(a, vec, grid, ctx->stream); }
-    else if (nb1 <= 4) { if (wide) launch_pair<T, 4, 8>(a, vec, grid, ctx->stream); else launch_pair<T, 4, 4>(a, vec, grid, ctx->stream); }
+    if (nb1 <= 4) { if (wide) launch_pair<T, 4, 8>(a, vec, grid, ctx->stream); else launch_pair<T, 4, 4>(a, vec, grid, ctx->stream); }
     else { if (wide) launch_pair<T, 8, 8>(a, vec, grid, ctx->stream); else launch_pair<T, 8, 4>(a, vec, grid, ctx->stream); }
+#ifdef KRON_DIAG
+    if (stamp_path) {   // the last launch's stamps, raw int64 [workgroup][wave][32]
+        std::vector<long long> h(stamp_bytes / sizeof(long long));
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_path, "wb")) { fwrite(h.data(), 1, stamp_bytes, f); fclose(f); }
+    }
+#endif
     return COVGRAM_OK;
 }
 
@@ -529,17 +640,15 @@ int run_mode(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t ld, int6
     constexpr int VW = 16 / (int)sizeof(T);
     ModeArgs<T> a;
     a.in = in; a.out = out; a.F = F; a.ld = ld; a.post = post;
-    a.pre = (int32_t)pre; a.K = (int32_t)K; a.M = (int32_t)M; a.alpha = alpha; a.beta = beta; a.diag = env_int("COVGRAM_KRON_DIAG", 0);
+    a.pre = (int32_t)pre; a.K = (int32_t)K; a.M = (int32_t)M; a.alpha = alpha; a.beta = beta; a.diag = diag_env("COVGRAM_KRON_DIAG");
     CG_REQUIRE(mode_ok(K, post, ld), COVGRAM_EUNSUPPORTED, "kron: tensor rows too far apart for the mode kernel");
     const bool vec = aligned_to(in, 16) && (post % VW == 0);
     const int strips = (int)((M + 15) / 16);
     // column tiles: 128 wide when that still gives every CU a workgroup, else 64 / 32
     int nbp = 8;
     while (nbp > 2 && (16 * nbp / 2 >= post || pre * ((post + 16 * nbp - 1) / (16 * nbp)) < (int64_t)ctx->num_cus)) nbp /= 2;
-    nbp = env_int("COVGRAM_KRON_NBP", nbp);
     const int64_t ntiles = (post + 16 * nbp - 1) / (16 * nbp);
-    int nw = pick_nw(strips, pre * ntiles, ctx->num_cus, 4, 8);
-    nw = env_int("COVGRAM_KRON_NW", nw);
+    const int nw = pick_nw(strips, pre * ntiles, ctx->num_cus, 4, 8);
     a.groups = (strips + nw - 1) / nw;
     a.ntiles = (int32_t)ntiles;
     const int64_t nblocks = pre * ntiles * a.groups;

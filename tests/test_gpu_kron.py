@@ -1,8 +1,8 @@
 """Kronecker MVM kernels (csrc/kron.hip) against the oracle's mode products (oracle/covgram_oracle.py::kron_mul, the identity
 KroneckerProducts 1.1.1 implements for the operators src/algebra.jl:91-95 and src/separable.jl:33-42 build).
 
-Every kernel and every template branch: the fused last-two-modes pass (kron_pair_kernel: 16 NB1 slab columns, NB1 in {2, 4, 8}; output chunks
-of 16 NB2 columns incl. more than one chunk; 1, 2 and 4 waves per workgroup; ragged strips), the single-mode kernels with trailing modes
+Every kernel and every template branch: the fused last-two-modes pass (kron_pair_kernel: 16 NB1 slab columns, NB1 in {4, 8}; output chunks
+of 16 NB2 columns incl. more than one chunk; ragged strips; small slabs go mode by mode), the single-mode kernels with trailing modes
 (kron_mode_kernel) and without (kron_modet_kernel: q = 1, c_q > 128, too few slabs), aligned (16-byte vector) and unaligned tensors, fp32 and
 fp64, alpha / beta, matrix right-hand sides, padded leading dimensions through the raw ABI, and the rocBLAS route for factors >= 1024."""
 import ctypes as C
