@@ -834,11 +834,12 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // set on both sides, one right-hand side, a single (non-composite) profile without a Power wrapper, d <= 64; from n = 8192 (16384 for
     // the profiles that cost a reciprocal or less: below that the launch is latency and the triangle's imbalance, not arithmetic —
     // tools/fp64_sym_sweep.py: break-even at n ~ 6000, x1.1-1.25 at 8192, x1.3-1.5 at 16384, x1.5-1.75 from 32768) while the column-sum
-    // slab n^2 / 8 bytes stays within 2 GiB (n <= 131072).
+    // slab n^2 / 8 bytes — held in workspace slot 4 for the life of the ctx — stays within 1 GiB (n <= 92681) when the choice is automatic,
+    // 2 GiB (n <= 131072) when option "dense_sym" = 1 asks for it; R = 1 row per lane (64-row blocks) is what the kernel is written for.
     const bool cheap_profile = hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ || hk.tu_family == COVGRAM_DOT;
     const bool dsym = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && ctx->dense_sym != 0 && X->dptr == Y->dptr && n == m &&
                       hk.tu_family < COVGRAM_NFAMILY && hk.k.power == 1 && (ctx->dense_sym == 1 || n >= (cheap_profile ? 16384 : 8192)) &&
-                      (size_t)rowblocks * (size_t)npad * ts <= ((size_t)2 << 30);
+                      R == 1 && (size_t)rowblocks * (size_t)npad * ts <= ((size_t)(ctx->dense_sym == 1 ? 2 : 1) << 30);
     ctx->last_dense_sym = dsym ? 1 : 0;
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);

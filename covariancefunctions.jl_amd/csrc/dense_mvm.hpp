@@ -425,6 +425,8 @@ __global__ __launch_bounds__(1024) void dense_sym_reduce_kernel(const double* __
 
 template <int FAM, int D>
 static int launch_dense_sym_one(const DenseArgs& a) {
+    // the kernel, its reduce kernel and covgram_mvm's slab sizes are written for 64-row blocks and one wave per workgroup
+    static_assert(DENSE_THREADS == 64, "dense_sym_kernel: 64-row blocks, one wave per workgroup (CG_DENSE_THREADS must stay 64)");
     const typename ParamsOf<FAM, double>::type kp = make_params<FAM, double>(*a.hk);
     dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)a.jsplit);
     hipLaunchKernelGGL((dense_sym_kernel<FAM, D>), grid, dim3(DENSE_THREADS), 0, a.stream, (const double*)a.X, a.n, a.d,

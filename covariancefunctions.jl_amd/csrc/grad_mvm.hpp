@@ -196,7 +196,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
         }
         if constexpr (EXPD) {                                     // x'.y' -> |x' - y'|^2 (never negative), x'.a -> r'.a
             s = cg_fma((T)-2, s, nx + eny);
-            s = s > (T)0 ? s : (T)0;
+            s = (s < (T)0) ? (T)0 : s;      // rounding may take s a few ulp below zero; a NaN coordinate stays a NaN (as on the direct-difference path)
             t -= eya;
         }
         T k1, k2, c2;

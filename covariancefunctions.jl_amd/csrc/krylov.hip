@@ -40,7 +40,8 @@ __global__ __launch_bounds__(CG_THREADS) void cg_update_kernel(int64_t n, T* __r
                                                                const T* __restrict__ Ap, T* __restrict__ scal, int nblocks) {
     __shared__ double sh[CG_THREADS / 64];
     const double pAp = block_sum<T>(threadIdx.x < nblocks ? (double)scal[2 + threadIdx.x] : 0.0, sh);
-    const T alpha = (T)((double)scal[0] / pAp);
+    // a converged system (r = 0 exactly: rho = 0 and p . Ap = 0) keeps iterating under a replayed graph: 0 / 0 must not reach x
+    const T alpha = (scal[0] == (T)0 || pAp == 0.0) ? (T)0 : (T)((double)scal[0] / pAp);
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) {
         x[i] = cg_fma(alpha, p[i], x[i]);
@@ -57,7 +58,7 @@ template <typename T>
 __global__ __launch_bounds__(CG_THREADS) void cg_direction_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ r, T* __restrict__ scal, int nblocks) {
     __shared__ double sh[CG_THREADS / 64];
     const double rho = block_sum<T>(threadIdx.x < nblocks ? (double)scal[2 + CG_BLOCKS + threadIdx.x] : 0.0, sh);
-    const T beta = (T)(rho / (double)scal[0]);
+    const T beta = (scal[0] == (T)0) ? (T)0 : (T)(rho / (double)scal[0]);
     for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) p[i] = cg_fma(beta, p[i], r[i]);
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = (T)rho;
 }

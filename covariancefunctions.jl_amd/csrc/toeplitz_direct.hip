@@ -141,6 +141,7 @@ static int stage_in(covgram_ctx* ctx, char*& p, const void* src, size_t bytes, i
 int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y, int32_t dtype, int32_t loc) {
     CG_REQUIRE(ctx && r && y, COVGRAM_EINVAL, "NULL argument");
     CG_REQUIRE(n >= 1, COVGRAM_EINVAL, "durbin: need n >= 1");
+    CG_REQUIRE(n <= COVGRAM_TOEPLITZ_DIRECT_MAX_N, COVGRAM_EUNSUPPORTED, "durbin: n = %lld is above the direct solvers' cap of %d (one uninterruptible launch of n - 1 dependent O(n) steps): use the preconditioned CG over the FFT MVM", (long long)n, COVGRAM_TOEPLITZ_DIRECT_MAX_N);
     CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
     const size_t ts = dtype_size(dtype), vb = ((size_t)n * ts + 255) & ~(size_t)255;
     CG_DEVICE(ctx);
@@ -158,6 +159,7 @@ int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y,
 int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, int64_t n, void* x, int32_t dtype, int32_t loc) {
     CG_REQUIRE(ctx && b && x && (r || n == 1), COVGRAM_EINVAL, "NULL argument");
     CG_REQUIRE(n >= 1, COVGRAM_EINVAL, "levinson: need n >= 1");
+    CG_REQUIRE(n <= COVGRAM_TOEPLITZ_DIRECT_MAX_N, COVGRAM_EUNSUPPORTED, "levinson: n = %lld is above the direct solvers' cap of %d (one uninterruptible launch of n - 1 dependent O(n) steps): use the preconditioned CG over the FFT MVM", (long long)n, COVGRAM_TOEPLITZ_DIRECT_MAX_N);
     CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
     const size_t ts = dtype_size(dtype), vb = ((size_t)n * ts + 255) & ~(size_t)255;
     CG_DEVICE(ctx);
@@ -184,6 +186,7 @@ int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, in
 int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B, int64_t ldb, int32_t dtype, int32_t loc) {
     CG_REQUIRE(ctx && B && (r || n == 1), COVGRAM_EINVAL, "NULL argument");
     CG_REQUIRE(n >= 1 && ldb >= n, COVGRAM_EINVAL, "trench: need n >= 1 and ldb >= n");
+    CG_REQUIRE(n <= COVGRAM_TOEPLITZ_DIRECT_MAX_N, COVGRAM_EUNSUPPORTED, "trench: n = %lld is above the direct solvers' cap of %d", (long long)n, COVGRAM_TOEPLITZ_DIRECT_MAX_N);
     CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "unknown dtype %d", dtype);
     const size_t ts = dtype_size(dtype), vb = ((size_t)n * ts + 255) & ~(size_t)255;
     CG_DEVICE(ctx);

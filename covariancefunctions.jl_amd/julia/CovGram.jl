@@ -57,11 +57,14 @@ const F_EQ, F_EXP, F_RQ, F_GAMMAEXP, F_CAUCHY, F_IMQ, F_MATERNP, F_DOT, F_EXPDOT
 const F_CONSTANT, F_COMPOSITE = Int32(100), Int32(101)
 const ISO, DOTP = Int32(1), Int32(2)
 const HOST, DEVICE = Int32(0), Int32(1)
+const ABI_VERSION = 110              # COVGRAM_VERSION of the header these ccall signatures mirror
 dtype_code(::Type{Float32}) = Int32(0); dtype_code(::Type{Float64}) = Int32(1)
 const DevFloat = Union{Float32, Float64}
 
 function __init__()
     isfile(libcovgram) || return          # enable!() reports the missing library
+    v = ccall((:covgram_version, libcovgram), Cint, ())
+    v == ABI_VERSION || error("libcovgram.so is ABI version $v, CovGram.jl binds version $ABI_VERSION (include/covgram.h COVGRAM_VERSION): rebuild the library")
     sk = ccall((:covgram_sizeof_kernel, libcovgram), Cint, ())
     sc = ccall((:covgram_sizeof_composite, libcovgram), Cint, ())
     (sk == sizeof(CKernel) && sc == sizeof(CComposite)) ||
@@ -329,7 +332,14 @@ function device_trench(r::Vector{T}) where {T <: DevFloat}
 end
 device_levinson(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = device_levinson(A.vc[2:end] ./ A.vc[1], b) ./ A.vc[1]
 device_trench(A::DeviceToeplitz) = Symmetric(parent(device_trench(A.vc[2:end] ./ A.vc[1])) ./ A.vc[1])
-LinearAlgebra.:\(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = issymmetric(A) ? device_levinson(A, b) : error("only symmetric Toeplitz solves are served")
+# `\`: Levinson is ONE launch of n - 1 dependent O(n) steps on one workgroup (0.13 s at n = 16384, growing with n²; the library refuses
+# it above COVGRAM_TOEPLITZ_DIRECT_MAX_N = 65536), so it serves the small systems only; larger ones go to conjugate gradients over the FFT
+# MVM (`mul!` above: covgram_toeplitz_mvm), the reference's own solver for lazy operators (src/gramian.jl:229-238).
+const LEVINSON_MAX_N = 16384
+function LinearAlgebra.:\(A::DeviceToeplitz{T}, b::Vector{T}) where {T}
+    issymmetric(A) || error("only symmetric Toeplitz solves are served")
+    length(b) <= LEVINSON_MAX_N ? device_levinson(A, b) : CovarianceFunctions.IterativeSolvers.cg(A, b)
+end
 
 # --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, mode products on the matrix cores (csrc/kron.hip) --
 struct DeviceKronecker{T} <: AbstractMatrix{T}

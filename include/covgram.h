@@ -146,7 +146,8 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * -1 = from n = 12500 ... 18000 by the profile's cost, 0 = never, 1 = always),
  * "dense_sym" (the same for fp64 on the direct-difference path — the reference's default element type: gramian(k, x) with one
  * right-hand side evaluates every entry on or above the diagonal blocks once, dense_sym_kernel; -1 = from n = 8192 (16384 for
- * Cauchy / IMQ / Dot), 0 = never, 1 = always),
+ * Cauchy / IMQ / Dot) while its column-sum slab of n^2 / 8 bytes stays within 1 GiB, 0 = never, 1 = always, up to a 2 GiB slab — the
+ * slab lives in the ctx's workspace until the ctx is destroyed: 512 MiB at n = 65536, once per ctx),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
@@ -223,7 +224,10 @@ int covgram_toeplitz_destroy(covgram_toeplitz* T);
  *   covgram_toeplitz_durbin    replaces durbin!(y, r)        src/toeplitz.jl:12-27    y = K_n \ (-r), K_n = SymmetricToeplitz([1, r[1:n-1]]), n = length(r)
  *   covgram_toeplitz_levinson  replaces levinson!(x, r, b)   src/toeplitz.jl:75-98    x = K \ b, n = length(b) = length(r) + 1
  *   covgram_toeplitz_trench    replaces trench!(B, r)        src/toeplitz.jl:52-71    B = inv(K), n x n column-major (ldb), BOTH triangles filled
- * Durbin / Levinson are chains of n - 1 dependent steps: one workgroup walks them (O(n^2 / 1024) thread steps). */
+ * Durbin / Levinson are chains of n - 1 dependent steps: one workgroup walks them (O(n^2 / 1024) thread steps) in ONE launch that cannot be
+ * interrupted (n = 16384: 0.13 s; it grows with n^2), so all three return COVGRAM_EUNSUPPORTED above COVGRAM_TOEPLITZ_DIRECT_MAX_N: larger systems are
+ * for the circulant-preconditioned CG over covgram_toeplitz_mvm (covgram/solve.py: toeplitz_solve; julia/CovGram.jl: `\`). */
+#define COVGRAM_TOEPLITZ_DIRECT_MAX_N 65536
 int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y, int32_t dtype, int32_t loc);
 int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, int64_t n, void* x, int32_t dtype, int32_t loc);
 int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B, int64_t ldb, int32_t dtype, int32_t loc);
