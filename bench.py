@@ -84,12 +84,48 @@ def cpu_baseline(X: np.ndarray, a: np.ndarray, budget_s: float = 12.0):
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    topo = cpu_topology()
     return {
         "value": pairs_per_s / (float(n) * n), "unit": "MVM/s", "cores": threads, "kind": "port",
+        "threads": threads, "physical_cores": topo["physical_cores"], "sockets": topo["sockets"], "logical_cpus": topo["logical_cpus"],
+        "cores_note": "`cores` = OpenMP threads the run used (the contract's field); physical_cores / sockets / logical_cpus from /proc/cpuinfo: "
+                      "with SMT on, threads = 2 x physical_cores",
         "sample": f"{rows} of {n} rows x all {n} columns, {best:.2f} s, scaled by n/rows (rows are independent); "
                   f"C restatement of src/gramian.jl:78-87 (oracle/covgram_oracle.c, {flags}); CPU: {model}",
         "pairs_per_s": pairs_per_s,
     }
+
+
+def cpu_topology():
+    """Sockets, physical cores and logical CPUs of this host from /proc/cpuinfo (unique (physical id, core id) pairs)."""
+    cores, socks, logical = set(), set(), 0
+    try:
+        phys = core = None
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("processor"):
+                logical += 1
+            elif l.startswith("physical id"):
+                phys = l.split(":")[1].strip(); socks.add(phys)
+            elif l.startswith("core id"):
+                core = l.split(":")[1].strip(); cores.add((phys, core))
+    except Exception:
+        pass
+    return {"physical_cores": len(cores) or None, "sockets": len(socks) or None, "logical_cpus": logical or (os.cpu_count() or None)}
+
+
+def _event_loop(fn, steps):
+    """K steps with one event pair per step on the current stream (the library launches on it); returns the per-step ms list
+    after a synchronise.  The events sit between the steps, so the wall-clock mean of the same loop is unchanged by them."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in ev:
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    return [e0.elapsed_time(e1) for e0, e1 in ev]
+
+
+def _stats(ms):
+    v = sorted(ms)
+    return {"ms_median": v[len(v) // 2], "ms_min": v[0], "ms_max": v[-1], "steps": len(v)}
 
 
 def _timed(fn, warm=5, reps=20, after_warm=None, warm_s=0.25):
@@ -176,12 +212,12 @@ def other_configs(cg, dev):
     out["C3_shard"] = {"what": "EQ dense Gramian mul!, d=8 n=524288 fp32: one rank's row shard of the 8-GPU config (65536 rows x 524288 columns, all entries)",
                        "ms": ms, "kernel_avg_ms": kavg, "pairs_per_s": float(per) * n / (ms * 1e-3), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
                        "checked_rows": len(rows),
-                       "roofline": {"bound": "valu", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": fl / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
-                                    "note": "frac = the reference's 3d+3 = 27 flops per pair against the FP32 VECTOR peak (SURVEY.md \u00a78d(i)); 24 of them run on the "
-                                            "matrix pipe here, so it can exceed 1 — the utilisation figure is issue_roofline_frac (v_exp_f32 8 + v_fma_f32 4 + MFMA hold 2 "
-                                            "cycles per 64 pairs per SIMD at 2.4 GHz)",
-                                    "issue_roofline_frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0))}}
+                       "roofline": {"bound": "valu_issue", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0) * (3 * d + 3) * 1e-12,
+                                    "unit": "TFLOP/s", "frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0)),
+                                    "reference_flops_frac": fl / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
+                                    "note": "peak = the VALU issue ceiling of this kernel's instruction stream (v_exp_f32 8 + v_fma_f32 4 + MFMA hold 2 cycles per 64 pairs per SIMD at 2.4 GHz, "
+                                            "MI355X_MICROARCH.md) in the reference's 3d+3 flops per pair, so frac = achieved / peak = evaluated pairs per second over that ceiling; reference_flops_frac = the reference's 3d+3 = 27 flops per pair against the FP32 "
+                                            "VECTOR peak (SURVEY.md \u00a78d(i)) — 24 of them run on the matrix pipe here, so that ratio can exceed 1 and is no utilisation"}}
     Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n, dtype=torch.float32, device=dev)
     if Gf.sym_partial_supported():
         cg.set_option("time_kernels", 1)
@@ -191,9 +227,9 @@ def other_configs(cg, dev):
         ev = float(n) * (n + 32) / 2 / world
         out["C3_sym_partial"] = {"what": "the same config in the symmetric form: rank 3 of 8's cyclic panels of the upper triangle (covgram_mvm_sym_partial); "
                                          "an all-reduce of the 8 partials completes b", "ms": ms, "kernel_avg_ms": kavg, "evaluated_pairs_per_s": ev / (ms * 1e-3),
-                                 "roofline": {"bound": "valu", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                              "frac": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
-                                              "issue_roofline_frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0))}}
+                                 "roofline": {"bound": "valu_issue", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0) * (3 * d + 5) * 1e-12, "unit": "TFLOP/s",
+                                              "frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0)),
+                                              "reference_flops_frac": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS}}
     del G, Gf, X, a, y, part
     # C4: GradientKernel(EQ), d=32, n=16384, fp64
     n, d = 16384, 32
@@ -292,28 +328,45 @@ def main():
         step()
     torch.cuda.synchronize()
     cg.set_option("time_kernels", 1)
+    collective = world > 1 or G.force_collective
+    G.timing = collective                                    # events around the local kernel and around the one collective
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for e0, e1 in step_ev:                                    # EXACTLY K steps; one event pair per step on the launch stream
+        e0.record(); step(); e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in step_ev]
     kernel_ms, launches = cg.kernel_time()
+    loc_ms, col_ms, nsplit = G.timing_ms() if collective else (0.0, 0.0, 0)
+    G.timing = False
     cg.set_option("time_kernels", 0)
     dense_path = cg.get_info("last_dense_path")
     sym_path = cg.get_info("last_mfma_sym") == 1
 
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
+        # every rank's own split of a step, gathered to rank 0: where the time of an N-GPU step goes
+        mine = torch.tensor([kernel_ms / max(launches, 1), loc_ms / max(nsplit, 1), col_ms / max(nsplit, 1), float(G.hi - G.lo),
+                             float(np.median(step_ms)), float(min(step_ms))], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "kernel_ms": float(v[0]), "local_ms": float(v[1]), "collective_ms": float(v[2]), "shard_rows": int(v[3]),
+                     "step_ms_median": float(v[4]), "step_ms_min": float(v[5])} for r, v in enumerate(allr)]
     else:
         kern_avg_ms = kernel_ms / max(launches, 1)
+        if collective:
+            per_rank = [{"rank": 0, "kernel_ms": kern_avg_ms, "local_ms": loc_ms / max(nsplit, 1), "collective_ms": col_ms / max(nsplit, 1),
+                         "shard_rows": int(G.hi - G.lo), "step_ms_median": float(np.median(step_ms)), "step_ms_min": float(min(step_ms))}]
 
     # sustained shader clock under THIS kernel: a few launches of its clock-stamping diagnostic build (same loop, s_memtime /
     # s_memrealtime around the column loop of every workgroup; MI355X_MICROARCH.md DVFS item 6), untimed, right after the run
@@ -353,14 +406,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    s_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        Gs.matmul(a, out=bs)
+    for e0, e1 in s_ev:
+        e0.record(); Gs.matmul(a, out=bs); e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     s_elapsed = time.perf_counter() - t0
+    s_step = _stats([e0.elapsed_time(e1) for e0, e1 in s_ev])
     s_kernel_ms, s_launches = cg.kernel_time()
     cg.set_option("time_kernels", 0)
     s_used = cg.get_info("last_mfma_sym") == 1
@@ -370,6 +425,79 @@ def main():
         s_elapsed, s_kern_avg_ms = float(t[0]), float(t[1])
     else:
         s_kern_avg_ms = s_kernel_ms / max(s_launches, 1)
+    # ---- the reference's own arithmetic: the lane-per-row direct-difference kernel (dense_variant = 1: r^2 from the d differences in
+    # fp32, src/util.jl:40-47, no matrix cores), all n*m entries, same protocol with fewer steps (it is ~1.7x slower)
+    dd = None
+    try:
+        cg.set_option("mfma_sym", 0); cg.set_option("dense_variant", 1)
+        Gd = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+        bd = torch.empty_like(b)
+        d_steps = max(5, min(args.steps, 20))
+        for _ in range(5):
+            Gd.matmul(a, out=bd)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_ms = _event_loop(lambda: Gd.matmul(a, out=bd), d_steps)
+        if world > 1:
+            dist.barrier()
+        d_elapsed = time.perf_counter() - t0
+        d_path = cg.get_info("last_dense_path")
+        if world > 1:
+            t = torch.tensor([d_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d_elapsed = float(t[0])
+        dd = {"what": "the same contract workload on the reference's arithmetic: direct differences per pair in fp32 on the VALU (option dense_variant = 1, "
+                      "covgram::dense_mvm_kernel, one lane per output row), all n*m entries",
+              "used_direct_difference_kernel": d_path == 1, "value": d_steps / d_elapsed, "unit": "MVM/s", "ms_per_step": d_elapsed / d_steps * 1e3,
+              "steps": d_steps, **{k: v for k, v in _stats(d_ms).items() if k != "steps"}}
+        got_d = bd.cpu().numpy() if rank == 0 else None
+    except Exception as e:   # reporting only
+        dd = {"what": "failed", "error": str(e)[:200]}
+        got_d = None
+    finally:
+        cg.set_option("dense_variant", 0); cg.set_option("mfma_sym", -1)
+
+    # ---- the contract step including the transfers of a (host -> device) and b (device -> host), pinned host buffers (SURVEY.md \u00a78d:
+    # "a second number includes H2D/D2H of a, b"); never `value`
+    incl = None
+    if world == 1:
+        try:
+            cg.set_option("mfma_sym", 0)
+            a_h = torch.from_numpy(ah).pin_memory(); b_h = torch.empty(N_POINTS, dtype=torch.float32).pin_memory()
+            def step_io():
+                a.copy_(a_h, non_blocking=True); G.matmul(a, out=b); b_h.copy_(b, non_blocking=True)
+            for _ in range(5):
+                step_io()
+            torch.cuda.synchronize()
+            k_io = max(5, min(args.steps, 20))
+            t0 = time.perf_counter()
+            for _ in range(k_io):
+                step_io()
+            torch.cuda.synchronize()
+            io_ms = (time.perf_counter() - t0) / k_io * 1e3
+            incl = {"what": "one contract step with a copied host -> device before and b device -> host after it (pinned buffers, same stream)",
+                    "ms_per_step": io_ms, "value": 1e3 / io_ms, "unit": "MVM/s", "steps": k_io, "bytes_per_step": 2 * 4 * N_POINTS}
+        except Exception as e:
+            incl = {"what": "failed", "error": str(e)[:200]}
+        finally:
+            cg.set_option("mfma_sym", -1)
+
+    # ---- N > 1: what ONE GPU needs for the whole MVM (rank 0, after the timed regions): ideal_ms = t1 / N
+    t1_ms = None
+    if world > 1 and rank == 0:
+        cg.set_option("mfma_sym", 0)
+        G1 = cg.gramian(cg.EQ(), X); b1 = torch.empty_like(b)
+        for _ in range(3):
+            G1.mul_(b1, a)
+        torch.cuda.synchronize()
+        t1_ms = float(np.median(_event_loop(lambda: G1.mul_(b1, a), 10)))
+        cg.set_option("mfma_sym", -1)
+    if world > 1:
+        dist.barrier()
+
     symmetric_variant = None
     if rank == 0:
         # parity spot check outside the timed regions: 1024 random rows against the fp64 oracle (tests/ hold the full suite)
@@ -378,13 +506,15 @@ def main():
         ref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32)
         rel_err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
         gots = bs.cpu().numpy()[rows].astype(np.float64)
+        if dd is not None and got_d is not None:
+            dd["rel_err_vs_fp64_oracle"] = float(np.linalg.norm(got_d[rows].astype(np.float64) - ref) / np.linalg.norm(ref))
         symmetric_variant = {
             "what": "the same mul!(b, gramian(EQ, x), a) on the library's default path: the upper triangle of the symmetric Gramian is "
                     "evaluated once (row and column sums of the same tiles)" + ("" if world == 1 else f"; rank r of {world} takes the cyclic "
                     "256-row panels p % N == r and one RCCL all-reduce completes b") + " — NOT the contract workload, which evaluates all n*m entries",
             "used_symmetric_kernel": bool(s_used),
             "value": args.steps / s_elapsed, "unit": "MVM/s", "ms_per_step": s_elapsed / args.steps * 1e3,
-            "kernel_avg_ms": s_kern_avg_ms,
+            "kernel_avg_ms": s_kern_avg_ms, "ms_median": s_step["ms_median"], "ms_min": s_step["ms_min"],
             "rel_err_vs_fp64_oracle": float(np.linalg.norm(gots - ref) / np.linalg.norm(ref)),
             "evaluated_pairs_per_launch": float(N_POINTS) * (N_POINTS + 32) / 2 / world,
         }
@@ -438,12 +568,12 @@ def main():
                      "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)")
             cycles64 = 8.0 + 4.0 + mfma_hold
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
-                    "products), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' / 'frac' use the reference's algorithmic "
-                    "3d+3 flops per pair against the FP32 vector peak (SURVEY.md \u00a78d(i)) — most of those flops now run on the matrix "
-                    "pipe, so 'frac' is a throughput ratio, not a utilisation; the utilisation figures are 'issue_roofline_frac' "
-                    "(2.4 GHz peak clock) and 'issue_roofline_frac_at_sustained_clock' (the clock measured in this run with the "
-                    "kernel's stamping build): the VALU issue stream priced with the guide's costs (v_exp_f32 8 + v_fma_f32 4 + MFMA "
-                    "hold 1 cycle per 64 pairs per SIMD). 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
+                    "products), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' is the reference's algorithmic 3d+3 flops per "
+                    "pair over the measured kernel time; 'peak' is the kernel's VALU issue ceiling in the same flops (v_exp_f32 8 + v_fma_f32 4 + "
+                    "MFMA hold 1 cycle per 64 pairs per SIMD at the 2.4 GHz peak clock), so 'frac' is the utilisation of the binding pipe; "
+                    "'issue_roofline_frac_at_sustained_clock' prices the same ceiling at the clock measured in this run with the kernel's "
+                    "stamping build; 'reference_flops_frac' is the flop ratio against the FP32 vector peak of SURVEY.md \u00a78d(i) (most of those "
+                    "flops run on the matrix pipe: a throughput ratio, not a utilisation). 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
         else:
             kname = "covgram::dense_mvm_kernel<float, EQ, D=3, NRHS=1, R=1>"
             cycles64 = 23.2                                           # measured packed body, profiles/r01_microbench_valu_rates.txt
@@ -451,10 +581,20 @@ def main():
                     "'mfma'/'hbm' do not bound this kernel (SURVEY.md §8d, DESIGN.md §4).")
         ceiling = 1024 * 2.4e9 * 64 / cycles64                        # evaluated pairs/s at the 2.4 GHz peak clock
         ceiling_sustained = 1024 * clock_ghz * 1e9 * 64 / cycles64 if clock_ghz else None
+        flops_per_pair = flops_launch / evaluated_pairs
+        on_matrix_cores = dense_path == 2
+        # roofline: for the matrix-core kernels the bound is the VALU issue stream (exp + fma + MFMA hold), so `peak` is that issue
+        # ceiling expressed in the algorithm's flops per pair and frac = achieved / peak = evaluated pairs per second over the ceiling
+        # (never > 1); the reference's flop count against the FP32 vector peak (SURVEY.md \u00a78d(i)) is reference_flops_frac.
+        peak_tflops = ceiling * flops_per_pair * 1e-12 if on_matrix_cores else FP32_VECTOR_PEAK_TFLOPS
+        step_stats = _stats(step_ms)
         line = {
             "metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (+ achieved HBM GB/s in roofline.hbm_*)",
             "value": mvms, "unit": "MVM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_median": step_stats["ms_median"], "ms_min": step_stats["ms_min"], "ms_max": step_stats["ms_max"],
+            "timing_note": "value / ms_per_step: wall clock over the K steps between barrier + synchronize (the contract); ms_median / ms_min: one HIP event pair "
+                           "per step on the launch stream, same K steps",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "EQ dense Gramian mul!, d=3 n=131072 fp32 (BASELINE.json configs[1]); x ~ N(0, I_3), a ~ N(0,1), "
                                    "alpha=1, beta=0, y == x" + ("; the upper triangle is evaluated once" if sym_path else "; all n*m entries evaluated") + "; points/a/b resident in HBM",
@@ -465,10 +605,17 @@ def main():
             "pairs_per_s": mvms * float(n) * m,
             "rel_err_vs_fp64_oracle": rel_err,
             "symmetric_variant": symmetric_variant,
+            "direct_difference_variant": dd,
+            "incl_h2d_d2h": incl,
             "roofline": {
-                "bound": "valu", "kernel": kname,
-                "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "bound": "valu_issue" if on_matrix_cores else "valu", "kernel": kname,
+                "achieved": achieved_tflops, "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": achieved_tflops / peak_tflops,
+                "peak_note": ("the VALU issue ceiling of this kernel's stream — " + f"{cycles64:g}" + " issue cycles per 64 pairs per SIMD (v_exp_f32 8, v_fma_f32 4, MFMA hold; "
+                              "MI355X_MICROARCH.md) on 1024 SIMDs at 2.4 GHz — times the algorithm's flops per pair" if on_matrix_cores
+                              else "FP32 vector peak (MI355X_MICROARCH.md)"),
+                "reference_flops_frac": float(n_local) * m * (3 * d + 3) / kern_s * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
+                "vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": "recorded rocprofv3 --pmc pass of this kernel (profiles/, FETCH_SIZE doubled per the guide), not measured in this run",
                 "kernel_avg_ms": kern_avg_ms, "launches": int(launches),
@@ -485,6 +632,14 @@ def main():
                 "hbm_frac": bytes_launch / kern_s * 1e-9 / HBM_PEAK_GBPS,
             },
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["per_rank_note"] = ("kernel_ms: the rank's dominant kernel by HIP events on the launch stream; local_ms / collective_ms: events on the same stream "
+                                     "around the shard's MVM and around the ONE collective (RCCL runs it on its own stream between two event waits of this one)")
+        if t1_ms is not None:
+            line["single_gpu_ms"] = t1_ms
+            line["ideal_ms"] = t1_ms / world
+            line["ideal_note"] = "single_gpu_ms: the whole n x n MVM (same kernel, all entries) on rank 0's GPU alone, median of 10 event-timed steps after the run; ideal_ms = that / N"
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         if world == 1 and not args.no_configs:

@@ -101,6 +101,10 @@ class ShardedGramian:
         # symmetric form: `sym_partial(out, a, rank, world)` fills out with this rank's partial product.  By default the
         # device Gramian's own method when it says the symmetric kernel applies (the answer depends on k and x only, so all
         # ranks agree); the CPU multi-process tests inject a factory.  symmetric=False forces row shards.
+        # optional split of a step into its two parts (bench.py's per-rank report): when `timing` is set, events on the current
+        # stream bracket the local kernel(s) and the one collective; read with timing_ms()
+        self.timing = False
+        self._ev = []
         self.sym_partial = None
         if symmetric is not False and y is None and self.block == 1 and (self.world > 1 or self.force_collective):
             if sym_partial_factory is not None:
@@ -119,6 +123,26 @@ class ShardedGramian:
             self._full = torch.empty((self.per * self.world * self.block,) + tail, dtype=a.dtype, device=a.device)
             self._buf_key = key
         return self._shard, self._full
+
+    def _mark(self, dev):
+        """An event on the current stream (timing only).  The collective runs on the backend's own stream between two event
+        waits of the current stream, so the interval between the marks around it is its full cost to this stream."""
+        if not (self.timing and dev.type == "cuda"):
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def timing_ms(self, reset: bool = True):
+        """(local_ms, collective_ms, steps) summed over the steps recorded since the last reset; synchronises."""
+        if self._ev:
+            torch.cuda.synchronize()
+        loc = sum(a.elapsed_time(b) for a, b, _ in self._ev)
+        col = sum(b.elapsed_time(c) for _, b, c in self._ev)
+        n = len(self._ev)
+        if reset:
+            self._ev = []
+        return loc, col, n
 
     def _local_into(self, view: torch.Tensor, a: torch.Tensor):
         from .gramian import LazyOperator
@@ -143,18 +167,28 @@ class ShardedGramian:
                 res = torch.empty(self.n, dtype=a.dtype, device=a.device)
             else:
                 res = out
+            e0 = self._mark(a.device)
             self.sym_partial(res, a, self.rank, self.world)
+            e1 = self._mark(a.device)
             _all_reduce_sum(res, self.group)
+            e2 = self._mark(a.device)
+            if e0 is not None:
+                self._ev.append((e0, e1, e2))
             if out is not None and res is not out:
                 out.copy_(res)
                 return out
             return res
         shard, full = self._buffers(a)
+        e0 = self._mark(a.device)
         if self.local is not None:
             self._local_into(shard[:rows], a)
+        e1 = self._mark(a.device)
         exact = (self.per * self.world == self.n)
         target = out if (exact and out is not None and out.is_contiguous()) else full
         _all_gather_into(target, shard, self.group)                        # the ONLY collective of the MVM
+        e2 = self._mark(a.device)
+        if e0 is not None:
+            self._ev.append((e0, e1, e2))
         if target is out:
             return out
         b = full[: self.n * self.block]
