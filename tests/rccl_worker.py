@@ -1,0 +1,59 @@
+"""One rank of the RCCL check (tests/test_gpu_dist.py): launched by `python -m torch.distributed.run`, one process per GPU, backend "nccl"
+(= RCCL on ROCm).  Row shards + ONE all-gather, symmetric partials + ONE all-reduce, an fp64 matrix right-hand side and the gradient
+blocks, each against rows of the fp64 oracle; rank 0 prints one JSON line.  Not collected by pytest (no test_ prefix)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    world = int(os.environ["WORLD_SIZE"]); rank = int(os.environ["RANK"]); local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("COVGRAM_FORCE_COLLECTIVE", "1")       # world = 1 still issues the collectives
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import covgram as cg
+    import covgram_oracle as o
+    res = {"world": world, "backend": dist.get_backend()}
+    rng = np.random.default_rng(77)                          # same seed on every rank: replicated inputs
+    n, d = 40001, 3
+    Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+    X = torch.from_numpy(Xh).to(dev); a = torch.from_numpy(ah).to(dev)
+    rows = np.random.default_rng(1).choice(n, 256, replace=False)
+    ref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32)
+    rel = lambda b, r: float(np.linalg.norm(np.asarray(b, dtype=np.float64) - r) / np.linalg.norm(r))
+    G = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+    G.timing = True
+    b = G @ a
+    loc, col, steps = G.timing_ms()
+    res["gather"] = {"rel": rel(b.cpu().numpy()[rows], ref), "shard": [G.lo, G.hi], "local_ms": loc, "collective_ms": col, "steps": steps}
+    Gs = cg.ShardedGramian(cg.EQ(), X, symmetric=True)
+    res["reduce"] = {"rel": rel((Gs @ a).cpu().numpy()[rows], ref), "used_partials": Gs.sym_partial is not None}
+    m, p = 2111, 3
+    Yh = rng.standard_normal((m, d)); Ah = rng.standard_normal((m, p)); X64 = rng.standard_normal((3001, d))
+    Gm = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X64).to(dev), torch.from_numpy(Yh).to(dev))
+    res["matrix"] = rel((Gm @ torch.from_numpy(Ah).to(dev)).cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), X64, Yh, Ah))
+    Xg = rng.standard_normal((333, 5)); ag = rng.standard_normal(333 * 5)
+    Gg = cg.ShardedGramian(cg.GradientKernel(cg.EQ()), torch.from_numpy(Xg).to(dev))
+    res["grad"] = rel((Gg @ torch.from_numpy(ag).to(dev)).cpu().numpy(), o.grad_mul(None, o.Kernel(o.EQ), Xg, Xg, ag))
+    # every rank holds the same complete b: compare a checksum across ranks
+    chk = torch.tensor([float(b.double().sum())], dtype=torch.float64, device=dev)
+    lo = chk.clone(); hi = chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    res["replicated"] = bool(lo.item() == hi.item())
+    dist.barrier()
+    if rank == 0:
+        print("RCCL_WORKER " + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,37 @@ def test_bench_runs_its_rccl_collectives_at_world_one():
     assert line["rel_err_vs_fp64_oracle"] <= 1e-5
     assert line["symmetric_variant"]["rel_err_vs_fp64_oracle"] <= 1e-5
     assert "row-shard" in line["config"]["parallelism"] or "1 GPU" in line["config"]["parallelism"]
+
+
+def _run_rccl_worker(nproc):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)       # fresh children of this process, nothing re-exec'ed
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_WORKER ")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0][len("RCCL_WORKER "):])
+
+
+def _check_rccl(res, world):
+    assert res["world"] == world and res["backend"] == "nccl"
+    assert res["gather"]["rel"] <= 1e-5 and res["gather"]["steps"] == 1 and res["gather"]["collective_ms"] > 0, res["gather"]
+    assert res["reduce"]["rel"] <= 1e-5 and res["reduce"]["used_partials"], res["reduce"]
+    assert res["matrix"] <= 1e-12 and res["grad"] <= 1e-12, (res["matrix"], res["grad"])
+    assert res["replicated"]
+
+
+def test_rccl_worker_at_world_one():
+    """The worker script of the two-rank RCCL test below, on the one GPU every box has: backend "nccl", the all-gather and the all-reduce
+    issued for real (world = 1), every result against the oracle — so the script itself is known good where two GPUs are missing."""
+    _check_rccl(_run_rccl_worker(1), 1)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: two ranks over RCCL / xGMI")
+def test_rccl_two_ranks_row_shards_and_symmetric_partials():
+    """Two ranks, one per GPU, backend "nccl" (= RCCL): row shards + ONE all-gather, cyclic-panel partials + ONE all-reduce, fp64 matrix
+    right-hand sides and gradient blocks against the oracle; b identical on both ranks."""
+    res = _run_rccl_worker(2)
+    _check_rccl(res, 2)
+    assert res["gather"]["shard"] == [0, 20001]
