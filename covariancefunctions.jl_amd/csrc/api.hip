@@ -600,7 +600,8 @@ int covgram_points_slice(const covgram_points* parent, int64_t first, int64_t co
     covgram_points* p = new covgram_points(*parent);
     p->owns = false;
     p->owns_center = false;            // the centre buffer stays the parent's
-    p->frag_cache = nullptr; p->frag_bytes = 0; p->frag_g = 0; p->frag_k2 = 0;   // a slice packs its own fragments
+    for (auto& f : p->frag) f = covgram_points::FragSlot{};   // a slice packs its own fragments
+    p->frag_clock = 0;
     p->n = count;
     p->dptr = (char*)parent->dptr + (size_t)first * parent->d * dtype_size(parent->dtype);
     parent->ctx->live_handles++;
@@ -612,8 +613,10 @@ int covgram_points_destroy(covgram_points* p) {
     if (!p) return COVGRAM_OK;
     {
         ::covgram::DeviceGuard _cg_dev(p->ctx->device);            // (a finalizer may call this from any thread state)
-        if (p->frag_cache || (p->owns && p->dptr) || (p->owns_center && p->center_buf)) (void)hipStreamSynchronize(p->ctx->stream);
-        if (p->frag_cache) (void)hipFree(p->frag_cache);
+        bool frags = false;
+        for (const auto& f : p->frag) frags = frags || f.ptr;
+        if (frags || (p->owns && p->dptr) || (p->owns_center && p->center_buf)) (void)hipStreamSynchronize(p->ctx->stream);
+        for (auto& f : p->frag) if (f.ptr) (void)hipFree(f.ptr);
         if (p->owns && p->dptr) (void)hipFree(p->dptr);
         if (p->owns_center && p->center_buf) (void)hipFree(p->center_buf);
     }

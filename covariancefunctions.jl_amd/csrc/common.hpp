@@ -216,11 +216,14 @@ struct covgram_points {
     double max_cnorm2 = 0; // max_i |x_i - c|^2 (upper bound), same reduction as max_norm2
     // matrix-core EQ path: the B fragments of this point set as the COLUMN side depend only on (points, gamma), not on the
     // weights, so they are packed once and reused by every later MVM (the points are resident and immutable while the handle
-    // lives); only the 4-byte-per-column weights are rebuilt per MVM
-    mutable void* frag_cache = nullptr;
-    mutable size_t frag_bytes = 0;
-    mutable float frag_g = 0;
-    mutable int frag_k2 = 0;
+    // lives); only the 4-byte-per-column weights are rebuilt per MVM.  FRAG_SLOTS slots keyed on (gamma, K2): a hyper-parameter
+    // loop or the terms of EQ(l1) + EQ(l2) alternate lengthscales on one handle, and a changed gamma re-packs the least recently
+    // used slot IN PLACE, ordered on the ctx stream behind the MVMs that read it — no hipFree, no stream synchronisation and no
+    // allocation on the MVM path once the slots exist (a slot is allocated the first time it is needed and lives as long as the handle)
+    static constexpr int FRAG_SLOTS = 4;
+    struct FragSlot { void* ptr = nullptr; size_t bytes = 0; float g = 0; int k2 = 0; uint64_t used = 0; };
+    mutable FragSlot frag[FRAG_SLOTS];
+    mutable uint64_t frag_clock = 0;
 };
 
 namespace covgram {

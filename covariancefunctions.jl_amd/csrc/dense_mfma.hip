@@ -515,17 +515,34 @@ static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const floa
 static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float g, const float* Cn, const uint4** PB, const float** EF) {
     const int64_t m = Y->n, ntile = (m + 31) / 32;
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
-    if (Y->frag_cache == nullptr || Y->frag_bytes != fbytes || Y->frag_g != g || Y->frag_k2 != K2) {
-        if (Y->frag_cache) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(Y->frag_cache); Y->frag_cache = nullptr; }
-        hipError_t me = hipMalloc(&Y->frag_cache, fbytes + (size_t)ntile * 32 * sizeof(float));   // fragments + EF
-        if (me != hipSuccess) { Y->frag_cache = nullptr; set_error("hipMalloc(%zu) failed: %s", fbytes, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
-        Y->frag_bytes = fbytes; Y->frag_g = g; Y->frag_k2 = K2;
+    const size_t total = fbytes + (size_t)ntile * 32 * sizeof(float);   // fragments + EF
+    covgram_points::FragSlot* hit = nullptr;
+    covgram_points::FragSlot* victim = &Y->frag[0];
+    for (auto& f : Y->frag) {
+        if (f.ptr && f.bytes == total && f.g == g && f.k2 == K2) { hit = &f; break; }
+        // reuse order: an empty slot first, then a slot of another size (its buffer is replaced), then the least recently used
+        const auto rank = [&](const covgram_points::FragSlot& s) { return !s.ptr ? 0 : (s.bytes != total ? 1 : 2); };
+        if (rank(f) < rank(*victim) || (rank(f) == rank(*victim) && f.used < victim->used)) victim = &f;
+    }
+    if (!hit) {
+        if (victim->ptr && victim->bytes != total) {   // only when the handle is re-used at another K2: off the steady-state path
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(victim->ptr); victim->ptr = nullptr;
+        }
+        if (!victim->ptr) {
+            hipError_t me = hipMalloc(&victim->ptr, total);
+            if (me != hipSuccess) { victim->ptr = nullptr; set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(me)); return COVGRAM_ENOMEM; }
+            victim->bytes = total;
+        }
+        // in place, stream-ordered behind every MVM that still reads this slot
+        victim->g = g; victim->k2 = K2;
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, Y->d,
-                           (uint4*)Y->frag_cache, (float*)((char*)Y->frag_cache + fbytes), K2, g, Cn);
+                           (uint4*)victim->ptr, (float*)((char*)victim->ptr + fbytes), K2, g, Cn);
+        hit = victim;
     }
-    *PB = (const uint4*)Y->frag_cache;
-    *EF = (const float*)((const char*)Y->frag_cache + fbytes);
+    hit->used = ++Y->frag_clock;
+    *PB = (const uint4*)hit->ptr;
+    *EF = (const float*)((const char*)hit->ptr + fbytes);
     return COVGRAM_OK;
 }
 

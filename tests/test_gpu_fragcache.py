@@ -1,0 +1,80 @@
+"""The matrix-core EQ path keeps the packed column fragments of a point handle in slots keyed on the lengthscale (csrc/dense_mfma.hip
+eq_fragments): a hyper-parameter loop or the terms of EQ(l1) + EQ(l2) alternate lengthscales on ONE handle.  The
+re-pack is in place and stream-ordered — no hipFree / hipStreamSynchronize on the MVM path — so such loops run at the single-lengthscale
+rate and can be captured into a HIP graph (the reference's callers: cg! on G + sigma^2 I, src/gramian.jl:229-238, src/lazy_linear_algebra.jl:126-144)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(b, ref):
+    b = np.asarray(b, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return np.linalg.norm(b - ref) / np.linalg.norm(ref)
+
+
+def _loop_ms(fn, reps):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def test_alternating_lengthscales_on_one_handle(cg, oracle):
+    rng = np.random.default_rng(31)
+    n, d = 16384, 3
+    Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda()
+    ls = (0.8, 1.3, 2.1, 0.7, 3.0, 1.05)                        # six lengthscales through four slots: hits, in-place re-packs and LRU turnover
+    cg.set_option("mfma_sym", 0)                                # the general matrix-core kernel (the symmetric one shares the same cache)
+    try:
+        Gs = [cg.gramian(cg.Lengthscale(cg.EQ(), l), X) for l in ls]   # gramian() of the same tensor: one point handle
+        rows = rng.choice(n, 128, replace=False)
+        refs = [oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=l), Xh[rows], Xh, ah, dtype=np.float32) for l in ls]
+        y = torch.empty(n, dtype=torch.float32, device="cuda")
+        for it in range(100):                                   # 100 alternations, every result against the oracle rows
+            j = it % len(ls) if it % 7 else (it // 7) % 2       # mostly round-robin, sometimes straight back to the first two
+            Gs[j].mul_(y, a)
+            assert cg.get_info("last_dense_path") == 2
+            assert relerr(y.cpu().numpy()[rows], refs[j]) <= 1e-5, (it, j)
+        # steady state: two lengthscales alternating cost what one lengthscale costs (both resident: no re-pack, no synchronisation)
+        one = min(_loop_ms(lambda: Gs[0].mul_(y, a), 200) for _ in range(3))
+        flip = [0]
+        def two():
+            flip[0] ^= 1
+            Gs[flip[0]].mul_(y, a)
+        alt = min(_loop_ms(two, 200) for _ in range(3))
+        assert alt <= 1.05 * one, (one, alt)
+        # five lengthscales round-robin through four slots: every MVM re-packs in place (one extra small kernel), still no stall
+        idx = [0]
+        def five():
+            idx[0] = (idx[0] + 1) % 5
+            Gs[idx[0]].mul_(y, a)
+        rr = min(_loop_ms(five, 200) for _ in range(3))
+        assert rr <= 1.5 * one, (one, rr)
+    finally:
+        cg.set_option("mfma_sym", -1)
+
+
+def test_sum_of_two_lengthscales_solves_under_a_captured_graph(cg, oracle):
+    """(EQ(l1) + EQ(l2) + sigma^2 I) x = b by CG with the iteration replayed as a HIP graph: the two terms run one after the other on the
+    same point handle (composite_termwise), which needs both fragment sets resident and nothing synchronous on the MVM path."""
+    rng = np.random.default_rng(32)
+    n, d = 4096, 3
+    Xh = rng.standard_normal((n, d)).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda()
+    k = cg.Lengthscale(cg.EQ(), 0.7) + cg.Lengthscale(cg.EQ(), 1.9)
+    A = cg.gramian(k, X) + 0.5 * torch.ones(n, dtype=torch.float32, device="cuda")
+    bh = rng.standard_normal(n).astype(np.float32)
+    x, info = cg.cg(A, torch.from_numpy(bh).cuda(), reltol=1e-5, maxiter=400, graph=True)
+    assert info["graph"] and info["converged"], info
+    ko = oracle.Composite(((oracle.Kernel(oracle.EQ, lengthscale=0.7),), (oracle.Kernel(oracle.EQ, lengthscale=1.9),)), oracle.ISOTROPIC, 1.0)
+    M = oracle.matrix(ko, Xh.astype(np.float64), Xh.astype(np.float64)) + 0.5 * np.eye(n)
+    assert relerr(M @ x.cpu().numpy().astype(np.float64), bh) <= 1e-4
