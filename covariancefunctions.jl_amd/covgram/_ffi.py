@@ -97,8 +97,8 @@ PROTOTYPES = {
     "covgram_points_info": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I32)]),
     "covgram_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_matrix": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _I32]),
-    "covgram_grad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
-    "covgram_valgrad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D, _I32]),
+    "covgram_grad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
+    "covgram_valgrad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_mvm_sym_supported": (C.c_int, [_P, _KP, _P, C.POINTER(C.c_int32)]),
     "covgram_mvm_sym_partial": (C.c_int, [_P, _KP, _P, _P, _P, _I32, _I32]),
     "covgram_toeplitz_create": (C.c_int, [_P, C.POINTER(_P), _P, _P, _I64, _I64, _I32, _I32, _I32]),

@@ -391,21 +391,25 @@ class BlockGramian(LazyOperator):
     def mul_(self, y, a, alpha=1.0, beta=0.0):
         spec = K.require_device_spec(self.g.k)   # GenericInput gradient kernels have no device path
         a = _vec_arg(a, self.shape[1], self.dtype, self.device, "a")
-        if a.dim() != 1:
-            for c in range(a.shape[1]):                        # block solvers feed columns one at a time
-                yc = y[:, c].contiguous()
-                self.mul_(yc, a[:, c].contiguous(), alpha, beta)
-                y[:, c] = yc
-            return y
-        if y.shape[0] != self.shape[0] or y.dtype != self.dtype:
+        if y.shape[0] != self.shape[0] or y.dtype != self.dtype or y.dim() != a.dim() or (a.dim() == 2 and y.shape[1] != a.shape[1]):
             raise _ffi.DimensionMismatch(_ffi.EINVAL, f"DimensionMismatch: y has shape {tuple(y.shape)}")
-        a_c = a.contiguous()
-        y_c = y if y.is_contiguous() else y.contiguous()
+        # matrix right-hand sides (block solvers; src/gramian.jl:241-257 takes vectors of matrices): ONE library call, the columns
+        # as column-major storage (a torch matrix is row-major: its transpose's storage); the library shares the pair evaluations
+        # between two columns at a time where its kernel holds two accumulators
+        nrhs = 1 if a.dim() == 1 else a.shape[1]
+        if a.dim() == 1:
+            a_c = a.contiguous()
+            y_c = y if y.is_contiguous() else y.contiguous()
+        else:
+            a_c = a.t().contiguous()
+            y_c = y.t().contiguous() if beta != 0.0 else torch.empty((nrhs, self.shape[0]), dtype=self.dtype, device=self.device)
         ctx = self.inner._px.ctx.bind_stream()
         fn = _ffi.lib().covgram_valgrad_mvm if self.value else _ffi.lib().covgram_grad_mvm
-        _ffi.check(fn(ctx, _ffi.kref(spec), self.inner._px.handle, self.inner._py.handle, _ffi._P(a_c.data_ptr()),
-                                               _ffi._P(y_c.data_ptr()), float(alpha), float(beta), _ffi.DEVICE))
-        if y_c is not y:
+        _ffi.check(fn(ctx, _ffi.kref(spec), self.inner._px.handle, self.inner._py.handle, _ffi._P(a_c.data_ptr()), self.shape[1],
+                      _ffi._P(y_c.data_ptr()), self.shape[0], nrhs, float(alpha), float(beta), _ffi.DEVICE))
+        if a.dim() == 2:
+            y.copy_(y_c.t())
+        elif y_c is not y:
             y.copy_(y_c)
         return y
 

@@ -990,10 +990,15 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
 }
 
 // vg = 0: GradientKernel blocks (d × d); vg = 1: ValueGradientKernel blocks ((d+1) × (d+1))
-static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
-                         void* y, double alpha, double beta, int32_t loc, int vg) {
+// a: (m bd) x nrhs, y: (n bd) x nrhs, column-major (lda, ldy), bd = d + vg entries per block (src/gramian.jl:241-257: blockmul! takes
+// vectors OF MATRICES too, and the block mul! of src/gradient.jl:86-92 broadcasts over their columns)
+static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a, int64_t lda,
+                         void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc, int vg) {
     int rc = check_pair(ctx, X, Y);
     if (rc) return rc;
+    CG_REQUIRE(nrhs >= 1, COVGRAM_EINVAL, "nrhs must be >= 1");
+    CG_REQUIRE(lda >= Y->n * (int64_t)(Y->d + vg) && ldy >= X->n * (int64_t)(X->d + vg), COVGRAM_EINVAL,
+               "lda / ldy smaller than the block vectors (%lld, %lld)", (long long)(Y->n * (int64_t)(Y->d + vg)), (long long)(X->n * (int64_t)(X->d + vg)));
     {
         SumTerm terms[COVGRAM_COMPOSITE_MAX_TERMS];
         int nt = 0;
@@ -1003,12 +1008,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
             rc = make_host_kernel(k, X->dtype, true, &chk);
             if (rc) return rc;
             for (int t = 0; t < nt; ++t) {
-                rc = grad_mvm_impl(ctx, terms[t].ptr(), X, Y, a, y, alpha, t == 0 ? beta : 1.0, loc, vg);
+                rc = grad_mvm_impl(ctx, terms[t].ptr(), X, Y, a, lda, y, ldy, nrhs, alpha, t == 0 ? beta : 1.0, loc, vg);
                 if (rc) return rc;
             }
             // a constant has zero derivatives: only the value-value entry of the value-gradient blocks sees it
             if (!vg) return COVGRAM_OK;
-            return constant_term_mvm(ctx, X->dtype, a, Y->n, 0, X->d + 1, y, X->n, 0, X->d + 1, 1, alpha * constant);
+            return constant_term_mvm(ctx, X->dtype, a, Y->n, lda, X->d + 1, y, X->n, ldy, X->d + 1, nrhs, alpha * constant);
         }
     }
     const int64_t n = X->n, m = Y->n;
@@ -1037,15 +1042,16 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     CG_DEVICE(ctx);
     if (n == 0) return COVGRAM_OK;
 
-    const void* a_dev = a;
-    void* y_dev = y;
+    const void* a_all = a;
+    void* y_all = y;
+    int64_t lda_d = lda, ldy_d = ldy;
     if (loc == COVGRAM_HOST) {
         void *sa, *sy;
-        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * bd * ts, &sa); if (rc) return rc;
-        rc = ws_reserve(ctx, 3, (size_t)n * bd * ts, &sy); if (rc) return rc;
-        if (m > 0) CG_CHECK_HIP(hipMemcpyAsync(sa, a, (size_t)m * bd * ts, hipMemcpyHostToDevice, ctx->stream));
-        if (beta != 0.0) CG_CHECK_HIP(hipMemcpyAsync(sy, y, (size_t)n * bd * ts, hipMemcpyHostToDevice, ctx->stream));
-        a_dev = sa; y_dev = sy;
+        rc = ws_reserve(ctx, 2, (size_t)std::max<int64_t>(m, 1) * bd * nrhs * ts, &sa); if (rc) return rc;
+        rc = ws_reserve(ctx, 3, (size_t)n * bd * nrhs * ts, &sy); if (rc) return rc;
+        if (m > 0) CG_CHECK_HIP(hipMemcpy2DAsync(sa, (size_t)m * bd * ts, a, (size_t)lda * ts, (size_t)m * bd * ts, nrhs, hipMemcpyHostToDevice, ctx->stream));
+        if (beta != 0.0) CG_CHECK_HIP(hipMemcpy2DAsync(sy, (size_t)n * bd * ts, y, (size_t)ldy * ts, (size_t)n * bd * ts, nrhs, hipMemcpyHostToDevice, ctx->stream));
+        a_all = sa; y_all = sy; lda_d = m * (int64_t)bd; ldy_d = n * (int64_t)bd;
     }
     const bool iso = (k->trait == COVGRAM_ISOTROPIC);
     const void* Cn = iso ? Y->center : nullptr;
@@ -1054,7 +1060,13 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     const double alpha_eff = alpha * hk.kp.scale * (iso ? -2.0 * hk.kp.gamma2 : 1.0);
     const int64_t rowblocks = (n + GRAD_THREADS - 1) / GRAD_THREADS;
     const int64_t npad = rowblocks * GRAD_THREADS;
-    const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)bd);
+    // two right-hand sides per pass where the lane-per-row kernel is compiled for it (grad_mvm.hpp: r, s, phi', phi'' once per pair)
+    const bool two_ok = !wide && m > 0 && hk.k.power == 1 && grad_two_rhs_ok(ts, D, hk.tu_family);
+    for (int c0 = 0; c0 < nrhs;) {
+    const int nr = (two_ok && c0 + 1 < nrhs) ? 2 : 1;
+    const void* a_dev = (const char*)a_all + (size_t)c0 * lda_d * ts;
+    void* y_dev = (char*)y_all + (size_t)c0 * ldy_d * ts;
+    const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)bd, (unsigned)nr);
 
     if (m == 0) {
         if (dtype == COVGRAM_F32)
@@ -1130,19 +1142,19 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
                            (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
                             hk.tu_family != COVGRAM_GAMMAEXP && !(hk.tu_family == COVGRAM_MATERNP && hk.k.p == 0) &&
                             hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
-        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * (2 * D + vg + (expd ? 2 : 0)) * ts, &P); if (rc) return rc;
-        void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * 2 * D * ts) : nullptr;
-        void* Ex = expd ? (void*)((char*)P + (size_t)(m + 1) * (2 * D + vg) * ts) : nullptr;
+        rc = ws_reserve(ctx, 0, (size_t)(m + 1) * ((1 + nr) * D + nr * vg + (expd ? 1 + nr : 0)) * ts, &P); if (rc) return rc;
+        void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * (1 + nr) * D * ts) : nullptr;
+        void* Ex = expd ? (void*)((char*)P + (size_t)(m + 1) * ((1 + nr) * D + nr * vg) * ts) : nullptr;
         const int64_t pe = (m + 1) * (int64_t)D;
         if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(grad_pack_kernel<float>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma, vg, (float*)A0, (const float*)Cn);
+                               (const float*)Y->dptr, m, d, (const float*)a_dev, (float*)P, D, (float)hk.kp.gamma, vg, (float*)A0, (const float*)Cn, nr, lda_d);
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn);
+                               (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn, nr, lda_d);
         if (expd)
             hipLaunchKernelGGL(grad_pack_extra_kernel<double>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, d,
-                               (const double*)a_dev, hk.kp.gamma, vg, (const double*)Cn, (double*)Ex);
+                               (const double*)a_dev, hk.kp.gamma, vg, (const double*)Cn, (double*)Ex, nr, lda_d);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
@@ -1161,7 +1173,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         int64_t gsplit = std::max<int64_t>(1, ((int64_t)ctx->num_cus * 64 * 64 / gthreads + growwgs - 1) / growwgs);
         gsplit = std::min(gsplit, std::max<int64_t>(1, m / 64));   // >= 64 columns per workgroup: below that its prologue and slab rows dominate
                                                                     // (tools/c4_jsplit_sweep.py small: n = 4096, d = 8: 16-column chunks 0.109 ms, 64-column 0.059)
-        const int64_t gcap = std::max<int64_t>(1, (int64_t)(256.0e6 / ((double)npad * (D + vg) * ts)));
+        const int64_t gcap = std::max<int64_t>(1, (int64_t)(256.0e6 / ((double)npad * (D + vg) * nr * ts)));
         if (ctx->jsplit <= 0 && ctx->target_wgs <= 0 && gsplit > gcap) {
             gsplit = gcap;
             for (int64_t js = gsplit; js >= std::max<int64_t>(1, gsplit / 2); --js) {
@@ -1177,11 +1189,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         ga.vg = vg; ga.A0 = A0; ga.alpha0 = alpha0;
         ga.expd = expd ? 1 : 0; ga.Ex = Ex;
+        ga.nr = nr; ga.ldy = ldy_d;
         ctx->last_grad_expand = ga.expd;
         ga.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma;
         ga.vg_b = iso ? -2.0 * hk.kp.gamma : hk.kp.gamma;
         if (jsplit == 1) ga.out = y_dev;
-        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * (D + vg) * npad * ts, &ga.out); if (rc) return rc; }
+        else { rc = ws_reserve(ctx, 1, (size_t)jsplit * nr * (D + vg) * npad * ts, &ga.out); if (rc) return rc; }
         auto* tm = timer_next(ctx);
         if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(ga, dtype); if (rc) return rc;
@@ -1189,15 +1202,17 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         if (jsplit > 1) {
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(grad_reduce_kernel<float>, rgrid, dim3(256), 0, ctx->stream, (const float*)ga.out,
-                                   npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta, vg, (float)alpha0);
+                                   npad, D, jsplit, (float*)y_dev, n, d, (float)alpha_eff, (float)beta, vg, (float)alpha0, ldy_d);
             else
                 hipLaunchKernelGGL(grad_reduce_kernel<double>, rgrid, dim3(256), 0, ctx->stream, (const double*)ga.out,
-                                   npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta, vg, alpha0);
+                                   npad, D, jsplit, (double*)y_dev, n, d, alpha_eff, beta, vg, alpha0, ldy_d);
         }
     }
+    c0 += nr;
+    }   // right-hand sides
     CG_CHECK_HIP(hipGetLastError());
     if (loc == COVGRAM_HOST) {
-        CG_CHECK_HIP(hipMemcpyAsync(y, y_dev, (size_t)n * bd * ts, hipMemcpyDeviceToHost, ctx->stream));
+        CG_CHECK_HIP(hipMemcpy2DAsync(y, (size_t)ldy * ts, y_all, (size_t)n * bd * ts, (size_t)n * bd * ts, nrhs, hipMemcpyDeviceToHost, ctx->stream));
         CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     }
     return COVGRAM_OK;
@@ -1233,14 +1248,14 @@ int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const cov
     return mvm_eq_mfma_sym(ctx, hk, X, (const float*)a, (float*)y, 1.0, 0.0, rank, world, fast ? nullptr : k);
 }
 
-int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
-                     void* y, double alpha, double beta, int32_t loc) {
-    return grad_mvm_impl(ctx, k, X, Y, a, y, alpha, beta, loc, 0);
+int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a, int64_t lda,
+                     void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc) {
+    return grad_mvm_impl(ctx, k, X, Y, a, lda, y, ldy, nrhs, alpha, beta, loc, 0);
 }
 
-int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
-                        void* y, double alpha, double beta, int32_t loc) {
-    return grad_mvm_impl(ctx, k, X, Y, a, y, alpha, beta, loc, 1);
+int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a, int64_t lda,
+                        void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc) {
+    return grad_mvm_impl(ctx, k, X, Y, a, lda, y, ldy, nrhs, alpha, beta, loc, 1);
 }
 
 // debugging / test hook: the double-precision parameter block the device kernels receive.

@@ -262,7 +262,9 @@ struct GradArgs {
     int32_t vg = 0;                        // 1: ValueGradientKernel blocks of d+1 (out slab rows D+1)
     const void* A0 = nullptr;              // vg: value weights of the columns, m+1 entries
     double alpha0 = 0, vg_c = 0, vg_b = 0; // vg: scale of the value row, c2 and b0 coupling coefficients
-    int32_t expd = 0;                      // 1: expanded form (fp64 isotropic): Ex holds (|y'_j|^2, y'_j . a_j) per column, m + 1 entries
+    int32_t nr = 1;                        // right-hand sides of this launch (1 or 2: grad_two_rhs_ok): records of (1 + nr) D scalars
+    int64_t ldy = 0;                       // elements between the outputs of two right-hand sides
+    int32_t expd = 0;                      // 1: expanded form (fp64 isotropic): Ex holds (|y'_j|^2, y'_j . a_j^(0..nr-1)) per column, m + 1 entries
     const void* Ex = nullptr;
     double alpha, beta;
     const HostKernel* hk;

@@ -54,10 +54,17 @@ inline int grad_block_threads(int elem_size, int D, int fam) {
     return (512 / (state + temps) >= 3) ? GRAD_THREADS : 64;
 }
 
-template <typename T, int DC>
+// Two right-hand sides per pass (grad_mvm_kernel<..., NR = 2>): x and two accumulators are 3 d-vectors of VGPRs — compiled while they leave
+// room for the temporaries at two waves per SIMD (fp64 d <= 32, fp32 d <= 64), for the single profiles (the composite interpreter keeps its
+// jets live and stays at one right-hand side).  Host and device agree through this one function.
+constexpr bool grad_two_rhs_ok(size_t elem_size, int D, int fam) {
+    return fam < COVGRAM_NFAMILY && 3 * D * (int)(elem_size / 4) + (elem_size == 8 && (fam == COVGRAM_RQ || fam == COVGRAM_GAMMAEXP) ? 110 : 40) <= 256;
+}
+
+template <typename T, int DC, int NR = 1>
 struct GradChunk {
     T y[DC];
-    T a[DC];
+    T a[NR][DC];
 };
 
 // Register budget: the state is 2 (or 3 with KEEP_R) d-vectors; ask the allocator for the occupancy that state allows
@@ -68,9 +75,9 @@ struct GradChunk {
 template <typename T, int FAM> constexpr int grad_temp_regs() {
     return (sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP || fam_is_expr<FAM>)) ? 110 : 40;
 }
-template <typename T, int D, bool KEEP_R, int FAM = COVGRAM_EQ>
+template <typename T, int D, bool KEEP_R, int FAM = COVGRAM_EQ, int NR = 1>
 constexpr int grad_min_waves() {
-    const int state = (KEEP_R ? 3 : 2) * D * (int)(sizeof(T) / 4);
+    const int state = ((KEEP_R ? 2 : 1) + NR) * D * (int)(sizeof(T) / 4);
     const int w = 512 / (state + grad_temp_regs<T, FAM>());
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
@@ -81,20 +88,27 @@ constexpr int grad_min_waves() {
 //   dot product:  bv =    gamma^2 (phi' av + (  phi'' t + phi' a0 / gamma) y'),   b0 = phi a0 +   gamma phi' t
 // i.e. one extra FMA on c2 and one scalar accumulator; a0 streams from A0 (one scalar load per column, prefetched with
 // the column's first chunk), vg_c = -+1/gamma, vg_b = -2 gamma | gamma, and b0 is scaled by alpha0 = alpha * scale.
-template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG, bool EXPD = false>
-__global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
+// NR right-hand sides at once (src/gramian.jl:241-257 takes vectors of matrices, the block mul! of src/gradient.jl:86-92 broadcasts over the
+// columns): r, s, phi', phi'' are evaluated ONCE per pair and feed NR accumulators b_i; the record of column j is (y_j, a_j^(0), ..., a_j^(NR-1)),
+// the value weights / expanded-form scalars are NR (1 + NR) per column, the outputs NR vectors ldy apart (partial slabs: [split][NR][D (+1)][npad]).
+template <typename T, int FAM, int D, bool KEEP_R, bool POW, bool VG, bool EXPD = false, int NR = 1>
+__global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM, NR>())) void grad_mvm_kernel(const T* __restrict__ X, int64_t n, int32_t d,
                                                                 const T* __restrict__ P, const T* __restrict__ P2,
                                                                 int64_t m, T* __restrict__ out, int64_t npad,
                                                                 int64_t jchunk, T alpha, T beta, int32_t final_store,
                                                                 const T* __restrict__ A0, T alpha0, T vg_c, T vg_b,
                                                                 const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp,
-                                                                const T* __restrict__ Ex) {
+                                                                const T* __restrict__ Ex, int64_t ldy) {
     constexpr bool ISO = fam_is_iso<FAM>;
+    constexpr int RS = (1 + NR) * D;                                             // scalars per column record
     static_assert(!EXPD || (ISO && !KEEP_R), "the expanded form is an isotropic variant that keeps no r");
-    constexpr int DC = (64 / (int)sizeof(T) < D) ? 64 / (int)sizeof(T) : D;   // dims per chunk (one 64-byte s_load per operand)
+    // dims per chunk: one 64-byte s_load per operand; 32-byte loads with two right-hand sides — a chunk is (1 + NR) operands and two chunks
+    // are live (current + prefetched): 2 x 3 x 16 dwords would not fit the 102 SGPRs
+    constexpr int DCB = (NR > 1 ? 32 : 64) / (int)sizeof(T);
+    constexpr int DC = (DCB < D) ? DCB : D;
     constexpr int NC = (D + DC - 1) / DC;
     constexpr bool NEED_Y2 = !ISO || !KEEP_R;                                    // sweep 2 needs y_j again (EXPD: -c2 y_j)
-    using Chunk = GradChunk<T, DC>;
+    using Chunk = GradChunk<T, DC, NR>;
 
     const int tid = threadIdx.x;
     int64_t row = (int64_t)blockIdx.x * blockDim.x + tid;
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
     const int64_t j0 = (int64_t)blockIdx.y * jchunk;
     const int64_t j1 = (j0 + jchunk < m) ? (j0 + jchunk) : m;
 
-    T x[D], b[D];
+    T x[D], b[NR][D];
     {
         const T* xr = X + row * (int64_t)d;
         if (d == D) {   // common case: no padding, straight vector loads
@@ -114,9 +128,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
             for (int l = 0; l < D; ++l) x[l] = (l < d) ? (ISO ? xr[l] - Cn[l] : xr[l]) * kp.gamma : (T)0;
         }
 #pragma unroll
-        for (int l = 0; l < D; ++l) b[l] = (T)0;
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int l = 0; l < D; ++l) b[rr][l] = (T)0;
     }
-    [[maybe_unused]] T nx = (T)0, csum = (T)0;                    // EXPD: |x'_i|^2 and sum_j c2_j (b_i += x'_i csum at the end)
+    [[maybe_unused]] T nx = (T)0, csum[NR] = {};                    // EXPD: |x'_i|^2 and sum_j c2_j (b_i += x'_i csum at the end)
     if constexpr (EXPD) {
 #pragma unroll
         for (int l = 0; l < D; ++l) nx = cg_fma(x[l], x[l], nx);
@@ -128,7 +144,11 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
         Chunk ch;
         const int base = (c * DC + DC <= D) ? c * DC : D - DC;
 #pragma unroll
-        for (int e = 0; e < DC; ++e) { ch.y[e] = rec[base + e]; ch.a[e] = rec[D + base + e]; }
+        for (int e = 0; e < DC; ++e) {
+            ch.y[e] = rec[base + e];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) ch.a[rr][e] = rec[(1 + rr) * D + base + e];
+        }
         return ch;
     };
     auto load_a = [&](const T* __restrict__ rec, int c) {
@@ -136,7 +156,8 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
         const int base = (c * DC + DC <= D) ? c * DC : D - DC;
 #pragma unroll
         for (int e = 0; e < DC; ++e) {
-            ch.a[e] = rec[D + base + e];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) ch.a[rr][e] = rec[(1 + rr) * D + base + e];
             if constexpr (NEED_Y2) ch.y[e] = rec[base + e];
             else ch.y[e] = (T)0;
         }
@@ -146,21 +167,28 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
     // Sweep 2 reads the stream through P2 — the SAME address passed as a second kernel argument — so the compiler cannot
     // merge its loads with sweep 1's (it would re-materialise them right before use instead of prefetching them).
     const int cnt = (int)(j1 - j0);
-    const T* __restrict__ p = P + j0 * (2 * D);
-    const T* __restrict__ q = P2 + j0 * (2 * D);
+    const T* __restrict__ p = P + j0 * RS;
+    const T* __restrict__ q = P2 + j0 * RS;
     Chunk cur = load_ya(p, 0);
-    const T* __restrict__ a0p = VG ? A0 + j0 : nullptr;
-    T a0 = (T)0, a0n = (T)0, b0 = (T)0;
-    if constexpr (VG) a0 = a0p[0];
+    const T* __restrict__ a0p = VG ? A0 + NR * j0 : nullptr;       // NR value weights per column
+    T a0[NR] = {}, a0n[NR] = {}, b0[NR] = {};
+    if constexpr (VG) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) a0[rr] = a0p[rr];
+    }
     // EXPD: the column scalars (|y'_j|^2, y'_j . a_j) stream beside the records, prefetched one column ahead like a0
-    const T* __restrict__ exq = EXPD ? Ex + 2 * j0 : nullptr;
-    [[maybe_unused]] T eny = (T)0, eya = (T)0, enyn = (T)0, eyan = (T)0;
-    if constexpr (EXPD) { eny = exq[0]; eya = exq[1]; }
+    const T* __restrict__ exq = EXPD ? Ex + (1 + NR) * j0 : nullptr;   // (|y'_j|^2, y'_j . a_j^(0), ...)
+    [[maybe_unused]] T eny = (T)0, enyn = (T)0, eya[NR] = {}, eyan[NR] = {};
+    if constexpr (EXPD) {
+        eny = exq[0];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) eya[rr] = exq[1 + rr];
+    }
     // the column loop as a generic lambda: MaternP kernels run it with the order fixed at compile time when it is 2 (nu = 5/2)
     auto columns = [&](auto pfix_) {
     constexpr int PFIX = decltype(pfix_)::value;
-    for (int jj = 0; jj < cnt; ++jj, p += 2 * D, q += 2 * D) {
-        T s = (T)0, t = (T)0;
+    for (int jj = 0; jj < cnt; ++jj, p += RS, q += RS) {
+        T s = (T)0, t[NR] = {};
         T r[(ISO && KEEP_R) ? D : 1];
         // ---- sweep 1: s = |r|^2 (or x.y), t = r.a (or x.a) ------------------------------------------------------
 #pragma unroll
@@ -174,15 +202,18 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
                 const int l = base + e;
                 if constexpr (EXPD) {
                     s = cg_fma(x[l], cur.y[e], s);
-                    t = cg_fma(x[l], cur.a[e], t);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) t[rr] = cg_fma(x[l], cur.a[rr][e], t[rr]);
                 } else if constexpr (ISO) {
                     const T rl = x[l] - cur.y[e];
                     if constexpr (KEEP_R) r[l] = rl;
                     s = cg_fma(rl, rl, s);
-                    t = cg_fma(rl, cur.a[e], t);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) t[rr] = cg_fma(rl, cur.a[rr][e], t[rr]);
                 } else {
                     s = cg_fma(x[l], cur.y[e], s);
-                    t = cg_fma(x[l], cur.a[e], t);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) t[rr] = cg_fma(x[l], cur.a[rr][e], t[rr]);
                 }
                 if (e == skip) {   // the first use above carried the wait; now put the next chunk in flight
                     __builtin_amdgcn_sched_barrier(0);
@@ -190,27 +221,39 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            asm("" : "+v"(s), "+v"(t));   // pin both reductions at the chunk boundary (bounds VGPR live ranges)
+            asm("" : "+v"(s));            // pin the reductions at the chunk boundary (bounds VGPR live ranges)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) asm("" : "+v"(t[rr]));
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
         if constexpr (EXPD) {                                     // x'.y' -> |x' - y'|^2 (never negative), x'.a -> r'.a
             s = cg_fma((T)-2, s, nx + eny);
             s = (s < (T)0) ? (T)0 : s;      // rounding may take s a few ulp below zero; a NaN coordinate stays a NaN (as on the direct-difference path)
-            t -= eya;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) t[rr] -= eya[rr];
         }
-        T k1, k2, c2;
+        T k1, k2, c2[NR];
         if constexpr (VG) {
             T v;
             phi_jet<FAM, T, POW, PFIX>(s, kp, v, k1, k2);
-            c2 = cg_fma(vg_c * k1, a0, ISO ? (T)2 * k2 * t : k2 * t);
-            b0 = cg_fma(v, a0, cg_fma(vg_b * k1, t, b0));
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                c2[rr] = cg_fma(vg_c * k1, a0[rr], ISO ? (T)2 * k2 * t[rr] : k2 * t[rr]);
+                b0[rr] = cg_fma(v, a0[rr], cg_fma(vg_b * k1, t[rr], b0[rr]));
+            }
         } else {
             phi_derivs<FAM, T, POW, PFIX>(s, kp, k1, k2);
-            if constexpr (FAM == COVGRAM_EQ && !POW) c2 = -k1 * t;       // EQ: 2 k2 = -k1 (both exact scalings of the same exponential)
-            else c2 = ISO ? (T)2 * k2 * t : k2 * t;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                if constexpr (FAM == COVGRAM_EQ && !POW) c2[rr] = -k1 * t[rr];       // EQ: 2 k2 = -k1 (both exact scalings of the same exponential)
+                else c2[rr] = ISO ? (T)2 * k2 * t[rr] : k2 * t[rr];
+            }
         }
-        if constexpr (EXPD) { csum += c2; c2 = -c2; }            // b += k1 a - c2 y' here, + c2 x' through csum
+        if constexpr (EXPD) {                                     // b += k1 a - c2 y' here, + c2 x' through csum
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) { csum[rr] += c2[rr]; c2[rr] = -c2[rr]; }
+        }
         // ---- sweep 2: b += k1 a + c2 r   (or k1 a + c2 y) --------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -230,20 +273,39 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
                 } else {
                     v = cur.y[e];
                 }
-                b[l] = cg_fma(c2, v, cg_fma(k1, cur.a[e], b[l]));
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) b[rr][l] = cg_fma(c2[rr], v, cg_fma(k1, cur.a[rr][e], b[rr][l]));
                 if (e == skip) {
                     __builtin_amdgcn_sched_barrier(0);
-                    nxt = (c + 1 < NC) ? load_a(q, c + 1) : load_ya(p + 2 * D, 0);   // last chunk: next column (stream is padded)
-                    if constexpr (VG) { if (c + 1 == NC) a0n = a0p[jj + 1]; }
-                    if constexpr (EXPD) { if (c + 1 == NC) { enyn = exq[2 * (jj + 1)]; eyan = exq[2 * (jj + 1) + 1]; } }
+                    nxt = (c + 1 < NC) ? load_a(q, c + 1) : load_ya(p + RS, 0);   // last chunk: next column (stream is padded)
+                    if constexpr (VG) {
+                        if (c + 1 == NC) {
+#pragma unroll
+                            for (int rr = 0; rr < NR; ++rr) a0n[rr] = a0p[NR * (jj + 1) + rr];
+                        }
+                    }
+                    if constexpr (EXPD) {
+                        if (c + 1 == NC) {
+                            enyn = exq[(1 + NR) * (jj + 1)];
+#pragma unroll
+                            for (int rr = 0; rr < NR; ++rr) eyan[rr] = exq[(1 + NR) * (jj + 1) + 1 + rr];
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
-        if constexpr (VG) a0 = a0n;
-        if constexpr (EXPD) { eny = enyn; eya = eyan; }
+        if constexpr (VG) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) a0[rr] = a0n[rr];
+        }
+        if constexpr (EXPD) {
+            eny = enyn;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) eya[rr] = eyan[rr];
+        }
     }
     };
     if constexpr (FAM == COVGRAM_MATERNP) {
@@ -254,49 +316,56 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM>())
     }
     if constexpr (EXPD) {
 #pragma unroll
-        for (int l = 0; l < D; ++l) b[l] = cg_fma(x[l], csum, b[l]);
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int l = 0; l < D; ++l) b[rr][l] = cg_fma(x[l], csum[rr], b[rr][l]);
     }
 
     if (!live) return;
     constexpr int VGI = VG ? 1 : 0;
-    if (final_store) {
-        T* yp = out + row * (int64_t)(d + VGI);
-        if constexpr (VG) {
-            T v = alpha0 * b0;
-            if (beta != (T)0) v = cg_fma(beta, yp[0], v);
-            yp[0] = v;
-        }
 #pragma unroll
-        for (int l = 0; l < D; ++l) {
-            if (l < d) {
-                T v = alpha * b[l];
-                if (beta != (T)0) v = cg_fma(beta, yp[VGI + l], v);
-                yp[VGI + l] = v;
+    for (int rr = 0; rr < NR; ++rr) {
+        if (final_store) {
+            T* yp = out + rr * ldy + row * (int64_t)(d + VGI);
+            if constexpr (VG) {
+                T v = alpha0 * b0[rr];
+                if (beta != (T)0) v = cg_fma(beta, yp[0], v);
+                yp[0] = v;
             }
-        }
-    } else {
-        // partial slab [jsplit][D (+1: the value row)][npad]: lane-contiguous rows -> coalesced stores
-        T* op = out + (int64_t)blockIdx.y * (D + VGI) * npad + row;
 #pragma unroll
-        for (int l = 0; l < D; ++l) op[(int64_t)l * npad] = b[l];
-        if constexpr (VG) op[(int64_t)D * npad] = b0;
+            for (int l = 0; l < D; ++l) {
+                if (l < d) {
+                    T v = alpha * b[rr][l];
+                    if (beta != (T)0) v = cg_fma(beta, yp[VGI + l], v);
+                    yp[VGI + l] = v;
+                }
+            }
+        } else {
+            // partial slab [jsplit][NR][D (+1: the value row)][npad]: lane-contiguous rows -> coalesced stores
+            T* op = out + ((int64_t)blockIdx.y * NR + rr) * (D + VGI) * npad + row;
+#pragma unroll
+            for (int l = 0; l < D; ++l) op[(int64_t)l * npad] = b[rr][l];
+            if constexpr (VG) op[(int64_t)D * npad] = b0[rr];
+        }
     }
 }
 
 // y[i*d + l] = alpha * sum_s partial[s][l][i] + beta * y ; one thread per (i, l) with i fastest: coalesced slab reads.
 // vg = 1: blocks of d+1 — output entry 0 is the value row (slab row D, scaled by alpha0), entry 1+l the gradient row l.
+// blockIdx.z = right-hand side (slabs [split][nr][D (+1)][npad], outputs ldy apart).
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partial, int64_t npad, int32_t D, int32_t jsplit,
                                                           T* __restrict__ y, int64_t n, int32_t d, T alpha, T beta, int32_t vg,
-                                                          T alpha0) {
+                                                          T alpha0, int64_t ldy = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;                                  // output entry within the block
+    const int rr = blockIdx.z, nr = gridDim.z;
     if (i >= n || e >= d + vg) return;
     const int l = vg ? (e == 0 ? D : e - 1) : e;               // slab row
     if (vg && e == 0) alpha = alpha0;
     T s = (T)0;
-    for (int sp = 0; sp < jsplit; ++sp) s += partial[((int64_t)sp * (D + vg) + l) * npad + i];
-    T* yp = y + i * (int64_t)(d + vg) + e;
+    for (int sp = 0; sp < jsplit; ++sp) s += partial[(((int64_t)sp * nr + rr) * (D + vg) + l) * npad + i];
+    T* yp = y + rr * ldy + i * (int64_t)(d + vg) + e;
     T v = alpha * s;
     if (beta != (T)0) v = cg_fma(beta, *yp, v);
     *yp = v;
@@ -305,35 +374,39 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
 // P[j][0..D) = gamma * Y[j][0..d), P[j][D..2D) = a[j*d + 0..d)   (zero padded); record m (one past the end) is zeroed:
 // the kernel's software pipeline prefetches it and never consumes it.
 // vg = 1: A holds blocks of d+1 (value weight first); the value weights go to A0[0..m] (A0[m] = 0, prefetch only).
+// nr right-hand sides lda apart: records of (1 + nr) D scalars, nr value weights per column.
 template <typename T>
 __global__ __launch_bounds__(256) void grad_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
                                                         T* __restrict__ P, int32_t D, T gamma, int32_t vg, T* __restrict__ A0,
-                                                        const T* __restrict__ Cn) {
+                                                        const T* __restrict__ Cn, int32_t nr = 1, int64_t lda = 0) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (m + 1) * (int64_t)D) return;
     const int64_t j = e / D;
     const int l = (int)(e - j * D);
-    T* p = P + j * (int64_t)(2 * D);
+    T* p = P + j * (int64_t)((1 + nr) * D);
     const bool real = (j < m) && (l < d);
     p[l] = real ? (Y[j * (int64_t)d + l] - (Cn ? Cn[l] : (T)0)) * gamma : (T)0;
-    p[D + l] = real ? A[j * (int64_t)(d + vg) + vg + l] : (T)0;
-    if (vg && l == 0) A0[j] = (j < m) ? A[j * (int64_t)(d + 1)] : (T)0;
+    for (int rr = 0; rr < nr; ++rr) {
+        p[(1 + rr) * D + l] = real ? A[rr * lda + j * (int64_t)(d + vg) + vg + l] : (T)0;
+        if (vg && l == 0) A0[nr * j + rr] = (j < m) ? A[rr * lda + j * (int64_t)(d + 1)] : (T)0;
+    }
 }
 
 // EXPD: Ex[2 j] = |gamma (y_j - c)|^2, Ex[2 j + 1] = gamma (y_j - c) . a_j for j < m; entry m (prefetch only) is zero
 template <typename T>
 __global__ __launch_bounds__(256) void grad_pack_extra_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A, T gamma, int32_t vg,
-                                                              const T* __restrict__ Cn, T* __restrict__ Ex) {
+                                                              const T* __restrict__ Cn, T* __restrict__ Ex, int32_t nr = 1, int64_t lda = 0) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > m) return;
-    T ny = (T)0, ya = (T)0;
+    T ny = (T)0, ya[2] = {(T)0, (T)0};
     if (j < m)
         for (int l = 0; l < d; ++l) {
             const T yl = (Y[j * (int64_t)d + l] - (Cn ? Cn[l] : (T)0)) * gamma;
             ny = cg_fma(yl, yl, ny);
-            ya = cg_fma(yl, A[j * (int64_t)(d + vg) + vg + l], ya);
+            for (int rr = 0; rr < nr; ++rr) ya[rr] = cg_fma(yl, A[rr * lda + j * (int64_t)(d + vg) + vg + l], ya[rr]);
         }
-    Ex[2 * j] = ny; Ex[2 * j + 1] = ya;
+    Ex[(1 + nr) * j] = ny;
+    for (int rr = 0; rr < nr; ++rr) Ex[(1 + nr) * j + 1 + rr] = ya[rr];
 }
 
 template <typename T, int FAM, int D>
@@ -356,20 +429,29 @@ static int launch_grad_one(const GradArgs& a) {
     if (a.keep_r == 1) keep = CAN_KEEP;
     const bool pow = !fam_is_expr<FAM> && a.hk->k.power != 1;
     constexpr bool POWT = !fam_is_expr<FAM>;   // composites apply Power per factor: no POW = true instantiation
-#define CG_GRAD_LAUNCH(KEEPV, POWV, VGV)                                                                                                \
-    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV>), grid, dim3(threads), 0, a.stream, (const T*)a.X, a.n, a.d,  \
+#define CG_GRAD_LAUNCH_N(KEEPV, POWV, VGV, EXPV, NRV)                                                                                   \
+    hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, KEEPV, POWV, VGV, EXPV, NRV>), grid, dim3(threads), 0, a.stream, (const T*)a.X, a.n, a.d, \
                        (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,             \
-                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)nullptr)
+                       (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)((EXPV) ? a.Ex : nullptr), a.ldy)
+#define CG_GRAD_LAUNCH(KEEPV, POWV, VGV) CG_GRAD_LAUNCH_N(KEEPV, POWV, VGV, false, 1)
     bool done = false;
+    // two right-hand sides per pass: r, s, phi', phi'' once per pair, two accumulators (the caller checked grad_two_rhs_ok: no Power
+    // wrapper, 3 d-vectors of state within the registers); r is recomputed in the second sweep
+    if constexpr (grad_two_rhs_ok(sizeof(T), D, FAM)) {
+        if (a.nr == 2) {
+            bool x2 = false;
+            if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
+                if (a.expd) { if (a.vg) CG_GRAD_LAUNCH_N(false, false, true, true, 2); else CG_GRAD_LAUNCH_N(false, false, false, true, 2); x2 = true; }
+            }
+            if (!x2) { if (a.vg) CG_GRAD_LAUNCH_N(false, false, true, false, 2); else CG_GRAD_LAUNCH_N(false, false, false, false, 2); }
+            done = true;
+        }
+    }
+    if (!done && a.nr != 1) { set_error("grad_mvm: %d right-hand sides per launch are not compiled for this shape", a.nr); return COVGRAM_EUNSUPPORTED; }
     if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
-        if (a.expd) {   // expanded form: 4 fma per dimension and pair (header)
-#define CG_GRAD_LAUNCH_X(POWV, VGV)                                                                                                     \
-            hipLaunchKernelGGL((grad_mvm_kernel<T, FAM, D, false, POWV, VGV, true>), grid, dim3(threads), 0, a.stream, (const T*)a.X, a.n, a.d, \
-                               (const T*)a.P, (const T*)a.P, a.m, (T*)a.out, a.npad, a.jchunk, (T)a.alpha, (T)a.beta, final_store,     \
-                               (const T*)a.A0, (T)a.alpha0, (T)a.vg_c, (T)a.vg_b, (const T*)a.C, kp, (const T*)a.Ex)
-            if (a.vg) { if (pow) CG_GRAD_LAUNCH_X(POWT, true); else CG_GRAD_LAUNCH_X(false, true); }
-            else { if (pow) CG_GRAD_LAUNCH_X(POWT, false); else CG_GRAD_LAUNCH_X(false, false); }
-#undef CG_GRAD_LAUNCH_X
+        if (!done && a.expd) {   // expanded form: 4 fma per dimension and pair (header)
+            if (a.vg) { if (pow) CG_GRAD_LAUNCH_N(false, POWT, true, true, 1); else CG_GRAD_LAUNCH_N(false, false, true, true, 1); }
+            else { if (pow) CG_GRAD_LAUNCH_N(false, POWT, false, true, 1); else CG_GRAD_LAUNCH_N(false, false, false, true, 1); }
             done = true;
         }
     }
@@ -385,6 +467,7 @@ static int launch_grad_one(const GradArgs& a) {
     }
     if (!done) { if (pow) CG_GRAD_LAUNCH(false, POWT, false); else CG_GRAD_LAUNCH(false, false, false); }
 #undef CG_GRAD_LAUNCH
+#undef CG_GRAD_LAUNCH_N
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("grad_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

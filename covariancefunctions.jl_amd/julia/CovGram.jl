@@ -221,16 +221,18 @@ function Base.Matrix(G::Gramian{T}) where {T <: DevFloat}
 end
 
 # --- src/gramian.jl:241-257 with src/gradient.jl:86-115: flat point-major block vectors ---------------------------
-function device_blockmul!(sym::Symbol, y::StridedVector{T}, G::Gramian, a::StridedVector{T}, α, β, spec) where {T}
+function device_blockmul!(sym::Symbol, y::StridedVecOrMat{T}, G::Gramian, a::StridedVecOrMat{T}, α, β, spec) where {T}
     X = points(G.x, T); Y = G.x === G.y ? X : points(G.y, T)
+    size(y, 2) == size(a, 2) || throw(DimensionMismatch("mul!: y has $(size(y, 2)) columns, a has $(size(a, 2))"))
+    lda = max(stride(a, 2), size(a, 1)); ldy = max(stride(y, 2), size(y, 1)); nrhs = Int32(size(a, 2))
     if sym === :grad
         check(ccall((:covgram_grad_mvm, libcovgram), Cint,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
-                    ctx(), kref(spec), X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
+                    ctx(), kref(spec), X.handle, Y.handle, a, lda, y, ldy, nrhs, Float64(α), Float64(β), HOST))
     else   # src/gradient.jl:400-474 (ValueGradientKernel), block mul! :319-351: blocks of d+1, value component first
         check(ccall((:covgram_valgrad_mvm, libcovgram), Cint,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32),
-                    ctx(), kref(spec), X.handle, Y.handle, a, y, Float64(α), Float64(β), HOST))
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Int32, Float64, Float64, Int32),
+                    ctx(), kref(spec), X.handle, Y.handle, a, lda, y, ldy, nrhs, Float64(α), Float64(β), HOST))
     end
     return y
 end
@@ -240,6 +242,14 @@ function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFac
     spec = device_kernel_for(G.k.k)
     spec === nothing ? invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β) :
                        device_blockmul!(:grad, y, G, a, α, β, spec)
+end
+# matrix right-hand sides (src/gramian.jl:241-257: AbstractVecOfVecOrMat): one library call for all columns
+function LinearAlgebra.mul!(Y::StridedMatrix{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:GradientKernel}},
+                            A::StridedMatrix{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    G = B.A
+    spec = device_kernel_for(G.k.k)
+    spec === nothing ? invoke(mul!, Tuple{AbstractMatrix, BlockFactorizations.BlockFactorization, AbstractMatrix, Real, Real}, Y, B, A, α, β) :
+                       device_blockmul!(:grad, Y, G, A, α, β, spec)
 end
 function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:ValueGradientKernel}},
                             a::StridedVector{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}

@@ -198,17 +198,21 @@ int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const c
 int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y,
                             int32_t rank, int32_t world);
 
-/* Gradient-kernel Gramian (nd × md): y <- alpha * G a + beta * y with flat point-major block vectors
- * a (length m*d) and y (length n*d). */
-int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,
-                     const covgram_points* Y, const void* a, void* y, double alpha, double beta, int32_t loc);
+/* Gradient-kernel Gramian (nd × md): Y <- alpha * G A + beta * Y with flat point-major block vectors as the columns of
+ * A (m*d × nrhs, lda >= m*d) and Y (n*d × nrhs, ldy >= n*d), column-major; a vector is nrhs = 1 (lda, ldy then unused beyond the check).
+ * blockmul! takes vectors of matrices and the block mul! broadcasts over their columns (src/gramian.jl:241-257, src/gradient.jl:86-92):
+ * two right-hand sides share one pass over the pairs (r, phi', phi'' evaluated once) where the lane-per-row kernel holds two
+ * accumulators (fp64 d <= 32, fp32 d <= 64, single profiles without a Power wrapper); otherwise one pass per column. */
+int covgram_grad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                     int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc);
 
 /* Value-and-gradient Gramian (n(d+1) × m(d+1)), src/gradient.jl:400-474 with the block mul! of :319-351: block (i,j) is
  *     [ k(x_i,y_j)        (d/dy k)^T      ]
  *     [ d/dx k            d/dx d/dy^T k   ]
- * flat point-major block vectors: entry i*(d+1) is the value component, i*(d+1)+1+l the l-th gradient component. */
-int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X,
-                        const covgram_points* Y, const void* a, void* y, double alpha, double beta, int32_t loc);
+ * flat point-major block vectors: entry i*(d+1) is the value component, i*(d+1)+1+l the l-th gradient component; right-hand sides
+ * as for covgram_grad_mvm (lda >= m*(d+1), ldy >= n*(d+1)). */
+int covgram_valgrad_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                        int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc);
 
 /* Toeplitz T[i,j] = vc[i-j] (i >= j), vr[j-i] (i < j); vr == NULL: symmetric (vr = vc, m = n).
  * circulant != 0: T[i,j] = vc[(i-j) mod n] (vr must be NULL).  The spectrum of the circulant embedding

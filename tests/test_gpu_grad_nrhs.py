@@ -1,0 +1,114 @@
+"""Matrix right-hand sides of the gradient / value-gradient Gramians: blockmul! takes vectors of matrices and the block mul! broadcasts
+over their columns (src/gramian.jl:241-257, src/gradient.jl:86-92, :319-351).  covgram_grad_mvm / covgram_valgrad_mvm take (lda, ldy, nrhs);
+two columns share one pass over the pairs where the lane-per-row kernel holds two accumulators (grad_mvm.hpp, NR = 2), every other case runs
+column by column inside the library.  Each result column against the oracle's single-vector product."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(b, ref):
+    b = np.asarray(b, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return np.linalg.norm(b - ref) / np.linalg.norm(ref)
+
+
+def _cases(cg, o):
+    return [("EQ", cg.EQ(), o.Kernel(o.EQ)), ("MaternP2_l", cg.Lengthscale(cg.MaternP(2), 0.8), o.Kernel(o.MATERNP, p=2, lengthscale=0.8)),
+            ("RQ", cg.RQ(1.5), o.Kernel(o.RQ, param=1.5)), ("Dot3", cg.Dot() ** 3, o.Kernel(o.DOT, power=3)),
+            ("ExpDot", cg.ExponentialDot(), o.Kernel(o.EXPDOT))]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("value", [False, True])
+def test_gradient_matrix_right_hand_sides(cg, oracle, dtype, value):
+    o = oracle
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    tol = 2e-5 if dtype == torch.float32 else 1e-12
+    rng = np.random.default_rng(71 + int(value))
+    ref_mul = o.valgrad_mul if value else o.grad_mul
+    for d in (3, 8, 32, 40, 70):                        # 40: fp64 keeps one column per pass (registers); 70: the wide-row path
+        n, m = 97, 61
+        bd = d + 1 if value else d
+        X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(npdt); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(npdt)
+        Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+        for name, k, ko in _cases(cg, o):
+            if d > 32 and name not in ("EQ", "Dot3"):
+                continue
+            G = cg.gramian((cg.ValueGradientKernel if value else cg.GradientKernel)(k), Xd, Yd)
+            for p in (1, 2, 3, 5):
+                A = rng.standard_normal((m * bd, p)).astype(npdt); Y0 = rng.standard_normal((n * bd, p)).astype(npdt)
+                for alpha, beta in ((1.0, 0.0), (-0.6, 1.4)):
+                    Yt = torch.from_numpy(Y0.copy()).cuda()
+                    if beta == 0.0:
+                        Yt.fill_(float("nan"))              # beta == 0: previous contents are not read (src/gramian.jl:245)
+                    cg.mul_(Yt, G, torch.from_numpy(A).cuda(), alpha, beta)
+                    got = Yt.cpu().numpy()
+                    for c in range(p):
+                        ref = ref_mul(Y0[:, c], ko, X, Y, A[:, c], alpha, beta, npdt)
+                        assert relerr(got[:, c], ref) <= tol, (name, d, p, c, alpha, beta, value, relerr(got[:, c], ref))
+
+
+def test_gradient_rhs_raw_abi_padded_and_both_forms(cg, oracle):
+    """Padded lda / ldy through the C ABI, host and device pointers, expanded and direct fp64 forms, a Power wrapper (column by column)."""
+    o = oracle
+    rng = np.random.default_rng(73)
+    f = cg._ffi; lib = f.lib()
+    n, m, d, p = 130, 75, 16, 3
+    X = rng.standard_normal((n, d)) / 4; Y = rng.standard_normal((m, d)) / 4
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lda, ldy = m * d + 7, n * d + 3
+    A = rng.standard_normal((p, lda)); Y0 = rng.standard_normal((p, ldy))
+    for k, ko in ((cg.EQ(), o.Kernel(o.EQ)), (cg.Cauchy() ** 2, o.Kernel(o.CAUCHY, power=2))):
+        G = cg.gramian(cg.GradientKernel(k), Xd, Yd)
+        spec = cg.kernels.require_device_spec(k)
+        ctx = G.inner._px.ctx.bind_stream()
+        ref = np.stack([o.grad_mul(Y0[c, :n * d], ko, X, Y, A[c, :m * d], 0.7, -1.1) for c in range(p)])
+        for expand in (1, 0):
+            cg.set_option("grad_expand", expand)
+            try:
+                Yh = Y0.copy()
+                f.check(lib.covgram_grad_mvm(ctx, f.kref(spec), G.inner._px.handle, G.inner._py.handle, A.ctypes.data_as(C.c_void_p), lda,
+                                             Yh.ctypes.data_as(C.c_void_p), ldy, p, 0.7, -1.1, f.HOST))
+                assert relerr(Yh[:, :n * d], ref) <= 1e-12 and np.array_equal(Yh[:, n * d:], Y0[:, n * d:]), (expand,)
+                Ad = torch.from_numpy(A).cuda(); Yd2 = torch.from_numpy(Y0.copy()).cuda()
+                f.check(lib.covgram_grad_mvm(ctx, f.kref(spec), G.inner._px.handle, G.inner._py.handle, f._P(Ad.data_ptr()), lda,
+                                             f._P(Yd2.data_ptr()), ldy, p, 0.7, -1.1, f.DEVICE))
+                Yg = Yd2.cpu().numpy()
+                assert relerr(Yg[:, :n * d], ref) <= 1e-12 and np.array_equal(Yg[:, n * d:], Y0[:, n * d:]), (expand,)
+            finally:
+                cg.set_option("grad_expand", -1)
+        assert lib.covgram_grad_mvm(ctx, f.kref(spec), G.inner._px.handle, G.inner._py.handle, A.ctypes.data_as(C.c_void_p), m * d - 1,
+                                    Y0.ctypes.data_as(C.c_void_p), ldy, p, 1.0, 0.0, f.HOST) == f.EINVAL
+
+
+def test_two_columns_share_the_pair_evaluations_at_the_c4_shape(cg):
+    """BASELINE config 4's shape (GradientKernel(EQ), d = 32, n = 16384, fp64) with two right-hand sides: one pass with two accumulators.
+    In the expanded form a pair costs 4 d fma for one column and 7 d for two (s once, t and the accumulator update per column): the
+    two-column pass must stay clearly under two single passes — measured 1.7-1.8x one pass, which is the arithmetic's 1.75."""
+    rng = np.random.default_rng(74)
+    n, d = 16384, 32
+    X = torch.from_numpy(rng.standard_normal((n, d))).cuda()
+    G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
+    a1 = torch.from_numpy(rng.standard_normal(n * d)).cuda(); A2 = torch.from_numpy(rng.standard_normal((n * d, 2))).cuda()
+    y1 = torch.empty_like(a1); Y2 = torch.empty_like(A2)
+
+    def ms(fn, reps=8):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    t1 = min(ms(lambda: G.mul_(y1, a1)) for _ in range(2))
+    t2 = min(ms(lambda: G.mul_(Y2, A2)) for _ in range(2))
+    G.mul_(y1, A2[:, 1].contiguous())
+    assert float((Y2[:, 1] - y1).abs().max()) <= 1e-9 * float(y1.abs().max())
+    assert t2 <= 1.9 * t1, (t1, t2)
+    print(f"C4 shape: one column {t1:.3f} ms, two columns in one pass {t2:.3f} ms ({t2 / t1:.2f}x)")

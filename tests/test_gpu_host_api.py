@@ -73,18 +73,18 @@ def test_host_pointer_mvm_matrix_gradient(cg, oracle, ctx, dt):
     assert lib.covgram_points_slice(hx, 290, 50, C.byref(f._P())) == f.EINVAL
     # gradient MVM through host pointers
     ag = rng.standard_normal(m * d).astype(dt); yg = rng.standard_normal(n * d).astype(dt); yg0 = yg.copy()
-    f.check(lib.covgram_grad_mvm(ctx, C.byref(spec), hx, hy, P(ag), P(yg), 0.4, -0.9, f.HOST))
+    f.check(lib.covgram_grad_mvm(ctx, C.byref(spec), hx, hy, P(ag), ag.size, P(yg), yg.size, 1, 0.4, -0.9, f.HOST))
     assert relerr(yg, oracle.grad_mul(yg0, ko, X, Y, ag, 0.4, -0.9, dt)) <= (1e-5 if dt == np.float32 else 1e-12)
     # value-gradient blocks and a composite kernel through host pointers (the composite goes in through its head)
     av = rng.standard_normal(m * (d + 1)).astype(dt); yv = rng.standard_normal(n * (d + 1)).astype(dt); yv0 = yv.copy()
-    f.check(lib.covgram_valgrad_mvm(ctx, C.byref(spec), hx, hy, P(av), P(yv), 0.4, -0.9, f.HOST))
+    f.check(lib.covgram_valgrad_mvm(ctx, C.byref(spec), hx, hy, P(av), av.size, P(yv), yv.size, 1, 0.4, -0.9, f.HOST))
     assert relerr(yv, oracle.valgrad_mul(yv0, ko, X, Y, av, 0.4, -0.9, dt)) <= (1e-5 if dt == np.float32 else 1e-12)
     comp = cg.device_spec(1.5 * cg.Lengthscale(cg.MaternP(2), 0.8) + 0.5 * cg.EQ())
     kc = oracle.Composite(((oracle.Kernel(oracle.MATERNP, p=2, lengthscale=0.8, scale=1.5),), (oracle.Kernel(oracle.EQ, scale=0.5),)))
     yc = np.zeros(n, dtype=dt)
     f.check(lib.covgram_mvm(ctx, f.kref(comp), hx, hy, P(a), m, P(yc), n, 1, 1.0, 0.0, f.HOST))
     assert relerr(yc, oracle.mul(None, kc, X, Y, a, dtype=dt)) <= tol
-    f.check(lib.covgram_grad_mvm(ctx, f.kref(comp), hx, hy, P(ag), P(yg), 1.0, 0.0, f.HOST))
+    f.check(lib.covgram_grad_mvm(ctx, f.kref(comp), hx, hy, P(ag), ag.size, P(yg), yg.size, 1, 1.0, 0.0, f.HOST))
     assert relerr(yg, oracle.grad_mul(None, kc, X, Y, ag, dtype=dt)) <= (1e-5 if dt == np.float32 else 1e-12)
     Mc = np.zeros((m, n), dtype=dt)
     f.check(lib.covgram_matrix(ctx, f.kref(comp), hx, hy, P(Mc), n, f.HOST))
