@@ -7,7 +7,8 @@ complete on every rank — which is exactly the replicated `a` the next Krylov i
 no other exchange.  Shards are padded to ceil(n/P) rows so the collective is a single
 all_gather_into_tensor of equal pieces.
 
-Symmetric form (gramian(k, x), vectors, where the library's symmetric matrix-core kernel applies — fp32 EQ): the n(n+1)/2
+Symmetric form (gramian(k, x), vectors, where a symmetric kernel of the library applies — fp32 on the matrix cores, fp64 on the
+direct-difference kernel): the n(n+1)/2
 unordered pairs are independent too, so rank g evaluates the upper-triangle tiles of the 256-row panels p ≡ g (mod P) — a
 cyclic assignment that gives every rank the same share of the triangle — and produces the partial product of those entries
 and their mirror images (covgram_mvm_sym_partial); ONE all-reduce (sum) completes b on every rank.  Half the kernel
@@ -25,6 +26,9 @@ import torch.distributed as dist
 # P: 636 vs 820 us per rank at P = 2, 333 vs 427 at P = 4, 173-199 vs 226 at P = 8; below that its 8-wave workgroups leave the
 # chip under-filled) — its all-reduce moves n scalars per rank where the all-gather moves n / P, a few microseconds apart at these sizes.
 SYM_MIN_PAIRS_PER_RANK = 1.0e9
+# fp64 (direct-difference symmetric kernel, 64-row blocks): a pair costs ~10x the fp32 matrix-core pair, so the form pays from fewer of them
+# (one GPU: from n = 8192, tools/fp64_sym_sweep.py)
+SYM_MIN_PAIRS_PER_RANK_F64 = 2.5e8
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -109,7 +113,8 @@ class ShardedGramian:
         if symmetric is not False and y is None and self.block == 1 and (self.world > 1 or self.force_collective):
             if sym_partial_factory is not None:
                 self.sym_partial = sym_partial_factory(k, x)
-            elif local_factory_is_default and (symmetric is True or self.n * (self.n / 2.0) / self.world >= SYM_MIN_PAIRS_PER_RANK):
+            elif local_factory_is_default and (symmetric is True or self.n * (self.n / 2.0) / self.world >=
+                                               (SYM_MIN_PAIRS_PER_RANK_F64 if x.dtype == torch.float64 else SYM_MIN_PAIRS_PER_RANK)):
                 full = local_factory(k, x)
                 if hasattr(full, "sym_partial_supported") and full.sym_partial_supported():
                     self._full_op = full

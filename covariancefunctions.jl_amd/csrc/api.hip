@@ -811,7 +811,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const void* Cn = (hk.k.trait == COVGRAM_ISOTROPIC) ? Y->center : nullptr;
     // Gramian(Dot(), x, y) = X Y' (src/gramian.jl:23,150-151): the reference goes entry by entry through the generic loop; the
     // product is X (Y' a), two O((n + m) d) streaming passes (lowrank.hip).  dense_variant = 1 / 2 keep the entry-by-entry kernels.
-    const bool dotfac = m > 0 && hk.tu_family == COVGRAM_DOT && hk.k.power == 1 && ctx->dense_variant == 0 &&
+    const bool dotfac = m > 0 && hk.tu_family == COVGRAM_DOT && hk.k.power == 1 && ctx->dense_variant == 0 && ctx->sym_part_world == 0 &&
                         (size_t)X->d * (size_t)nrhs * ts <= 65536;
     if (dotfac) {
         rc = mvm_dot_factored(ctx, hk, X, Y, a_dev, lda_d, y_dev, ldy_d, nrhs, alpha, beta); if (rc) return rc;
@@ -840,9 +840,14 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // slab n^2 / 8 bytes — held in workspace slot 4 for the life of the ctx — stays within 1 GiB (n <= 92681) when the choice is automatic,
     // 2 GiB (n <= 131072) when option "dense_sym" = 1 asks for it; R = 1 row per lane (64-row blocks) is what the kernel is written for.
     const bool cheap_profile = hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ || hk.tu_family == COVGRAM_DOT;
-    const bool dsym = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && ctx->dense_sym != 0 && X->dptr == Y->dptr && n == m &&
-                      hk.tu_family < COVGRAM_NFAMILY && hk.k.power == 1 && (ctx->dense_sym == 1 || n >= (cheap_profile ? 16384 : 8192)) &&
-                      R == 1 && (size_t)rowblocks * (size_t)npad * ts <= ((size_t)(ctx->dense_sym == 1 ? 2 : 1) << 30);
+    // covgram_mvm_sym_partial (fp64): rank r of P evaluates the 64-row blocks r, r + P, ... only (sym_part_world > 0)
+    const int sp_world = ctx->sym_part_world, sp_rank = ctx->sym_part_rank;
+    const int64_t sym_blocks = sp_world > 0 ? (rowblocks + sp_world - 1) / sp_world : rowblocks;
+    const bool dsym = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && (ctx->dense_sym != 0 || sp_world > 0) && X->dptr == Y->dptr && n == m &&
+                      hk.tu_family < COVGRAM_NFAMILY && hk.k.power == 1 &&
+                      (ctx->dense_sym == 1 || sp_world > 0 || n >= (cheap_profile ? 16384 : 8192)) &&
+                      R == 1 && (size_t)sym_blocks * (size_t)npad * ts <= ((size_t)((ctx->dense_sym == 1 || sp_world > 0) ? 2 : 1) << 30);
+    if (sp_world > 0 && !dsym) { set_error("the fp64 symmetric direct-difference kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
     ctx->last_dense_sym = dsym ? 1 : 0;
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
@@ -899,14 +904,15 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             da.jchunk = jchunk = per * 64;
             da.jsplit = jsplit = (int)((blocks + per - 1) / per);
             da.sym = 1;
+            if (sp_world > 0) { da.sym_first = sp_rank; da.sym_stride = sp_world; }
             rc = ws_reserve(ctx, 1, (size_t)jsplit * npad * ts, &da.out); if (rc) return rc;
-            rc = ws_reserve(ctx, 4, (size_t)rowblocks * npad * ts, &da.colslab); if (rc) return rc;
+            rc = ws_reserve(ctx, 4, (size_t)std::max<int64_t>(sym_blocks, 1) * npad * ts, &da.colslab); if (rc) return rc;
             auto* tms = timer_next(ctx);
             if (tms) (void)hipEventRecord(tms->first, ctx->stream);
             rc = launch(da, dtype); if (rc) return rc;
             if (tms) (void)hipEventRecord(tms->second, ctx->stream);
             hipLaunchKernelGGL(dense_sym_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(1024), 0, ctx->stream, (const double*)da.out,
-                               (const double*)da.colslab, npad, jsplit, (double*)y_c, n, alpha_eff, beta);
+                               (const double*)da.colslab, npad, jsplit, (double*)y_c, n, alpha_eff, beta, da.sym_first, da.sym_stride);
             continue;
         }
         if (jsplit == 1) da.out = y_c;
@@ -1218,6 +1224,13 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     return COVGRAM_OK;
 }
 
+// fp64: the direct-difference symmetric kernel (dense_sym_kernel) in its partial form — any single profile without a Power wrapper, d <= 64
+static bool dense_sym_partial_ok(const covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X) {
+    if (X->dtype != COVGRAM_F64 || X->n <= 0 || k == nullptr || k->family == COVGRAM_COMPOSITE || k->power != 1) return false;
+    if (X->d > kDims[kNumDims - 1] || pad_dim(X->d) < 0 || rows_per_lane_for(pad_dim(X->d)) != 1) return false;
+    return true;
+}
+
 int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported) {
     CG_REQUIRE(supported != nullptr, COVGRAM_EINVAL, "NULL argument");
     *supported = 0;
@@ -1227,6 +1240,7 @@ int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const c
     HostKernel hk;
     rc = make_host_kernel(k, X->dtype, false, &hk);
     if (rc) return rc;
+    if (X->dtype == COVGRAM_F64) { *supported = dense_sym_partial_ok(ctx, k, X) ? 1 : 0; return COVGRAM_OK; }
     *supported = (X->n > 0 && (mfma_eq_sym_eligible(ctx, hk, X, X, 1) || mfma_gen_sym_eligible(ctx, hk, X, X, 1))) ? 1 : 0;
     return COVGRAM_OK;
 }
@@ -1238,7 +1252,15 @@ int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const cov
     int32_t ok = 0;
     int rc = covgram_mvm_sym_supported(ctx, k, X, &ok);
     if (rc) return rc;
-    if (!ok) { set_error("symmetric matrix-core kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
+    if (!ok) { set_error("no symmetric kernel applies to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
+    if (X->dtype == COVGRAM_F64) {
+        // the reference's default element type: rank r takes the 64-row blocks r, r + P, ... of the upper triangle on the direct-
+        // difference kernel; the partials of all ranks add up to G a
+        ctx->sym_part_rank = rank; ctx->sym_part_world = world;
+        rc = covgram_mvm(ctx, k, X, X, a, X->n, y, X->n, 1, 1.0, 0.0, COVGRAM_DEVICE);
+        ctx->sym_part_rank = 0; ctx->sym_part_world = 0;
+        return rc;
+    }
     CG_DEVICE(ctx);
     HostKernel hk;
     rc = make_host_kernel(k, X->dtype, false, &hk);

@@ -171,6 +171,7 @@ struct covgram_ctx {
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
     int64_t last_dense_sym = 0;
+    int32_t sym_part_rank = 0, sym_part_world = 0;   // set by covgram_mvm_sym_partial around its fp64 call of covgram_mvm: world > 0 = partial form
     int64_t mfma_sym = -1;       // matrix-core EQ path on gramian(k, x): evaluate the upper triangle once (-1 auto, 0 never, 1 always)
     int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
     int64_t mfma_stamp = 0;      // 1: the general matrix-core EQ kernel runs its clock-stamping diagnostic build (info key "last_clock_khz")
@@ -243,7 +244,8 @@ struct DenseArgs {
     int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
     int32_t lds_pad = 0;                   // dynamic LDS bytes requested only to cap waves per CU (occupancy experiments)
     const void* C = nullptr;               // common centre (d scalars on the device) subtracted from both sides by isotropic kernels
-    int32_t sym = 0; void* colslab = nullptr;   // fp64 gramian(k, x): dense_sym_kernel (upper triangle once) + its [rowblocks][npad] column-sum slab
+    int32_t sym = 0; void* colslab = nullptr;   // fp64 gramian(k, x): dense_sym_kernel (upper triangle once) + its [row blocks of this launch][npad] column-sum slab
+    int32_t sym_first = 0, sym_stride = 1;      // ... over the 64-row blocks first, first + stride, ... (covgram_mvm_sym_partial: rank, world)
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;

@@ -313,13 +313,15 @@ template <int FAM, int D>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
     const double* __restrict__ X, int64_t n, int32_t d, const double* __restrict__ P, double* __restrict__ out,
     double* __restrict__ colslab, int64_t npad, int64_t jchunk, const double* __restrict__ Cn,
-    const typename ParamsOf<FAM, double>::type kp0) {
+    const typename ParamsOf<FAM, double>::type kp0, int32_t rb_first, int32_t rb_stride) {
     using T = double;
     constexpr bool ISO = fam_is_iso<FAM>;
     using Body = DenseBody<T, FAM, D, 1, 1, false, ISO>;
     constexpr int S = D + 1;
     const int lane = threadIdx.x;
-    const int64_t row_lo = (int64_t)blockIdx.x * 64;
+    // workgroup x takes the 64-row block rb_first + x rb_stride (all blocks: 0, 1; rank r of P in the multi-GPU form: r, P — a cyclic
+    // assignment gives every rank the same share of the triangle); its column sums go to row x of the launch's own slab
+    const int64_t row_lo = ((int64_t)rb_first + (int64_t)blockIdx.x * rb_stride) * 64;
     const int64_t j0 = (int64_t)blockIdx.y * jchunk;
     const int64_t j1 = (j0 + jchunk < n) ? (j0 + jchunk) : n;
     const int64_t row = row_lo + lane;
@@ -397,10 +399,12 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
 }
 
 // y[i] = alpha * (sum_sp out[sp][i] + sum_{rb < i / 64} colslab[rb][i]) + beta * y[i]   (fixed order: deterministic)
+// Partial form (rb_stride > 1): only the row blocks first, first + stride, ... were evaluated by this launch — rows of other blocks
+// get their column-sum terms only, and slab row x belongs to row block first + x stride.
 template <typename T /* double */>
 __global__ __launch_bounds__(1024) void dense_sym_reduce_kernel(const double* __restrict__ out, const double* __restrict__ colslab,
                                                                 int64_t npad, int32_t jsplit, double* __restrict__ y, int64_t n,
-                                                                double alpha, double beta) {
+                                                                double alpha, double beta, int32_t rb_first, int32_t rb_stride) {
     // 64 rows per workgroup, the terms strided over 16 waves (the last row blocks add n / 64 column-sum rows each: with 4 waves the
     // kernel ran at 1.6 TB/s of slab reads, 42 us at n = 32768)
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -408,8 +412,11 @@ __global__ __launch_bounds__(1024) void dense_sym_reduce_kernel(const double* __
     __shared__ double red[16][64];
     double s = 0.0;
     if (i < n) {
-        for (int sp = part; sp < jsplit; sp += 16) s += out[(int64_t)sp * npad + i];
-        const int64_t nb = blockIdx.x;                                 // row blocks above this one hold column sums for these rows
+        const int64_t B = blockIdx.x;
+        if (B >= rb_first && (B - rb_first) % rb_stride == 0)          // this launch evaluated the block's own rows
+            for (int sp = part; sp < jsplit; sp += 16) s += out[(int64_t)sp * npad + i];
+        // evaluated row blocks above this one hold column sums for these rows: first + x stride < B
+        const int64_t nb = B > rb_first ? (B - rb_first + rb_stride - 1) / rb_stride : 0;
         for (int64_t rb = part; rb < nb; rb += 16) s += colslab[rb * npad + i];
     }
     red[part][lane] = s;
@@ -428,9 +435,12 @@ static int launch_dense_sym_one(const DenseArgs& a) {
     // the kernel, its reduce kernel and covgram_mvm's slab sizes are written for 64-row blocks and one wave per workgroup
     static_assert(DENSE_THREADS == 64, "dense_sym_kernel: 64-row blocks, one wave per workgroup (CG_DENSE_THREADS must stay 64)");
     const typename ParamsOf<FAM, double>::type kp = make_params<FAM, double>(*a.hk);
-    dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)a.jsplit);
+    const int64_t blocks = (a.n + 63) / 64;
+    const int64_t mine = a.sym_first < blocks ? (blocks - a.sym_first + a.sym_stride - 1) / a.sym_stride : 0;
+    if (mine == 0) return COVGRAM_OK;
+    dim3 grid((unsigned)mine, (unsigned)a.jsplit);
     hipLaunchKernelGGL((dense_sym_kernel<FAM, D>), grid, dim3(DENSE_THREADS), 0, a.stream, (const double*)a.X, a.n, a.d,
-                       (const double*)a.P, (double*)a.out, (double*)a.colslab, a.npad, a.jchunk, (const double*)a.C, kp);
+                       (const double*)a.P, (double*)a.out, (double*)a.colslab, a.npad, a.jchunk, (const double*)a.C, kp, a.sym_first, a.sym_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;

@@ -190,7 +190,9 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
  * evaluates the upper-triangle tiles of gramian(k, x) whose 256-row panel p satisfies p % world == r — cyclic, so every rank
  * gets the same share of the triangle — and returns in y (n scalars, device) the partial product of those entries AND their
  * mirror images; the partials of all ranks add up to G a, so ONE all-reduce (RCCL) completes b on every rank
- * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  Only where the symmetric
+ * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  fp64 (the reference's default element type): the
+ * direct-difference symmetric kernel over the cyclic 64-row blocks p % world == rank — any single profile without a Power wrapper, d <= 64.
+ * fp32: only where the symmetric
  * matrix-core kernels apply (fp32, EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm gate, n from 12500 ... 18000 by profile or option "mfma_sym" = 1): `*supported` of
  * covgram_mvm_sym_supported says so (identically on every rank: it depends on k and x only), and
  * covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED otherwise — callers then shard rows and all-gather (covgram_mvm). */

@@ -37,6 +37,11 @@ def main():
     res["gather"] = {"rel": rel(b.cpu().numpy()[rows], ref), "shard": [G.lo, G.hi], "local_ms": loc, "collective_ms": col, "steps": steps}
     Gs = cg.ShardedGramian(cg.EQ(), X, symmetric=True)
     res["reduce"] = {"rel": rel((Gs @ a).cpu().numpy()[rows], ref), "used_partials": Gs.sym_partial is not None}
+    n6 = 6001
+    X6h = rng.standard_normal((n6, d)); a6h = rng.standard_normal(n6)
+    G6 = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X6h).to(dev), symmetric=True)
+    res["reduce64"] = {"rel": rel((G6 @ torch.from_numpy(a6h).to(dev)).cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), X6h, X6h, a6h)),
+                       "used_partials": G6.sym_partial is not None}
     m, p = 2111, 3
     Yh = rng.standard_normal((m, d)); Ah = rng.standard_normal((m, p)); X64 = rng.standard_normal((3001, d))
     Gm = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X64).to(dev), torch.from_numpy(Yh).to(dev))

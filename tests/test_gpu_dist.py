@@ -47,6 +47,14 @@ def _worker(rank, world, port, q):
         assert Gs.sym_partial is not None
         bs = Gs @ a
         res["reduce"] = (float(np.linalg.norm(bs.cpu().numpy()[rows] - ref) / np.linalg.norm(ref)), cg.get_info("last_mfma_sym"))
+        # (2b) the same in fp64 (the reference's default element type): cyclic 64-row blocks on the direct-difference symmetric kernel
+        n6 = 6001
+        X6h = rng.standard_normal((n6, d)); a6h = rng.standard_normal(n6)
+        G6 = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X6h).to(dev), symmetric=True)
+        assert G6.sym_partial is not None
+        b6 = G6 @ torch.from_numpy(a6h).to(dev)
+        ref6 = o.mul(None, o.Kernel(o.MATERNP, p=2), X6h, X6h, a6h)
+        res["reduce64"] = (float(np.linalg.norm(b6.cpu().numpy() - ref6) / np.linalg.norm(ref6)), cg.get_info("last_dense_sym"))
         # (3) fp64 MaternP(2), two point sets, matrix right-hand side (direct-difference kernel), and the gradient blocks
         m, p = 2111, 3
         Yh = rng.standard_normal((m, d)); Ah = rng.standard_normal((m, p)); X64 = rng.standard_normal((3001, d))
@@ -100,6 +108,7 @@ def test_two_processes_share_a_gpu_over_gloo():
     for r in (0, 1):
         assert out[r]["gather"][2] <= 1e-5 and out[r]["gather"][3] == 2, out[r]["gather"]       # the matrix-core kernel ran in each rank
         assert out[r]["reduce"][0] <= 1e-5 and out[r]["reduce"][1] == 1, out[r]["reduce"]         # the symmetric kernel ran in each rank
+        assert out[r]["reduce64"][0] <= 1e-12 and out[r]["reduce64"][1] == 1, out[r]["reduce64"]  # ... and its fp64 counterpart
         assert out[r]["matrix"] <= 1e-12 and out[r]["grad"] <= 1e-12, (out[r]["matrix"], out[r]["grad"])
     assert out[0]["cg_converged"] and out[0]["cg_err"] <= 1e-8, out[0]["cg_err"]
     assert np.array_equal(out[0]["cg"], out[1]["cg"])                                             # replicated vectors stay bit-identical
@@ -137,6 +146,7 @@ def _check_rccl(res, world):
     assert res["world"] == world and res["backend"] == "nccl"
     assert res["gather"]["rel"] <= 1e-5 and res["gather"]["steps"] == 1 and res["gather"]["collective_ms"] > 0, res["gather"]
     assert res["reduce"]["rel"] <= 1e-5 and res["reduce"]["used_partials"], res["reduce"]
+    assert res["reduce64"]["rel"] <= 1e-12 and res["reduce64"]["used_partials"], res["reduce64"]
     assert res["matrix"] <= 1e-12 and res["grad"] <= 1e-12, (res["matrix"], res["grad"])
     assert res["replicated"]
 
