@@ -73,6 +73,20 @@ static int run_blas(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t l
     return COVGRAM_OK;
 }
 
+// The explicit Kronecker product of two SMALL factors, column-major: P[(i1 r2 + i2) + (j1 c2 + j2) R] = F1[i1, j1] F2[i2, j2].  Two trailing modes
+// of 16 x 16 factors are two launch-bound passes over the tensor (16^5: 30 + 11 us); as ONE 256 x 256 factor they are one pass of the last-mode
+// kernel, whose extra flops are free at these sizes.
+constexpr int64_t MERGE_MAX_SIDE = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void kron_factor_kernel(const T* __restrict__ F1, int64_t ld1, int r1, int c1, const T* __restrict__ F2, int64_t ld2, int r2, int c2,
+                                                          T* __restrict__ P) {
+    const int R = r1 * r2, C = c1 * c2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * C) return;
+    const int i = e % R, j = e / R;
+    P[e] = F1[(i / r2) + (int64_t)(j / c2) * ld1] * F2[(i % r2) + (int64_t)(j % c2) * ld2];
+}
+
 constexpr int64_t BLAS_MIN_SIDE = 1024;       // a factor side from which a mode is always a library GEMM
 constexpr int64_t BLAS_MID_SIDE = 256;        // ... and from this side on when the mode has BLAS_MID_FLOPS of work: compute-bound, where a
 constexpr double BLAS_MID_FLOPS = 2.0e9;      // register-blocked GEMM wins (256^3 fp64: 547 us on the kernels here, 471 us on rocBLAS)
@@ -80,7 +94,7 @@ constexpr double BLAS_MID_FLOPS = 2.0e9;      // register-blocked GEMM wins (256
 // (F_1 (x) ... (x) F_q) applied to `batch` tensors that lie one after the other (the right-hand sides)
 template <typename T>
 static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t* rows, const int64_t* cols, const int64_t* lds, int q, int64_t batch,
-                    const T* a_dev, T* y_dev, T alpha, T beta, T* bufA, T* bufB) {
+                    const T* a_dev, T* y_dev, T alpha, T beta, T* bufA, T* bufB, T* merged) {
     int64_t cur[16];
     for (int i = 0; i < q; ++i) cur[i] = cols[i];
     const T* src = a_dev;
@@ -107,8 +121,19 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
         // small slabs leave most of the fused pass's eight waves idle (16^5: 104 us fused against 2 x 7 us mode by mode)
         if (rows[q - 2] < PAIR_MIN_SIDE || cols[q - 1] < PAIR_MIN_SIDE) pair = false;
     }
-    const int nsingle = pair ? q - 2 : q;
     int rc;
+    // two small trailing factors the fused pass does not take: multiply them out (<= 256 x 256) and run ONE last-mode pass
+    if (!pair && q >= 2 && rows[q - 2] * rows[q - 1] <= MERGE_MAX_SIDE && cols[q - 2] * cols[q - 1] <= MERGE_MAX_SIDE && merged != nullptr) {
+        const int r1 = (int)rows[q - 2], c1 = (int)cols[q - 2], r2 = (int)rows[q - 1], c2 = (int)cols[q - 1];
+        const int tot = r1 * r2 * c1 * c2;
+        hipLaunchKernelGGL(kron_factor_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)factors[q - 2], lds[q - 2], r1, c1,
+                           (const T*)factors[q - 1], lds[q - 1], r2, c2, merged);
+        const void* f2[16]; int64_t rows2[16], cols2[16], lds2[16];
+        for (int i = 0; i + 2 < q; ++i) { f2[i] = factors[i]; rows2[i] = rows[i]; cols2[i] = cols[i]; lds2[i] = lds[i]; }
+        f2[q - 2] = merged; rows2[q - 2] = (int64_t)r1 * r2; cols2[q - 2] = (int64_t)c1 * c2; lds2[q - 2] = (int64_t)r1 * r2;
+        return kron_run<T>(ctx, f2, rows2, cols2, lds2, q - 1, batch, a_dev, y_dev, alpha, beta, bufA, bufB, nullptr);
+    }
+    const int nsingle = pair ? q - 2 : q;
     if (pair && pair_first) {
         const bool final = (nsingle == 0);
         rc = run_pair<T>(ctx, src, next_out(final), (const T*)factors[q - 2], lds[q - 2], rows[q - 2], cols[q - 2], (const T*)factors[q - 1], lds[q - 1],
@@ -191,7 +216,8 @@ int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t
     const size_t tens = (((size_t)maxel * nrhs * ts) + 255) & ~(size_t)255;
     const size_t abytes = (((size_t)nin * nrhs * ts) + 255) & ~(size_t)255, ybytes = (((size_t)nout * nrhs * ts) + 255) & ~(size_t)255;
     const bool stage_a = host || !packed_a, stage_y = host || !packed_y;
-    const size_t need = 2 * tens + (stage_a ? abytes : 0) + (stage_y ? ybytes : 0) + fbytes + 1024;
+    const size_t mbytes = (size_t)kron::MERGE_MAX_SIDE * kron::MERGE_MAX_SIDE * ts;      // the multiplied-out pair of small trailing factors
+    const size_t need = 2 * tens + (stage_a ? abytes : 0) + (stage_y ? ybytes : 0) + fbytes + mbytes + 1024;
     void* w; int rc = ws_reserve(ctx, 1, need, &w); if (rc) return rc;
     char* base = (char*)w;
     void* bufA = base; void* bufB = base + tens;
@@ -214,8 +240,9 @@ int covgram_kron_mvm(covgram_ctx* ctx, const void* const* factors, const int64_t
             fdev[i] = p; ldd[i] = rows[i]; p += (((size_t)rows[i] * cols[i] * ts) + 15) & ~(size_t)15;
         }
     }
-    if (dtype == COVGRAM_F32) rc = kron::kron_run<float>(ctx, fdev, rows, cols, ldd, q, nrhs, (const float*)a_dev, (float*)y_dev, (float)alpha, (float)beta, (float*)bufA, (float*)bufB);
-    else rc = kron::kron_run<double>(ctx, fdev, rows, cols, ldd, q, nrhs, (const double*)a_dev, (double*)y_dev, alpha, beta, (double*)bufA, (double*)bufB);
+    void* merged = (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    if (dtype == COVGRAM_F32) rc = kron::kron_run<float>(ctx, fdev, rows, cols, ldd, q, nrhs, (const float*)a_dev, (float*)y_dev, (float)alpha, (float)beta, (float*)bufA, (float*)bufB, (float*)merged);
+    else rc = kron::kron_run<double>(ctx, fdev, rows, cols, ldd, q, nrhs, (const double*)a_dev, (double*)y_dev, alpha, beta, (double*)bufA, (double*)bufB, (double*)merged);
     if (rc) return rc;
     if (stage_y) {
         const hipMemcpyKind down = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
