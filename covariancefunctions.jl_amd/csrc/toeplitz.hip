@@ -704,6 +704,9 @@ __global__ void permute16_kernel(const typename V2T<T>::type* __restrict__ S, vo
 
 // REALS: the digit-reversed spectrum copy of a symmetric matrix holds real parts only (C5 fp64 89.2 -> 86.7 us).
 // (Measured and not kept: fetching the thread's 16 spectrum values into registers at kernel start (fp64, 206 VGPRs): 96.1 vs 89.7 us.)
+// (Measured and not kept, round 3 — VERDICT r2 item 8: ONE row in LDS (68 KB) and the other row's spectrum in registers, 256-thread workgroups,
+//  two per CU in different phases, twiddles from the global table: C5 fp64 86.9 us against 86.1 for this kernel, fp32 62.8 / 60.5 — the row pass is
+//  not short of overlap between a CU's load, compute and store phases; profiles/r03_c5_one_row_lds_ab.txt.)
 template <typename T, bool REALS>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
                                                                           const typename V2T<T>::type* __restrict__ S,
