@@ -530,7 +530,7 @@ def main():
         achieved_tflops = flops_launch / kern_s * 1e-12
         traffic = None
         pmc = None
-        for rnd in ("r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
+        for rnd in ("r03", "r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
             cand = os.path.join(ROOT, "profiles", f"{rnd}_" + (("dense_mfma_sym_pmc.json" if sym_path else "dense_mfma_pmc.json") if dense_path == 2
                                                                else "dense_pmc.json"))
             if os.path.exists(cand):
