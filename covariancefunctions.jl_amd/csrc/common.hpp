@@ -15,6 +15,11 @@
 
 namespace covgram {
 
+// fused multiply-add in the operands' own precision (__builtin_fma on floats is the DOUBLE fma behind two conversions)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+
 void set_error(const char* fmt, ...);
 
 #define CG_CHECK_HIP(expr)                                                                          \

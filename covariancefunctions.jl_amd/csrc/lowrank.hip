@@ -26,10 +26,10 @@ template <> struct VecOf<double, 1> { typedef double type; };
 
 template <typename T, int VEC>
 __device__ __forceinline__ T vdot(typename VecOf<T, VEC>::type u, typename VecOf<T, VEC>::type w, T acc) {
-    if constexpr (VEC == 1) return __builtin_fma(u, w, acc);
+    if constexpr (VEC == 1) return fma_t(u, w, acc);
     else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc = __builtin_fma(u[e], w[e], acc);
+        for (int e = 0; e < VEC; ++e) acc = fma_t(u[e], w[e], acc);
         return acc;
     }
 }
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ 
                 for (int64_t jj = j; jj < j1; ++jj)
 #pragma unroll
                     for (int c = 0; c < LR_RC; ++c)
-                        if (c < nc) acc[c] = __builtin_fma(V[(c0 + c) * ldv + jj], a[jj], acc[c]);
+                        if (c < nc) acc[c] = fma_t(V[(c0 + c) * ldv + jj], a[jj], acc[c]);
             }
         }
         // block reduction through LDS: thread t sums 32 of column (t / 8)'s 256 partials, then 8 lanes combine (fixed order)
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void lowrank_uz_kernel(const T* __restrict__ U
     } else {
         for (int64_t ii = i; ii < n; ++ii) {
             T s = (T)0;
-            for (int64_t k = 0; k < r; ++k) s = __builtin_fma(U[ii + k * ldu], z[k], s);
+            for (int64_t k = 0; k < r; ++k) s = fma_t(U[ii + k * ldu], z[k], s);
             T v = alpha * s;
-            if (beta != (T)0) v = __builtin_fma(beta, y[ii], v);
+            if (beta != (T)0) v = fma_t(beta, y[ii], v);
             y[ii] = v;
         }
     }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void lowrank_uz_mfma_kernel(const T* __restric
             if (jr < p) {
                 T* yp = y + irow + (int64_t)jr * ldy;
                 T val = alpha * acc[j][v];
-                if (beta != (T)0) val = __builtin_fma(beta, *yp, val);
+                if (beta != (T)0) val = fma_t(beta, *yp, val);
                 *yp = val;
             }
         }
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void dot_vta_kernel(const T* __restrict__ Y, i
                 for (int c = 0; c < DOT_DC; ++c) {
                     const T yv = Y[j * (int64_t)d + (c0 + c < d ? c0 + c : d - 1)];
 #pragma unroll
-                    for (int q = 0; q < DOT_NQ; ++q) acc[c][q] = __builtin_fma(yv, av[q], acc[c][q]);
+                    for (int q = 0; q < DOT_NQ; ++q) acc[c][q] = fma_t(yv, av[q], acc[c][q]);
                 }
             }
 #pragma unroll
@@ -440,14 +440,14 @@ __global__ __launch_bounds__(256) void dot_xz_kernel(const T* __restrict__ X, in
         for (int c = 0; c < d; ++c) {
             const T xv = xr[c];
 #pragma unroll
-            for (int q = 0; q < DOT_NQ; ++q) s[q] = __builtin_fma(xv, z[c + (q0 + q < nrhs ? q0 + q : nrhs - 1) * d], s[q]);
+            for (int q = 0; q < DOT_NQ; ++q) s[q] = fma_t(xv, z[c + (q0 + q < nrhs ? q0 + q : nrhs - 1) * d], s[q]);
         }
 #pragma unroll
         for (int q = 0; q < DOT_NQ; ++q)
             if (q0 + q < nrhs) {
                 T* yp = y + i + (int64_t)(q0 + q) * ldy;
                 T v = alpha * s[q];
-                if (beta != (T)0) v = __builtin_fma(beta, *yp, v);
+                if (beta != (T)0) v = fma_t(beta, *yp, v);
                 *yp = v;
             }
     }

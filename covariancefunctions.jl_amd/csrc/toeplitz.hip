@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void toep_epilogue_kernel(const T* __restrict_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     T v = alpha * t[i];
-    if (beta != (T)0) v = __builtin_fma(beta, y[i], v);
+    if (beta != (T)0) v = fma_t(beta, y[i], v);
     y[i] = v;
 }
 
@@ -218,12 +218,12 @@ __global__ __launch_bounds__(COLFFT_THREADS, 8) void colfft_kernel(const T* __re
                 const int64_t jj = (int64_t)row * Mp + np;            // natural order: y[2jj], y[2jj+1]
                 if (2 * jj < n) {
                     T ov = alpha * o[q].x;
-                    if (beta != (T)0) ov = __builtin_fma(beta, y[2 * jj], ov);
+                    if (beta != (T)0) ov = fma_t(beta, y[2 * jj], ov);
                     y[2 * jj] = ov;
                 }
                 if (2 * jj + 1 < n) {
                     T ov = alpha * o[q].y;
-                    if (beta != (T)0) ov = __builtin_fma(beta, y[2 * jj + 1], ov);
+                    if (beta != (T)0) ov = fma_t(beta, y[2 * jj + 1], ov);
                     y[2 * jj + 1] = ov;
                 }
             }
@@ -675,12 +675,12 @@ __global__ __launch_bounds__(16 * R * TW, (R == 8 ? 1 : 2)) void colfft16_kernel
             const int64_t e = 2 * ((int64_t)(r + BLK * q) * Mp + np);       // natural order: y[e], y[e + 1]
             if (e < n) {
                 T ov = alpha * x[q].x;
-                if (beta != (T)0) ov = __builtin_fma(beta, y[e], ov);
+                if (beta != (T)0) ov = fma_t(beta, y[e], ov);
                 y[e] = ov;
             }
             if (e + 1 < n) {
                 T ov = alpha * x[q].y;
-                if (beta != (T)0) ov = __builtin_fma(beta, y[e + 1], ov);
+                if (beta != (T)0) ov = fma_t(beta, y[e + 1], ov);
                 y[e + 1] = ov;
             }
         }

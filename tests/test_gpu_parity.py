@@ -1246,6 +1246,38 @@ def test_toeplitz_direct_solvers_durbin_levinson_trench(cg, oracle, n):
         cg.levinson(rd, torch.zeros(n + 3, dtype=torch.float64, device="cuda"))
 
 
+@pytest.mark.parametrize("m", [63, 64, 65, 511, 512, 513, 1025, 4097, 16383, 16384, 16385])
+def test_toeplitz_direct_solvers_on_chip_boundaries(cg, oracle, m):
+    """Durbin / Levinson at the sizes where the on-chip kernel (csrc/toeplitz_direct.hip: levinson_reg_kernel, m <= 16384, 16 / 32
+    entries per thread, 64-lane waves) changes regime — one entry either side of a wave, of the whole workgroup, and of the size
+    cap where the global-memory kernel takes over — against the oracle's restatement of src/toeplitz.jl:14-27 / :77-98 and
+    through the residual of the FFT MVM.  Exponential kernel on a grid: condition number ~ m^2, so the fp64 chains keep
+    ~ 16 - 2 log10(m) digits."""
+    rng = np.random.default_rng(4100 + m)
+    xs = np.linspace(-1.0, 1.0, m)
+    vc = np.exp(-np.abs(xs - xs[0]))
+    r, b = vc[1:].copy(), rng.standard_normal(m)
+    tol = max(1e-10, 1e-15 * m * m)
+    rd, bd = torch.from_numpy(r).cuda(), torch.from_numpy(b).cuda()
+    x = cg.levinson(rd, bd)
+    if m <= 4097:                                                   # (the oracle's Levinson is a Python double loop: a minute at m = 16384)
+        assert relerr(x.cpu().numpy(), oracle.levinson(r, b)) <= tol, ("levinson", m)
+    T = cg.SymmetricToeplitz(torch.from_numpy(vc).cuda())
+    assert relerr((T @ x).cpu().numpy(), b) <= tol
+    y = cg.durbin(rd).cpu().numpy()                                 # length m - 1: the next size down of the same kernel
+    assert relerr(y, oracle.durbin(r)) <= tol, ("durbin", m)
+    # fp32: the same chains on a diagonal of 1.5 (well conditioned at every size: the unit-diagonal grid system loses ~ 4e-10 m^2
+    # to the rounding of its INPUTS alone, tools/levinson_fp32_accuracy.py) against the fp64 chain; measured 1.4e-7 sqrt(m)
+    # (Levinson) and 6e-7 sqrt(m) (Durbin)
+    rj = rd / 1.5
+    xj32, xj64 = cg.levinson(rj.float(), bd.float()), cg.levinson(rj, bd)
+    assert relerr(xj32.double().cpu().numpy(), xj64.cpu().numpy()) <= 1e-6 * np.sqrt(m), ("levinson fp32", m)
+    yj32, yj64 = cg.durbin(rj.float()), cg.durbin(rj)
+    assert relerr(yj32.double().cpu().numpy(), yj64.cpu().numpy()) <= 3e-6 * np.sqrt(m), ("durbin fp32", m)
+    if m <= 4097:
+        assert relerr(yj64.cpu().numpy(), oracle.durbin(r / 1.5)) <= 1e-11
+
+
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 65536), (torch.float64, 250000), (torch.float64, 1000000), (torch.float64, 3000001),
                                      (torch.float32, 250000), (torch.float32, 4000000),
                                      (torch.float64, 500000), (torch.float32, 100000),      # N = 2^20, 2^18: column length 512 (x 1024, x 256)
