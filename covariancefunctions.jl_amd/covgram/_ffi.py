@@ -22,7 +22,7 @@ F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE, ENOMEM = 0, -1, -2, -3, -4, -5
 MATERNP_MAX_P = 8
-ABI_VERSION = 110   # COVGRAM_VERSION of the include/covgram.h these prototypes mirror
+ABI_VERSION = 111   # COVGRAM_VERSION of the include/covgram.h these prototypes mirror
 
 
 class covgram_kernel(C.Structure):
@@ -105,6 +105,7 @@ PROTOTYPES = {
     "covgram_toeplitz_mvm": (C.c_int, [_P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_destroy": (C.c_int, [_P]),
     "covgram_cg_step": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
+    "covgram_cg_step_shifted": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "covgram_toeplitz_durbin": (C.c_int, [_P, _P, _I64, _P, _I32, _I32]),
     "covgram_toeplitz_levinson": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32]),
     "covgram_toeplitz_trench": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32]),

@@ -17,24 +17,48 @@ from . import _ffi
 from .gramian import LazyOperator, get_ctx, _dtype_code
 
 
+NORM_SLOT = 2 + 512            # scal[NORM_SLOT] = |r| after a step (include/covgram.h: covgram_cg_step_shifted)
+
+
+def _split_shift(A):
+    """A = G + Diagonal(d) with one lazy term and one 1-D tensor -> (G, d); otherwise (A, None).  The library's CG step adds the
+    diagonal term to Ap inside its first launch (covgram_cg_step_shifted), so the MVM of the iteration is the Gramian's alone."""
+    from .gramian import LazyMatrixSum
+    if isinstance(A, LazyMatrixSum) and len(A.args) == 2:
+        lazy = [t for t in A.args if hasattr(t, "mul_") and not torch.is_tensor(t)]
+        diag = [t for t in A.args if torch.is_tensor(t) and t.dim() == 1]
+        if len(lazy) == 1 and len(diag) == 1:
+            return lazy[0], diag[0]
+    return A, None
+
+
 def _fused_step(A, x, r, p, Ap):
-    """The iteration's vector work through covgram_cg_step when everything is a contiguous CUDA vector of one supported
-    dtype; returns (step, scal) or None.  scal[1] = |r|^2 after every step (and before the first)."""
+    """The iteration's work through the library when everything is a contiguous CUDA vector of one supported dtype:
+    returns (iterate, scal) or None; iterate() = the MVM Ap = G p + covgram_cg_step_shifted (alpha, x, r, rho', p, |r|: three
+    launches).  scal[1] = |r|^2 and scal[NORM_SLOT] = |r| after every step."""
     if not (x.is_cuda and x.dim() == 1 and x.dtype in (torch.float32, torch.float64)):
         return None
     if not all(t.is_contiguous() and t.dtype == x.dtype and t.device == x.device for t in (r, p, Ap)):
         return None
+    G, diag = _split_shift(A)
+    if diag is not None:
+        diag = diag.to(device=x.device, dtype=x.dtype).contiguous()
+        if diag.shape[0] != x.shape[0]:
+            G, diag = A, None
     lib = _ffi.lib()
-    scal = torch.zeros(2 + 512, dtype=x.dtype, device=x.device)
+    scal = torch.zeros(NORM_SLOT + 1, dtype=x.dtype, device=x.device)
     scal[1] = torch.dot(r, r)
     ctx = get_ctx(x.device)
     code, n = _dtype_code(x.dtype), x.shape[0]
     P = _ffi._P
+    dptr = P(diag.data_ptr()) if diag is not None else None
 
-    def step():
-        _ffi.check(lib.covgram_cg_step(ctx.bind_stream(), n, code, P(x.data_ptr()), P(r.data_ptr()), P(p.data_ptr()), P(Ap.data_ptr()),
-                                       P(scal.data_ptr())))
-    return step, scal
+    def iterate():
+        G.mul_(Ap, p)                       # the hot path
+        _ffi.check(lib.covgram_cg_step_shifted(ctx.bind_stream(), n, code, P(x.data_ptr()), P(r.data_ptr()), P(p.data_ptr()),
+                                               P(Ap.data_ptr()), P(scal.data_ptr()), dptr))
+    iterate.keep = (diag, G)                # (the captured graph holds raw pointers)
+    return iterate, scal
 
 
 def cg(A: LazyOperator, b: torch.Tensor, x0: Optional[torch.Tensor] = None, reltol: float = 1e-8, abstol: float = 0.0,
@@ -68,11 +92,10 @@ def cg(A: LazyOperator, b: torch.Tensor, x0: Optional[torch.Tensor] = None, relt
     it, res = 0, r0
     fused = _fused_step(A, x, r, p, Ap) if precond is None else None
     if fused is not None:
-        step, scal = fused
+        iterate, scal = fused
         while it < maxiter and res > tol:
-            A.mul_(Ap, p)                   # the hot path
-            step()                          # alpha, x, r, rho', p: three launches
-            res = float(scal[1]) ** 0.5     # the convergence test: the iteration's one synchronisation
+            iterate()                       # Ap = A p; alpha, x, r, rho', p
+            res = float(scal[NORM_SLOT])    # the convergence test: the iteration's one synchronisation
             it += 1
         return x, {"iterations": it, "residual_norm": res, "converged": res <= tol}
     while it < maxiter and res > tol:
@@ -117,11 +140,10 @@ def _cg_graph(A, b, x0, reltol, abstol, maxiter, precond, check_every):
     fused = _fused_step(A, x, r, p, Ap) if precond is None else None
 
     def body():
-        A.mul_(Ap, p)
         if fused is not None:
-            fused[0]()
-            torch.sqrt(fused[1][1], out=res)
+            fused[0]()                      # |r| is left in scal[NORM_SLOT]
             return
+        A.mul_(Ap, p)
         alpha = rz / torch.dot(p, Ap)
         x.addcmul_(p, alpha)
         r.addcmul_(Ap, -alpha)
@@ -139,6 +161,8 @@ def _cg_graph(A, b, x0, reltol, abstol, maxiter, precond, check_every):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
         body()
+    if fused is not None:
+        res = fused[1][NORM_SLOT]
     resf = float(res)
     while it < maxiter and resf > tol:
         k = min(check_every, maxiter - it)

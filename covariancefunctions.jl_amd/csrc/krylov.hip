@@ -1,4 +1,5 @@
-// covgram — the vector recurrences of one conjugate-gradient iteration in three launches.
+// covgram — the vector recurrences of one conjugate-gradient iteration in three launches (the noise term of G + sigma^2 I and the
+// residual norm ride along in the first and the last one: covgram_cg_step_shifted).
 //
 // The reference solves G \ b with IterativeSolvers.cg! (src/gramian.jl:229-238, src/lazy_linear_algebra.jl:135-144); the package
 // is a dependency (Manifest.toml: IterativeSolvers 0.9.2), not part of /root/reference.  Its published iteration, restated:
@@ -23,13 +24,18 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return t;
 }
 
-// scal[0] <- scal[1] (the rho committed by the previous step);  partA[b] = sum over block b's elements of p . Ap
-template <typename T>
-__global__ __launch_bounds__(CG_THREADS) void cg_dot_kernel(int64_t n, const T* __restrict__ p, const T* __restrict__ Ap, T* __restrict__ scal) {
+// scal[0] <- scal[1] (the rho committed by the previous step);  partA[b] = sum over block b's elements of p . Ap.
+// SHIFT: Ap holds G p of the Gramian alone and A = G + Diagonal(diag): the pass completes Ap <- Ap + diag .* p on its way.
+template <typename T, bool SHIFT>
+__global__ __launch_bounds__(CG_THREADS) void cg_dot_kernel(int64_t n, const T* __restrict__ p, T* __restrict__ Ap, T* __restrict__ scal, const T* __restrict__ diag) {
     __shared__ double sh[CG_THREADS / 64];
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = scal[1];
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) s += (double)p[i] * (double)Ap[i];
+    for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) {
+        T ap = Ap[i];
+        if (SHIFT) { ap = cg_fma(diag[i], p[i], ap); Ap[i] = ap; }
+        s += (double)p[i] * (double)ap;
+    }
     const double t = block_sum<T>(s, sh);
     if (threadIdx.x == 0) scal[2 + blockIdx.x] = (T)t;
 }
@@ -55,35 +61,44 @@ __global__ __launch_bounds__(CG_THREADS) void cg_update_kernel(int64_t n, T* __r
 
 // rho' = sum(partB);  p = r + (rho' / scal[0]) p;  scal[1] <- rho'
 template <typename T>
-__global__ __launch_bounds__(CG_THREADS) void cg_direction_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ r, T* __restrict__ scal, int nblocks) {
+__global__ __launch_bounds__(CG_THREADS) void cg_direction_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ r, T* __restrict__ scal, int nblocks, T* __restrict__ norm_out) {
     __shared__ double sh[CG_THREADS / 64];
     const double rho = block_sum<T>(threadIdx.x < nblocks ? (double)scal[2 + CG_BLOCKS + threadIdx.x] : 0.0, sh);
     const T beta = (scal[0] == (T)0) ? (T)0 : (T)(rho / (double)scal[0]);
     for (int64_t i = (int64_t)blockIdx.x * CG_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_THREADS) p[i] = cg_fma(beta, p[i], r[i]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = (T)rho;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[1] = (T)rho; if (norm_out) *norm_out = (T)__builtin_sqrt(rho); }
 }
 
 template <typename T>
-static void cg_step_T(hipStream_t st, int64_t n, T* x, T* r, T* p, const T* Ap, T* scal) {
+static void cg_step_T(hipStream_t st, int64_t n, T* x, T* r, T* p, T* Ap, T* scal, const T* diag, bool norm) {
     const int nb = (int)std::min<int64_t>(CG_BLOCKS, std::max<int64_t>(1, (n + 4 * CG_THREADS - 1) / (4 * CG_THREADS)));
-    hipLaunchKernelGGL(cg_dot_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, (const T*)p, Ap, scal);
-    hipLaunchKernelGGL(cg_update_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, x, r, (const T*)p, Ap, scal, nb);
-    hipLaunchKernelGGL(cg_direction_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, p, (const T*)r, scal, nb);
+    if (diag) hipLaunchKernelGGL((cg_dot_kernel<T, true>), dim3(nb), dim3(CG_THREADS), 0, st, n, (const T*)p, Ap, scal, diag);
+    else hipLaunchKernelGGL((cg_dot_kernel<T, false>), dim3(nb), dim3(CG_THREADS), 0, st, n, (const T*)p, Ap, scal, diag);
+    hipLaunchKernelGGL(cg_update_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, x, r, (const T*)p, (const T*)Ap, scal, nb);
+    hipLaunchKernelGGL(cg_direction_kernel<T>, dim3(nb), dim3(CG_THREADS), 0, st, n, p, (const T*)r, scal, nb, norm ? scal + 2 + 2 * CG_BLOCKS : (T*)nullptr);
 }
 
 }  // namespace covgram
 
 using namespace covgram;
 
-extern "C" int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal) {
+static int cg_step_impl(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, void* Ap, void* scal, const void* diag, bool norm) {
     CG_REQUIRE(ctx != nullptr, COVGRAM_EINVAL, "ctx is NULL");
     CG_REQUIRE(dtype == COVGRAM_F32 || dtype == COVGRAM_F64, COVGRAM_EINVAL, "dtype must be COVGRAM_F32 or COVGRAM_F64");
     CG_REQUIRE(n >= 0, COVGRAM_EINVAL, "n must be >= 0");
     if (n == 0) return COVGRAM_OK;
     CG_REQUIRE(x && r && p && Ap && scal, COVGRAM_EINVAL, "NULL vector");
     CG_DEVICE(ctx);
-    if (dtype == COVGRAM_F32) cg_step_T<float>(ctx->stream, n, (float*)x, (float*)r, (float*)p, (const float*)Ap, (float*)scal);
-    else cg_step_T<double>(ctx->stream, n, (double*)x, (double*)r, (double*)p, (const double*)Ap, (double*)scal);
+    if (dtype == COVGRAM_F32) cg_step_T<float>(ctx->stream, n, (float*)x, (float*)r, (float*)p, (float*)Ap, (float*)scal, (const float*)diag, norm);
+    else cg_step_T<double>(ctx->stream, n, (double*)x, (double*)r, (double*)p, (double*)Ap, (double*)scal, (const double*)diag, norm);
     CG_CHECK_HIP(hipGetLastError());
     return COVGRAM_OK;
+}
+
+extern "C" int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal) {
+    return cg_step_impl(ctx, n, dtype, x, r, p, const_cast<void*>(Ap), scal, nullptr, false);   // (Ap is only read without a shift)
+}
+
+extern "C" int covgram_cg_step_shifted(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, void* Ap, void* scal, const void* diag) {
+    return cg_step_impl(ctx, n, dtype, x, r, p, Ap, scal, diag, true);
 }

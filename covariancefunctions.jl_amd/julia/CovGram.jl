@@ -57,7 +57,7 @@ const F_EQ, F_EXP, F_RQ, F_GAMMAEXP, F_CAUCHY, F_IMQ, F_MATERNP, F_DOT, F_EXPDOT
 const F_CONSTANT, F_COMPOSITE = Int32(100), Int32(101)
 const ISO, DOTP = Int32(1), Int32(2)
 const HOST, DEVICE = Int32(0), Int32(1)
-const ABI_VERSION = 110              # COVGRAM_VERSION of the header these ccall signatures mirror
+const ABI_VERSION = 111              # COVGRAM_VERSION of the header these ccall signatures mirror
 dtype_code(::Type{Float32}) = Int32(0); dtype_code(::Type{Float64}) = Int32(1)
 const DevFloat = Union{Float32, Float64}
 

@@ -45,8 +45,8 @@
 extern "C" {
 #endif
 
-#define COVGRAM_VERSION 110 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); a binding checks
-                               covgram_version() against the header it mirrors at load time */
+#define COVGRAM_VERSION 111 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); 111 adds
+                               covgram_cg_step_shifted.  A binding checks covgram_version() against the header it mirrors at load time */
 
 typedef enum covgram_status {
     COVGRAM_OK = 0,
@@ -245,6 +245,11 @@ int covgram_toeplitz_trench(covgram_ctx* ctx, const void* r, int64_t n, void* B,
  * type; the caller sets scal[1] = r . r before the first step; after a step scal[1] = rho' (= |r|^2: the residual test) and
  * scal[0] = the rho it divided by.  The rest of scal is scratch. */
 int covgram_cg_step(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, const void* Ap, void* scal);
+/* The same step for A = G + Diagonal(diag) (the reference's G + sigma^2 I, kept lazy: src/gramian.jl:55-60, src/lazy_linear_algebra.jl:126-133)
+ * after the caller's Ap = G p of the Gramian ALONE: the first launch completes Ap <- Ap + diag .* p in the pass that takes p . Ap, and the
+ * last one leaves |r| = sqrt(rho') in scal[2 + 512] — the diagonal term and the residual norm cost no launch of their own (a graph-replayed
+ * iteration at n = 16384 is launch-bound: tools/cg_rate.py).  diag: n device entries, or NULL (no shift).  scal: 2 + 512 + 1 elements. */
+int covgram_cg_step_shifted(covgram_ctx* ctx, int64_t n, int32_t dtype, void* x, void* r, void* p, void* Ap, void* scal, const void* diag);
 
 /* Y <- alpha * (F_1 ⊗ F_2 ⊗ ... ⊗ F_q) A + beta * Y, standard Kronecker order (F_1 = slowest index).
  * factors[i]: dense rows[i]×cols[i] column-major matrix with leading dimension lds[i] (device or host per loc).

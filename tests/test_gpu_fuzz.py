@@ -77,7 +77,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
             assert e <= tol or np.linalg.norm(ref) < 1e-30, (name, dt.__name__, d, n, alpha, beta, cg.get_info("last_mfma_sym"), e)
             if hasattr(G, "sym_partial_supported") and G.sym_partial_supported():
                 world = int(rng.choice([2, 3, 5]))
-                tot = torch.zeros(n, dtype=torch.float32, device="cuda"); part = torch.empty_like(tot)
+                tot = torch.zeros(n, dtype=Xd.dtype, device="cuda"); part = torch.empty_like(tot)   # (fp32 matrix-core panels or fp64 direct-difference blocks)
                 for r in range(world):
                     G.sym_partial_(part, ad, r, world); tot += part
                 e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))

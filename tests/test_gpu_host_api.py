@@ -215,3 +215,42 @@ def test_cg_step_is_the_cg_recurrence(cg, ctx, dt):
                 assert relerr(got.cpu().numpy(), want) <= tol * 50, (n, step, relerr(got.cpu().numpy(), want))
     f.check(lib.covgram_cg_step(ctx, 0, f.F64, None, None, None, None, None))
     assert lib.covgram_cg_step(ctx, 5, 7, None, None, None, None, None) == f.EINVAL
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_cg_step_shifted_adds_the_diagonal_term_and_leaves_the_norm(cg, ctx, dt):
+    """covgram_cg_step_shifted: the step for A = G + Diagonal(d) (src/gramian.jl:55-60; mul! of the lazy sum,
+    src/lazy_linear_algebra.jl:126-133) given Ap = G p of the Gramian alone — Ap comes back completed (Ap + d .* p), the
+    recurrences use it, and |r| sits in scal[2 + 512]; diag = NULL is the plain step plus the norm."""
+    lib, f = cg._ffi.lib(), cg._ffi
+    DP = lambda t: f._P(t.data_ptr())
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    tol = 2e-6 if dt == np.float32 else 1e-14
+    rng = np.random.default_rng(23)
+    for n in (1, 1000, 70001):
+        for with_diag in (True, False):
+            x, r, p, d = (rng.standard_normal(n).astype(dt) for _ in range(4))
+            d = np.abs(d) + dt(0.1)
+            xd, rd, pd, dd = (torch.from_numpy(v.copy()).cuda() for v in (x, r, p, d))
+            scal = torch.zeros(2 + 512 + 1, dtype=tdt, device="cuda")
+            scal[1] = torch.dot(rd, rd)
+            x64, r64, p64, d64 = (v.astype(np.float64) for v in (x, r, p, d))
+            rho = float(r64 @ r64)
+            for step in range(2):
+                Gp = rng.standard_normal(n).astype(dt)
+                Apd = torch.from_numpy(Gp.copy()).cuda()
+                f.check(lib.covgram_cg_step_shifted(ctx, n, f.F32 if dt == np.float32 else f.F64, DP(xd), DP(rd), DP(pd), DP(Apd), DP(scal),
+                                                    DP(dd) if with_diag else None))
+                torch.cuda.synchronize()
+                Ap64 = Gp.astype(np.float64) + (d64 * p64 if with_diag else 0.0)
+                assert relerr(Apd.cpu().numpy(), Ap64) <= tol * 10
+                alpha = rho / float(p64 @ Ap64)
+                x64 = x64 + alpha * p64; r64 = r64 - alpha * Ap64
+                rho_new = float(r64 @ r64)
+                p64 = r64 + (rho_new / rho) * p64
+                assert abs(float(scal[1]) - rho_new) <= tol * abs(rho_new) * 50
+                assert abs(float(scal[2 + 512]) - np.sqrt(rho_new)) <= tol * np.sqrt(rho_new) * 50
+                rho = rho_new
+                for got, want in ((xd, x64), (rd, r64), (pd, p64)):
+                    assert relerr(got.cpu().numpy(), want) <= tol * 200, (n, step, relerr(got.cpu().numpy(), want))
+    f.check(lib.covgram_cg_step_shifted(ctx, 0, f.F64, None, None, None, None, None, None))
