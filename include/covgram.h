@@ -230,8 +230,9 @@ int covgram_toeplitz_destroy(covgram_toeplitz* T);
  *   covgram_toeplitz_durbin    replaces durbin!(y, r)        src/toeplitz.jl:12-27    y = K_n \ (-r), K_n = SymmetricToeplitz([1, r[1:n-1]]), n = length(r)
  *   covgram_toeplitz_levinson  replaces levinson!(x, r, b)   src/toeplitz.jl:75-98    x = K \ b, n = length(b) = length(r) + 1
  *   covgram_toeplitz_trench    replaces trench!(B, r)        src/toeplitz.jl:52-71    B = inv(K), n x n column-major (ldb), BOTH triangles filled
- * Durbin / Levinson are chains of n - 1 dependent steps: one workgroup walks them (O(n^2 / 1024) thread steps) in ONE launch that cannot be
- * interrupted (n = 16384: 0.13 s; it grows with n^2), so all three return COVGRAM_EUNSUPPORTED above COVGRAM_TOEPLITZ_DIRECT_MAX_N: larger systems are
+ * Durbin / Levinson are chains of n - 1 dependent steps: one workgroup walks them in ONE launch that cannot be interrupted (n <= 16384: state
+ * in registers and LDS, 28 ms at n = 16384 fp64; above: vectors in global memory, ~8 us a step — n = 65536: 0.5 s; it grows with n^2), so all
+ * three return COVGRAM_EUNSUPPORTED above COVGRAM_TOEPLITZ_DIRECT_MAX_N: larger systems are
  * for the circulant-preconditioned CG over covgram_toeplitz_mvm (covgram/solve.py: toeplitz_solve; julia/CovGram.jl: `\`). */
 #define COVGRAM_TOEPLITZ_DIRECT_MAX_N 65536
 int covgram_toeplitz_durbin(covgram_ctx* ctx, const void* r, int64_t n, void* y, int32_t dtype, int32_t loc);

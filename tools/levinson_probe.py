@@ -9,6 +9,7 @@ for n in (1024, 4096, 16384):
     b = torch.randn(n, dtype=torch.float64, device="cuda")
     for _ in range(2): x = cg.levinson(T, b)
     torch.cuda.synchronize(); t0 = time.perf_counter(); x = cg.levinson(T, b); torch.cuda.synchronize(); tl = time.perf_counter() - t0
+    xp, info = cg.toeplitz_solve(T, b); torch.cuda.synchronize()     # (first call: rocFFT plans)
     t0 = time.perf_counter(); xp, info = cg.toeplitz_solve(T, b); torch.cuda.synchronize(); tp = time.perf_counter() - t0
     t0 = time.perf_counter(); y = cg.durbin((T.vc[1:] / T.vc[0]).contiguous()); torch.cuda.synchronize(); td = time.perf_counter() - t0
     res = float(torch.linalg.vector_norm(T @ x - b) / torch.linalg.vector_norm(b))
