@@ -9,6 +9,7 @@
 
 #include "common.hpp"
 #include "pack.hpp"
+#include "exp2_table.hpp"
 
 namespace covgram {
 
@@ -133,6 +134,26 @@ __device__ __forceinline__ double exp2_neg_clamped(double t) {
     return __builtin_ldexp(p, (int)n);
 }
 __device__ __forceinline__ float exp2_neg_clamped(float t) { return __builtin_amdgcn_exp2f(-t); }
+// exp2(-t) in fp64 for t >= 0 by table: -256 t = n + r with n an integer and |r| <= 1/2, exp2(-t) = 2^(n >> 8) T[n & 255] (1 + p(r)),
+// T[j] = 2^(j/256) correctly rounded (exp2_table.hpp: 2 KB, read per lane — L1-resident), p the degree-4 Taylor polynomial of
+// exp(r ln2 / 256) - 1 (0.17 ulp on the interval).  n comes out of the low word of fma(t, -256, 1.5 * 2^52), so the reduction is
+// three instructions and exact (the same product is rounded once to an integer and once not at all).  NaN propagates (the clamp only
+// replaces the high word of t > 1100, by that of 1100: inf and huge t give 2^-1100 = 0).  14 instructions + one load against the
+// 21 of the library's exp2 and the 17 of exp2_neg_clamped; <= 1.3 ulp (table 0.5, final fma 0.5, polynomial 0.2, its evaluation).
+__device__ __forceinline__ double exp2_neg_tab(double t) {
+    const double tc = __hiloint2double(t > 1100.0 ? 0x40913000 : __double2hiint(t), __double2loint(t));
+    const double magic = 0x1.8p52;
+    const double nb = __builtin_fma(tc, -256.0, magic);
+    const int ni = __double2loint(nb);                            // round(-256 t), two's complement
+    const double n = nb - magic;
+    const double r = __builtin_fma(tc, -256.0, -n);
+    const double tj = EXP2_TAB256[ni & 255];
+    double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+    q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
+    q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
+    return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
+}
+__device__ __forceinline__ float exp2_neg_tab(float t) { return __builtin_amdgcn_exp2f(-t); }
 // u^(-a) in fp64 for u >= 1, a > 0 (the rational-quadratic profile: u = 1 + s / (2 alpha); NaN propagates, u = inf gives 0).  The
 // library pow is a general function (sign / zero / infinity cases, ~150 instructions with hipcc's mov + fmac Horner steps); here
 // log2(u) = e + 2 z q(z^2) / ln 2 with u = m 2^e, m in [1/sqrt 2, sqrt 2), z = (m - 1) / (m + 1) (|z| <= 0.1716; no cancellation as
@@ -184,7 +205,7 @@ __device__ __forceinline__ double cg_exp_neg(double r) { return exp2_scaled_nonp
 template <typename T, bool FOLDED>
 struct Phi<COVGRAM_EQ, T, FOLDED> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {
-        if constexpr (FOLDED) return cg_exp2(-s);       // one v_exp_f32 with a free neg modifier
+        if constexpr (FOLDED) return exp2_neg_tab(s);   // fp32: one v_exp_f32 with a free neg modifier; fp64: the table form (14 + 1 load)
         else if constexpr (sizeof(T) == 8) return eq_exp_neg_half(s);
         else return cg_exp2(s * (T)-0.72134752044448170368);   // -log2(e)/2 as a literal: kp.c0 holds the same value, but a kernarg field can be
                                                                    // re-read inside a register-starved loop (grad_mvm.hpp)
@@ -227,7 +248,7 @@ struct Phi<COVGRAM_MATERNP, T, true> {
         // q(r) exp(-r) has no cancellation there and agrees with the truncated series to << eps at the bound (the first term
         // the series drops is r^(2p+1) <= eps^(1 + 1/(2p))), so the value-only kernels skip it: s is a sum of squares >= 0.
         T rr = cg_sqrt(s);
-        T e = exp2_neg_clamped(rr);
+        T e = exp2_neg_tab(rr);
         T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
         return q * e;
     }
