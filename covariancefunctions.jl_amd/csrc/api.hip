@@ -519,6 +519,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     CG_REQUIRE(ctx && key && value, COVGRAM_EINVAL, "NULL argument");
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
+    else if (!strcmp(key, "last_jsplit")) *value = ctx->last_jsplit;
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
@@ -890,6 +891,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         // chunks are multiples of 64 columns (whole packed pairs); small problems split finer than the 512-column
         // inner accumulation block so that they still expose thousands of waves
         choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
+        ctx->last_jsplit = jsplit;
         DenseArgs da;
         da.C = Cn;
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;

@@ -191,6 +191,7 @@ struct covgram_ctx {
     void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix cores, 3 wide rows, 4 factored dot product X (Y' a)
+    int64_t last_jsplit = 0;     // column split of the last lane-per-row dense launch (tools)
     int32_t* sym_map = nullptr;  // symmetric kernel: device list of its (local panel, chunk) workgroups, keyed by sym_key
     size_t sym_map_cap = 0, sym_map_len = 0;
     int64_t sym_key[4] = {-1, -1, -1, -1};

@@ -154,6 +154,22 @@ __device__ __forceinline__ double exp2_neg_tab(double t) {
     return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
 }
 __device__ __forceinline__ float exp2_neg_tab(float t) { return __builtin_amdgcn_exp2f(-t); }
+// exp(-r) in fp64 for r >= 0 on the same table: -256 log2(e) = chi + clo, n from the low word of fma(r, chi, 1.5 * 2^52), the
+// reduced argument fma(r, chi, -n) + r clo (the product never rounded).  The clamp is at r = 763 (exp(-763) < 2^-1100 = 0).
+__device__ __forceinline__ double exp_neg_tab(double r) {
+    const double rc = __hiloint2double(r > 763.0 ? 0x4087D800 : __double2hiint(r), __double2loint(r));
+    const double magic = 0x1.8p52, chi = -0x1.71547652b82fep+8, clo = -0x1.777d0ffda0d24p-48;
+    const double nb = __builtin_fma(rc, chi, magic);
+    const int ni = __double2loint(nb);
+    const double n = nb - magic;
+    const double f = __builtin_fma(rc, clo, __builtin_fma(rc, chi, -n));
+    const double tj = EXP2_TAB256[ni & 255];
+    double q = __builtin_fma(f, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+    q = __builtin_fma(q, f, 0x1.ebfbdff82c58fp-19);
+    q = __builtin_fma(q, f, 0x1.62e42fefa39efp-9);
+    return __builtin_ldexp(__builtin_fma(tj, f * q, tj), ni >> 8);
+}
+__device__ __forceinline__ float exp_neg_tab(float r) { return __builtin_amdgcn_exp2f(r * -1.44269504088896340736f); }
 // u^(-a) in fp64 for u >= 1, a > 0 (the rational-quadratic profile: u = 1 + s / (2 alpha); NaN propagates, u = inf gives 0).  The
 // library pow is a general function (sign / zero / infinity cases, ~150 instructions with hipcc's mov + fmac Horner steps); here
 // log2(u) = e + 2 z q(z^2) / ln 2 with u = m 2^e, m in [1/sqrt 2, sqrt 2), z = (m - 1) / (m + 1) (|z| <= 0.1716; no cancellation as
@@ -213,7 +229,7 @@ struct Phi<COVGRAM_EQ, T, FOLDED> {
 };
 template <typename T, bool F>
 struct Phi<COVGRAM_EXP, T, F> {
-    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return cg_exp(-cg_sqrt(s)); }   // (cg_exp_neg measured 6 % slower in the dense fp64 kernel, whose constants sit in SGPRs)
+    static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return exp_neg_tab(cg_sqrt(s)); }   // (fp64: the table form, 15 + 1 load; the polynomial cg_exp_neg measured 6 % slower than the library exp here)
 };
 template <typename T, bool F>
 struct Phi<COVGRAM_RQ, T, F> {
