@@ -1,5 +1,5 @@
 """Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).
-usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32|c1|f64sym|f64all|kron64|kron32 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
+usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32|c1|f64sym|f64all|f64eq3|kron64|kron32 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -37,6 +37,12 @@ elif which in ("f64sym", "f64all"):             # fp64 gramian(k, x) * a, Matern
     X = torch.from_numpy(np.random.default_rng(5).standard_normal((n, d)) * 0.3).cuda(); a = torch.from_numpy(rng.standard_normal(n)).cuda()
     cg.set_option("dense_sym", 1 if which == "f64sym" else 0)
     G = cg.gramian(cg.MaternP(2), X); y = torch.empty(n, dtype=torch.float64, device="cuda")
+    for _ in range(K): G.mul_(y, a)
+elif which == "f64eq3":                          # fp64 EQ, d = 3, n = 32768 against a second point set: the general lane-per-row kernel
+    n = 32768
+    X = torch.from_numpy(np.random.default_rng(5).standard_normal((n, 3))).cuda(); Y = torch.from_numpy(np.random.default_rng(6).standard_normal((n, 3))).cuda()
+    a = torch.from_numpy(rng.standard_normal(n)).cuda()
+    G = cg.gramian(cg.EQ(), X, Y); y = torch.empty(n, dtype=torch.float64, device="cuda")
     for _ in range(K): G.mul_(y, a)
 elif which in ("kron64", "kron32"):             # README.md:205-210: 128^3 grid, three 128 x 128 factors
     dt = torch.float64 if which == "kron64" else torch.float32
