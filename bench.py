@@ -191,7 +191,7 @@ def other_configs(cg, dev):
             "reference_published_s": 0.584813, "reference_source": "README.md:26-38 (CPU unstated)",
             "roofline": {"bound": "valu_fp64", "achieved": float(n) * n * (3 * d + 3) / (ms_all * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s",
                          "frac": float(n) * n * (3 * d + 3) / (ms_all * 1e-3) * 1e-12 / 78.6,
-                         "note": "frac prices the ALL-entries time with the reference's 3d+3 flops per pair; the fp64 MaternP pair body is 41 instructions (sqrt 11, exp2 17), DESIGN.md 3.1"}}
+                         "note": "frac prices the ALL-entries time with the reference's 3d+3 flops per pair; the fp64 MaternP pair body is 38 instructions (sqrt 11, exp2 by table 14 + one load), DESIGN.md 3.1"}}
     except Exception as e:   # reporting only: never fail the contract line for it
         cg.set_option("dense_sym", -1)
         out["README_MaternP2_n16384_f64"] = {"what": "failed", "error": str(e)[:200]}
