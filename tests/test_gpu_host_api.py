@@ -144,6 +144,45 @@ def test_host_pointer_toeplitz_kron_lowrank(cg, oracle, ctx):
     assert relerr(y, oracle.lowrank_mul(y0, U, V, a, 2.0, 0.25)) <= 1e-12
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_host_pointer_direct_toeplitz_solvers(cg, oracle, ctx, dt):
+    """covgram_toeplitz_durbin / _levinson / _trench with HOST pointers — the form julia/CovGram.jl's `\\`, durbin!, levinson!, trench!
+    (src/toeplitz.jl:12-111) use — on the on-chip kernel (n <= 16384), on the global-memory kernel above it, at n = 1, and above the
+    size cap (COVGRAM_EUNSUPPORTED, nothing launched)."""
+    lib, f = cg._ffi.lib(), cg._ffi
+    code = f.F64 if dt == np.float64 else f.F32
+    tol = 1e-9 if dt == np.float64 else 2e-3
+    rng = np.random.default_rng(77)
+    for m in (1, 2, 300, 16384, 16500):
+        vc = (1.5 * (np.arange(m) == 0) + np.exp(-np.abs(np.linspace(0.0, 3.0, m)))).astype(np.float64)   # diagonal 2.5: well conditioned
+        r = (vc[1:] / vc[0]).astype(dt)
+        b = rng.standard_normal(m).astype(dt)
+        x = np.full(m, np.nan, dtype=dt)
+        f.check(lib.covgram_toeplitz_levinson(ctx, P(r) if m > 1 else None, P(b), m, P(x), code, f.HOST))
+        r64, b64 = r.astype(np.float64), b.astype(np.float64)
+        if m <= 300:
+            K = np.array([[1.0 if i == j else r64[abs(i - j) - 1] for j in range(m)] for i in range(m)])
+            assert relerr(x, np.linalg.solve(K, b64)) <= tol, ("levinson", m)
+        else:                                                       # residual through the FFT MVM of the same matrix
+            T = cg.SymmetricToeplitz(torch.from_numpy(np.concatenate([[1.0], r64])).cuda())
+            assert relerr((T @ torch.from_numpy(x.astype(np.float64)).cuda()).cpu().numpy(), b64) <= tol, ("levinson", m)
+        if m > 1:
+            y = np.full(m - 1, np.nan, dtype=dt)
+            f.check(lib.covgram_toeplitz_durbin(ctx, P(r), m - 1, P(y), code, f.HOST))
+            assert relerr(y, oracle.durbin(r64)) <= tol, ("durbin", m)
+        if m <= 300:
+            B = np.full((m, m + 1), np.nan, dtype=dt)               # column-major with ldb = m + 1: as a (m, m + 1) C array of columns
+            Bc = np.zeros((m, m + 1), dtype=dt)
+            f.check(lib.covgram_toeplitz_trench(ctx, P(r) if m > 1 else None, m, P(Bc), m + 1, code, f.HOST))
+            Binv = Bc[:, :m].T                                       # entry (i, j) at i + j * ldb
+            assert relerr(Binv @ K, np.eye(m)) <= tol * 10, ("trench", m)
+    big = int(lib.covgram_version() and 65536) + 1
+    z = np.zeros(8, dtype=np.float64)
+    assert lib.covgram_toeplitz_levinson(ctx, P(z), P(z), big, P(z), f.F64, f.HOST) == f.EUNSUPPORTED
+    assert lib.covgram_toeplitz_durbin(ctx, P(z), big, P(z), f.F64, f.HOST) == f.EUNSUPPORTED
+    assert lib.covgram_toeplitz_levinson(ctx, P(z), P(z), 0, P(z), f.F64, f.HOST) == f.EINVAL
+
+
 def test_empty_and_degenerate_inputs(cg, oracle):
     """Edge cases the reference's loops accept: no columns (y <- beta y), no rows, one point, many RHS, d at the boundaries."""
     dev = "cuda"
