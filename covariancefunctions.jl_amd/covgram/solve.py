@@ -3,8 +3,9 @@
 The reference solves lazy (block) Gramians with IterativeSolvers.cg! (src/gramian.jl:229-238,
 src/lazy_linear_algebra.jl:135-144).  Here every MVM is a device kernel of libcovgram and all vectors stay resident on
 the GPU.  Without a preconditioner the O(n) vector updates and the two dot products of an iteration are ONE library call
-(covgram_cg_step: three launches, scalars on the device) — as torch ops they were eleven small launches, 45 us next to a
-40 us MVM at n = 16384; with a preconditioner they stay torch ops on the same stream.  One host synchronisation per
+(covgram_cg_step_shifted: one launch for vectors that fit a workgroup's registers, three above, scalars on the device; the
+diagonal term of G + σ²I and ‖r‖ ride along) — as torch ops they were eleven small launches, 45 us next to a 40 us MVM at
+n = 16384; with a preconditioner they stay torch ops on the same stream.  One host synchronisation per
 iteration (the convergence test), none inside the MVM.
 """
 from __future__ import annotations

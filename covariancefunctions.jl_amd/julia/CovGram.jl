@@ -342,7 +342,8 @@ function device_trench(r::Vector{T}) where {T <: DevFloat}
 end
 device_levinson(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = device_levinson(A.vc[2:end] ./ A.vc[1], b) ./ A.vc[1]
 device_trench(A::DeviceToeplitz) = Symmetric(parent(device_trench(A.vc[2:end] ./ A.vc[1])) ./ A.vc[1])
-# `\`: Levinson is ONE launch of n - 1 dependent O(n) steps on one workgroup (0.13 s at n = 16384, growing with n²; the library refuses
+# `\`: Levinson is ONE launch of n - 1 dependent O(n) steps on one workgroup (n <= 16384: state in registers and LDS, 28 ms at n = 16384
+# fp64; above that the vectors live in global memory, ~8 us a step, growing with n²; the library refuses
 # it above COVGRAM_TOEPLITZ_DIRECT_MAX_N = 65536), so it serves the small systems only; larger ones go to conjugate gradients over the FFT
 # MVM (`mul!` above: covgram_toeplitz_mvm), the reference's own solver for lazy operators (src/gramian.jl:229-238).
 const LEVINSON_MAX_N = 16384
