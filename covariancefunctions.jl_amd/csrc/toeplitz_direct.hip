@@ -47,15 +47,14 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // fixed-order sum of two per-thread values over the workgroup; `buf` alternates between two halves so one barrier suffices
-template <typename T, int NWAVES = LV_THREADS / 64>
-__device__ __forceinline__ void block_sum2(T& s0, T& s1, T (*red)[2][16], int parity) {
+template <typename T>
+__device__ __forceinline__ void block_sum2(T& s0, T& s1, T (*red)[2][16], int parity, int nwaves = LV_THREADS / 64) {
     s0 = wave_sum(s0); s1 = wave_sum(s1);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[parity][0][w] = s0; red[parity][1][w] = s1; }
     __syncthreads();
     T t0[2] = {0, 0}, t1[2] = {0, 0};
-#pragma unroll
-    for (int q = 0; q < NWAVES; ++q) { t0[q & 1] += red[parity][0][q]; t1[q & 1] += red[parity][1][q]; }
+    for (int q = 0; q < nwaves; ++q) { t0[q & 1] += red[parity][0][q]; t1[q & 1] += red[parity][1][q]; }
     s0 = t0[0] + t0[1]; s1 = t1[0] + t1[1];
 }
 
@@ -97,8 +96,8 @@ __global__ __launch_bounds__(LV_THREADS) void levinson_kernel(const T* __restric
 // round trips, not its flops.  Layout:
 //   * thread t OWNS the E entries e = E t .. E t + E - 1 of x and y, in registers; an LDS copy of y (16384 fp64 entries + 1 pad per
 //     E = 132 KB of the CU's 160 KB; the pad makes the lane stride E + 1 entries: conflict-free) is what every thread reads its
-//     PARTNER entries y[k-1-e] from.  fp32: 1024 threads x 16 entries; fp64: 512 threads x 32 (x, y and the sliding r are 3 E
-//     values per thread: 192 of the 256 registers a thread has at 2 waves per SIMD);
+//     PARTNER entries y[k-1-e] from.  E by size and type, see the geometry note at the kernel (n = 16384 fp64 Levinson: 512 threads
+//     x 32 — x, y and the sliding r are 3 E values per thread: 192 of the 256 registers a thread has at 2 waves per SIMD);
 //   * the reversed dot products are taken over the OWN entries, sum_e x[e] r[k-1-e]: the r operand slides by one entry per step,
 //     so each thread keeps rs[e] = r[k-1-e] in registers and shifts it (register renames within the thread, one lane shuffle
 //     for its first entry, one LDS word per wave for the wave boundary, r[k] enters at e = 0).  The sums touch no memory at all,
@@ -117,16 +116,21 @@ __device__ int lv_diag_step;
 #else
 #define LV_STAMP(i) do { } while (0)
 #endif
-template <typename T> struct LrGeo { static constexpr int E = sizeof(T) == 8 ? 32 : 16, THREADS = LR_MAX_N / E, LOG_E = sizeof(T) == 8 ? 5 : 4; };
-
-template <typename T, bool SOLVE>
-__global__ __launch_bounds__(LrGeo<T>::THREADS) void levinson_reg_kernel(const T* __restrict__ r, const T* __restrict__ b, T* __restrict__ xout,
-                                                                         T* __restrict__ yout, int n) {
-    constexpr int LR_E = LrGeo<T>::E, LR_CH = 4, LOG_E = LrGeo<T>::LOG_E, NWAVES = LrGeo<T>::THREADS / 64;
+// Geometry: E = 2^LOG_E entries per thread, up to MAXT threads (capacity MAXT * E entries; the launch uses ceil(n / E) threads, whole
+// waves).  A thread's entries are a serial stream, so E is as small as the size allows: 8 for n <= 8192 (1024 threads: n = 4096 fp64
+// 5.5 -> 4.2 ms, n = 1024 1.47 -> 0.93 against E = 32); above that 16 (fp32, 1024 threads) or 32 on 512 threads (fp64: the 3 E fp64
+// values per thread of Levinson need the 256 registers of two waves per SIMD; Durbin measured the same at 16 x 1024: all SIMDs are busy
+// at these sizes either way).
+template <typename T, bool SOLVE, int LOG_E, int MAXT>
+__global__ __launch_bounds__(MAXT) void levinson_reg_kernel(const T* __restrict__ r, const T* __restrict__ b, T* __restrict__ xout,
+                                                            T* __restrict__ yout, int n) {
+    constexpr int LR_E = 1 << LOG_E, LR_CH = 4, LR_CAP = MAXT * LR_E;
+    static_assert(LR_CAP <= LR_MAX_N && MAXT <= 1024, "geometry");
+    const int nwaves = (int)(blockDim.x >> 6);
     // LDS copy of y: entry e at slot e + (e >> LOG_E), behind a prefix that the same slot formula maps the entries -1 .. -E to:
     // slot -2 (entry -1) holds 1, the others 0 — see the update
     constexpr int LR_PRE = LR_E + 2;
-    __shared__ T Ybuf[LR_PRE + LR_MAX_N + LR_MAX_N / LR_E];
+    __shared__ T Ybuf[LR_PRE + LR_CAP + LR_CAP / LR_E];
     T* const Y = Ybuf + LR_PRE;
     __shared__ T red[2][2][16];
     __shared__ T edge[16];
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(LrGeo<T>::THREADS) void levinson_reg_kernel(const T
         }
         const T ibeta = (T)1 / beta;                               // off the chain: beta is known before the sums are
         LV_STAMP(1);
-        block_sum2<T, NWAVES>(sx, sy, red, k & 1);
+        block_sum2<T>(sx, sy, red, k & 1, nwaves);
         LV_STAMP(2);
         // (b[k] - sx) / beta and -(r[k] + sy) / beta of :20, :88 as products with 1 / beta: a division here is ~30 dependent
         // instructions on the step's critical path
@@ -287,9 +291,23 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(T* __restrict__ B, in
     }
 }
 
+// the on-chip kernel at the geometry of the size (n <= LR_MAX_N)
+template <typename T, bool SOLVE>
+static void levinson_reg_launch(hipStream_t st, const T* r, const T* b, T* x, T* y, int64_t n) {
+    auto go = [&](auto loge, auto maxt) {
+        constexpr int LOG_E = decltype(loge)::value, MAXT = decltype(maxt)::value;
+        const unsigned threads = (unsigned)std::min<int64_t>(MAXT, (((n + (1 << LOG_E) - 1) >> LOG_E) + 63) / 64 * 64);
+        hipLaunchKernelGGL((levinson_reg_kernel<T, SOLVE, LOG_E, MAXT>), dim3(1), dim3(threads), 0, st, r, b, x, y, (int)n);
+    };
+    using std::integral_constant;
+    if (n <= 8192) go(integral_constant<int, 3>{}, integral_constant<int, 1024>{});
+    else if constexpr (sizeof(T) == 8) go(integral_constant<int, 5>{}, integral_constant<int, 512>{});
+    else go(integral_constant<int, 4>{}, integral_constant<int, 1024>{});
+}
+
 template <typename T>
 static int durbin_run(covgram_ctx* ctx, const T* r, int64_t n, T* y) {
-    if (n <= LR_MAX_N) hipLaunchKernelGGL((levinson_reg_kernel<T, false>), dim3(1), dim3(LrGeo<T>::THREADS), 0, ctx->stream, r, (const T*)nullptr, (T*)nullptr, y, (int)n);
+    if (n <= LR_MAX_N) levinson_reg_launch<T, false>(ctx->stream, r, (const T*)nullptr, (T*)nullptr, y, n);
     else hipLaunchKernelGGL((levinson_kernel<T, false>), dim3(1), dim3(LV_THREADS), 0, ctx->stream, r, (const T*)nullptr, (T*)nullptr, y, n);
     return COVGRAM_OK;
 }
@@ -346,7 +364,7 @@ int covgram_toeplitz_levinson(covgram_ctx* ctx, const void* r, const void* b, in
     void* xd = loc == COVGRAM_DEVICE ? x : (void*)p;
 #define CG_LEVINSON(T)                                                                                                                \
     {                                                                                                                                  \
-        if (n <= LR_MAX_N) hipLaunchKernelGGL((levinson_reg_kernel<T, true>), dim3(1), dim3(LrGeo<T>::THREADS), 0, ctx->stream, (const T*)rd, (const T*)bd, (T*)xd, (T*)yw, (int)n); \
+        if (n <= LR_MAX_N) levinson_reg_launch<T, true>(ctx->stream, (const T*)rd, (const T*)bd, (T*)xd, (T*)yw, n);                  \
         else hipLaunchKernelGGL((levinson_kernel<T, true>), dim3(1), dim3(LV_THREADS), 0, ctx->stream, (const T*)rd, (const T*)bd, (T*)xd, (T*)yw, n); \
     }
     if (dtype == COVGRAM_F32) CG_LEVINSON(float) else CG_LEVINSON(double)
