@@ -35,6 +35,17 @@ __device__ __forceinline__ double cg_sqrt(double x) {
     g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
     return __builtin_amdgcn_class(y, 0x264) ? x : g;               // seed inf (x = 0) or 0 (x = inf): the argument itself (g is NaN there)
 }
+// the same for a STRICTLY POSITIVE argument (or NaN / inf, which come out as NaN): no class test.  For callers that add a tiny constant
+// to a sum of squares and whose value at inf is NaN anyway (MaternP: q(inf) exp(-inf) = inf * 0, as in the reference)
+__device__ __forceinline__ float cg_sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double cg_sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
 __device__ __forceinline__ float cg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double cg_rcp(double x) {
     const double y = __builtin_amdgcn_rcp(x);
@@ -140,8 +151,10 @@ __device__ __forceinline__ float exp2_neg_clamped(float t) { return __builtin_am
 // three instructions and exact (the same product is rounded once to an integer and once not at all).  NaN propagates (the clamp only
 // replaces the high word of t > 1100, by that of 1100: inf and huge t give 2^-1100 = 0).  14 instructions + one load against the
 // 21 of the library's exp2 and the 17 of exp2_neg_clamped; <= 1.3 ulp (table 0.5, final fma 0.5, polynomial 0.2, its evaluation).
+template <bool KEEP_NAN = true>
 __device__ __forceinline__ double exp2_neg_tab(double t) {
-    const double tc = __hiloint2double(t > 1100.0 ? 0x40913000 : __double2hiint(t), __double2loint(t));
+    // KEEP_NAN = false: one v_min_f64 (a NaN argument gives 0) for callers whose NaN travels in another factor (MaternP: q(NaN) * 0 = NaN)
+    const double tc = KEEP_NAN ? __hiloint2double(t > 1100.0 ? 0x40913000 : __double2hiint(t), __double2loint(t)) : __builtin_fmin(t, 1100.0);
     const double magic = 0x1.8p52;
     const double nb = __builtin_fma(tc, -256.0, magic);
     const int ni = __double2loint(nb);                            // round(-256 t), two's complement
@@ -153,6 +166,7 @@ __device__ __forceinline__ double exp2_neg_tab(double t) {
     q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
     return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
 }
+template <bool KEEP_NAN = true>
 __device__ __forceinline__ float exp2_neg_tab(float t) { return __builtin_amdgcn_exp2f(-t); }
 // exp(-r) in fp64 for r >= 0 on the same table: -256 log2(e) = chi + clo, n from the low word of fma(r, chi, 1.5 * 2^52), the
 // reduced argument fma(r, chi, -n) + r clo (the product never rounded).  The clamp is at r = 763 (exp(-763) < 2^-1100 = 0).
@@ -263,8 +277,11 @@ struct Phi<COVGRAM_MATERNP, T, true> {
         // The reference's Taylor branch below eps^(1/p) (src/stationary.jl:135-146) exists for the DERIVATIVES at 0; the value
         // q(r) exp(-r) has no cancellation there and agrees with the truncated series to << eps at the bound (the first term
         // the series drops is r^(2p+1) <= eps^(1 + 1/(2p))), so the value-only kernels skip it: s is a sum of squares >= 0.
-        T rr = cg_sqrt(s);
-        T e = exp2_neg_tab(rr);
+        // fp64: sqrt(s + 2^-1000) without the class test of cg_sqrt (s = 0 gives r = 2^-500: q(r) exp2(-r) = 1 exactly; any s the
+        // addition changes is below 2^-947, where the value is 1 to far below eps; s = inf / NaN give NaN as q(inf) * 0 does)
+        T rr;
+        if constexpr (sizeof(T) == 8) rr = cg_sqrt_pos(s + (T)0x1p-1000); else rr = cg_sqrt(s);
+        T e = exp2_neg_tab<false>(rr);
         T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
         return q * e;
     }
