@@ -35,6 +35,23 @@ constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, s
 // Dimensions are consumed in chunks of one 64-byte scalar load; for rows wider than a chunk a scheduling
 // barrier after each chunk keeps hipcc from hoisting every s_load of a column group to the top, which would
 // overflow the ~100 usable SGPRs and spill them through v_writelane.
+// The profile of the dense fp64 kernels: EQ / MaternP / Exponential read the exponential's table from the LDS copy their kernels
+// fill first (profiles.hpp: exp_tab_lds); everything else is phi_value.
+template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP);
+template <int FAM, typename T, bool POW>
+__device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::type& kp) {
+    if constexpr (sizeof(T) == 8 && dense_lds_tab<FAM>) {
+        T v;
+        if constexpr (FAM == COVGRAM_EQ) v = exp2_neg_tab(s, exp_tab_lds());
+        else if constexpr (FAM == COVGRAM_MATERNP) v = Phi<COVGRAM_MATERNP, T, true>::eval_tab(s, kp, exp_tab_lds());
+        else v = exp_neg_tab(cg_sqrt(s), exp_tab_lds());
+        if constexpr (POW) v = ipow(v, kp.power);
+        return v;
+    } else {
+        return phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), POW>(s, kp);
+    }
+}
+
 template <typename T, int FAM, int D, int NR, int R, bool POW, bool ISO>
 struct DenseBody {
     using PK = Pk<T>;
@@ -106,7 +123,7 @@ struct DenseBody {
         for (int c = 0; c < NR; ++c) aj[c] = p[D + c];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const V kv = PK::map(s[r], [&](T sv) { return phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), POW>(sv, kp); });
+            const V kv = PK::map(s[r], [&](T sv) { return dense_phi<FAM, T, POW>(sv, kp); });
 #pragma unroll
             for (int c = 0; c < NR; ++c) acc[r][c] = PK::fma(aj[c], kv, acc[r][c]);
         }
@@ -122,6 +139,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     // sides before the pre-scale: (x - c) gamma - (y - c) gamma keeps the rounding of the scaled coordinates relative to the
     // cloud's extent, not to its distance from the origin (the reference subtracts first and scales after, src/util.jl:40-47).
     constexpr bool ISO = fam_is_iso<FAM>;
+    if constexpr (sizeof(T) == 8 && dense_lds_tab<FAM>) exp_tab_lds_fill();
     using Body = DenseBody<T, FAM, D, NR, R, POW, ISO>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -316,6 +334,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
     const typename ParamsOf<FAM, double>::type kp0, int32_t rb_first, int32_t rb_stride) {
     using T = double;
     constexpr bool ISO = fam_is_iso<FAM>;
+    if constexpr (dense_lds_tab<FAM>) exp_tab_lds_fill();          // before the early return below: every thread reaches the barrier
     using Body = DenseBody<T, FAM, D, 1, 1, false, ISO>;
     constexpr int S = D + 1;
     const int lane = threadIdx.x;
@@ -349,7 +368,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
                 for (int u = 0; u < cnt; ++u, p += S) {
                     T sv[1];
                     Body::dist(p, x, sv);
-                    const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                    const T kv = dense_phi<FAM, T, false>(sv[0], kp);
                     acc = cg_fma(p[D], kv, acc);
                 }
             } else {
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
                 auto column = [&](const T* __restrict__ pc, int u) {
                     T sv[1];
                     Body::dist(pc, x, sv);
-                    const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                    const T kv = dense_phi<FAM, T, false>(sv[0], kp);
                     acc = cg_fma(pc[D], kv, acc);
                     const T c = wave_sum_lane63_f64(ai * kv);
                     if (lane == 63) cdst[u] = c;                     // one 8-byte store per column; the 64 of a block merge in L2
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
                         for (int q = 0; q < 4; ++q) {
                             T sv[1];
                             Body::dist(p + q * S, x, sv);
-                            const T kv = phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), false>(sv[0], kp);
+                            const T kv = dense_phi<FAM, T, false>(sv[0], kp);
                             acc = cg_fma(p[q * S + D], kv, acc);
                             c[q] = ai * kv;
                         }

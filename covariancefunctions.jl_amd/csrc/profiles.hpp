@@ -151,39 +151,55 @@ __device__ __forceinline__ float exp2_neg_clamped(float t) { return __builtin_am
 // three instructions and exact (the same product is rounded once to an integer and once not at all).  NaN propagates (the clamp only
 // replaces the high word of t > 1100, by that of 1100: inf and huge t give 2^-1100 = 0).  14 instructions + one load against the
 // 21 of the library's exp2 and the 17 of exp2_neg_clamped; <= 1.3 ulp (table 0.5, final fma 0.5, polynomial 0.2, its evaluation).
+// `tab`: the table in global memory (read through L1) or a copy in LDS (exp_tab_lds, for kernels that fill it: a per-lane gather of
+// 8-byte entries from 16 cache lines costs the CU's one texture unit ~16 clocks a wave — the bound of the dense fp64 loop once its
+// arithmetic was down to 20 instructions per pair; the same gather from LDS is a few clocks)
+__device__ __forceinline__ double* exp_tab_lds() { __shared__ double t[256]; return t; }
+// (a kernel that evaluates through the LDS copy calls this first, all threads)
+__device__ __forceinline__ void exp_tab_lds_fill() {
+    double* t = exp_tab_lds();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) t[i] = EXP2_TAB256[i];
+    __syncthreads();
+}
 template <bool KEEP_NAN = true>
-__device__ __forceinline__ double exp2_neg_tab(double t) {
+__device__ __forceinline__ double exp2_neg_tab(double t, const double* __restrict__ tab = EXP2_TAB256) {
     // KEEP_NAN = false: one v_min_f64 (a NaN argument gives 0) for callers whose NaN travels in another factor (MaternP: q(NaN) * 0 = NaN)
     const double tc = KEEP_NAN ? __hiloint2double(t > 1100.0 ? 0x40913000 : __double2hiint(t), __double2loint(t)) : __builtin_fmin(t, 1100.0);
-    const double magic = 0x1.8p52;
-    const double nb = __builtin_fma(tc, -256.0, magic);
+    // opaque registers: with literals the compiler forms a two-address v_fmac and re-materialises the addend per call (two v_mov)
+    double magic = 0x1.8p52, c256 = -256.0;
+    asm("" : "+v"(magic));
+    asm("" : "+s"(c256));
+    const double nb = __builtin_fma(tc, c256, magic);
     const int ni = __double2loint(nb);                            // round(-256 t), two's complement
     const double n = nb - magic;
-    const double r = __builtin_fma(tc, -256.0, -n);
-    const double tj = EXP2_TAB256[ni & 255];
+    const double r = __builtin_fma(tc, c256, -n);
+    const double tj = tab[ni & 255];
     double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
     q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
     q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
     return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
 }
 template <bool KEEP_NAN = true>
-__device__ __forceinline__ float exp2_neg_tab(float t) { return __builtin_amdgcn_exp2f(-t); }
+__device__ __forceinline__ float exp2_neg_tab(float t, const double* = nullptr) { return __builtin_amdgcn_exp2f(-t); }
 // exp(-r) in fp64 for r >= 0 on the same table: -256 log2(e) = chi + clo, n from the low word of fma(r, chi, 1.5 * 2^52), the
 // reduced argument fma(r, chi, -n) + r clo (the product never rounded).  The clamp is at r = 763 (exp(-763) < 2^-1100 = 0).
-__device__ __forceinline__ double exp_neg_tab(double r) {
+__device__ __forceinline__ double exp_neg_tab(double r, const double* __restrict__ tab = EXP2_TAB256) {
     const double rc = __hiloint2double(r > 763.0 ? 0x4087D800 : __double2hiint(r), __double2loint(r));
-    const double magic = 0x1.8p52, chi = -0x1.71547652b82fep+8, clo = -0x1.777d0ffda0d24p-48;
+    const double clo = -0x1.777d0ffda0d24p-48;
+    double magic = 0x1.8p52, chi = -0x1.71547652b82fep+8;
+    asm("" : "+v"(magic));
+    asm("" : "+s"(chi));
     const double nb = __builtin_fma(rc, chi, magic);
     const int ni = __double2loint(nb);
     const double n = nb - magic;
     const double f = __builtin_fma(rc, clo, __builtin_fma(rc, chi, -n));
-    const double tj = EXP2_TAB256[ni & 255];
+    const double tj = tab[ni & 255];
     double q = __builtin_fma(f, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
     q = __builtin_fma(q, f, 0x1.ebfbdff82c58fp-19);
     q = __builtin_fma(q, f, 0x1.62e42fefa39efp-9);
     return __builtin_ldexp(__builtin_fma(tj, f * q, tj), ni >> 8);
 }
-__device__ __forceinline__ float exp_neg_tab(float r) { return __builtin_amdgcn_exp2f(r * -1.44269504088896340736f); }
+__device__ __forceinline__ float exp_neg_tab(float r, const double* = nullptr) { return __builtin_amdgcn_exp2f(r * -1.44269504088896340736f); }
 // u^(-a) in fp64 for u >= 1, a > 0 (the rational-quadratic profile: u = 1 + s / (2 alpha); NaN propagates, u = inf gives 0).  The
 // library pow is a general function (sign / zero / infinity cases, ~150 instructions with hipcc's mov + fmac Horner steps); here
 // log2(u) = e + 2 z q(z^2) / ln 2 with u = m 2^e, m in [1/sqrt 2, sqrt 2), z = (m - 1) / (m + 1) (|z| <= 0.1716; no cancellation as
@@ -279,9 +295,12 @@ struct Phi<COVGRAM_MATERNP, T, true> {
         // the series drops is r^(2p+1) <= eps^(1 + 1/(2p))), so the value-only kernels skip it: s is a sum of squares >= 0.
         // fp64: sqrt(s + 2^-1000) without the class test of cg_sqrt (s = 0 gives r = 2^-500: q(r) exp2(-r) = 1 exactly; any s the
         // addition changes is below 2^-947, where the value is 1 to far below eps; s = inf / NaN give NaN as q(inf) * 0 does)
+        return eval_tab(s, kp, EXP2_TAB256);
+    }
+    static __device__ __forceinline__ T eval_tab(T s, const KParams<T>& kp, const double* __restrict__ tab) {
         T rr;
         if constexpr (sizeof(T) == 8) rr = cg_sqrt_pos(s + (T)0x1p-1000); else rr = cg_sqrt(s);
-        T e = exp2_neg_tab<false>(rr);
+        T e = exp2_neg_tab<false>(rr, tab);
         T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
         return q * e;
     }
