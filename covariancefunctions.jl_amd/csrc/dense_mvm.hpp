@@ -38,12 +38,14 @@ constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, s
 // The profile of the dense fp64 kernels: EQ / MaternP / Exponential read the exponential's table from the LDS copy their kernels
 // fill first (profiles.hpp: exp_tab_lds); everything else is phi_value.
 template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP);
+// what the sum of squares starts from: 2^-1000 for the fp64 MaternP profile (its square root then needs no zero test: profiles.hpp), else 0
+template <int FAM, typename T> constexpr T dense_s0 = (FAM == COVGRAM_MATERNP && sizeof(T) == 8) ? (T)0x1p-1000 : (T)0;
 template <int FAM, typename T, bool POW>
 __device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::type& kp) {
     if constexpr (sizeof(T) == 8 && dense_lds_tab<FAM>) {
         T v;
         if constexpr (FAM == COVGRAM_EQ) v = exp2_neg_tab(s, exp_tab_lds());
-        else if constexpr (FAM == COVGRAM_MATERNP) v = Phi<COVGRAM_MATERNP, T, true>::eval_tab(s, kp, exp_tab_lds());
+        else if constexpr (FAM == COVGRAM_MATERNP) v = Phi<COVGRAM_MATERNP, T, true>::template eval_tab<true>(s, kp, exp_tab_lds());   // s starts from 2^-1000: dense_s0
         else v = exp_neg_tab(cg_sqrt(s), exp_tab_lds());
         if constexpr (POW) v = ipow(v, kp.power);
         return v;
@@ -70,7 +72,8 @@ struct DenseBody {
                     const V xl = PK::splat(x[r][l]);
                     if constexpr (ISO) {
                         const V dl = xl - yl;
-                        s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
+                        if constexpr (dense_s0<FAM, T> != (T)0) s[r] = PK::fma(dl, dl, (l == 0) ? PK::splat(dense_s0<FAM, T>) : s[r]);
+                        else s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
                     } else {
                         s[r] = (l == 0) ? xl * yl : PK::fma(xl, yl, s[r]);
                     }
@@ -110,7 +113,8 @@ struct DenseBody {
                     const V xl = PK::splat(x[r][l]);
                     if constexpr (ISO) {
                         const V dl = xl - yl;
-                        s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
+                        if constexpr (dense_s0<FAM, T> != (T)0) s[r] = PK::fma(dl, dl, (l == 0) ? PK::splat(dense_s0<FAM, T>) : s[r]);
+                        else s[r] = (l == 0) ? dl * dl : PK::fma(dl, dl, s[r]);
                     } else {
                         s[r] = (l == 0) ? xl * yl : PK::fma(xl, yl, s[r]);
                     }
@@ -207,7 +211,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     }
     };
     if constexpr (FAM == COVGRAM_MATERNP) {
-        if (kp.p <= 3) {
+        if (kp.p == 1 || kp.p == 2) {                        // the common orders: their own copies (the polynomial at its own degree)
+            typename ParamsOf<FAM, T>::type kq = kp;
+            if (kp.p == 1) { kq.p = 1; sweep(kq); } else { kq.p = 2; sweep(kq); }
+        } else if (kp.p <= 3) {
             typename ParamsOf<FAM, T>::type kq = kp;
             kq.p = kp.p & 3;
             sweep(kq);
@@ -404,7 +411,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
         }
     };
     if constexpr (FAM == COVGRAM_MATERNP) {
-        if (kp0.p <= 3) {
+        if (kp0.p == 1 || kp0.p == 2) {
+            typename ParamsOf<FAM, T>::type kq = kp0;
+            if (kp0.p == 1) { kq.p = 1; sweep(kq); } else { kq.p = 2; sweep(kq); }
+        } else if (kp0.p <= 3) {
             typename ParamsOf<FAM, T>::type kq = kp0;
             kq.p = kp0.p & 3;
             sweep(kq);

@@ -297,11 +297,17 @@ struct Phi<COVGRAM_MATERNP, T, true> {
         // addition changes is below 2^-947, where the value is 1 to far below eps; s = inf / NaN give NaN as q(inf) * 0 does)
         return eval_tab(s, kp, EXP2_TAB256);
     }
+    // SHIFTED: the caller's s already carries the + 2^-1000 (the dense fp64 kernels start their sum of squares from it: free)
+    template <bool SHIFTED = false>
     static __device__ __forceinline__ T eval_tab(T s, const KParams<T>& kp, const double* __restrict__ tab) {
         T rr;
-        if constexpr (sizeof(T) == 8) rr = cg_sqrt_pos(s + (T)0x1p-1000); else rr = cg_sqrt(s);
+        if constexpr (sizeof(T) == 8) rr = cg_sqrt_pos(SHIFTED ? s : s + (T)0x1p-1000); else rr = cg_sqrt(s);
         T e = exp2_neg_tab<false>(rr, tab);
-        T q = (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
+        // the polynomial at its own degree where the order is a constant of the caller's copy of the loop (p = 1, 2: one / two fmas;
+        // the zero-padded degree-3 form otherwise)
+        T q = kp.p == 1 ? cg_fma(kp.h0[1], rr, kp.h0[0])
+            : kp.p == 2 ? cg_fma(cg_fma(kp.h0[2], rr, kp.h0[1]), rr, kp.h0[0])
+            : (kp.p <= 3) ? horner3(kp.h0, rr) : horner(kp.h0, kp.p, rr);
         return q * e;
     }
 };
