@@ -37,7 +37,42 @@ constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, s
 // overflow the ~100 usable SGPRs and spill them through v_writelane.
 // The profile of the dense fp64 kernels: EQ / MaternP / Exponential read the exponential's table from the LDS copy their kernels
 // fill first (profiles.hpp: exp_tab_lds); everything else is phi_value.
-template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP);
+template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP || FAM == COVGRAM_RQ ||
+                                                   FAM == COVGRAM_GAMMAEXP);
+// 2^(-L a) for L >= 0 and a uniform a > 0 on the LDS table (the rational-quadratic profile's u^(-alpha) with L = log2 u, 13 instructions
+// against the 23 of exp2_scaled_nonpos): L a = n / 256 + r exactly (n from the low word of fma(L, -256 a, 1.5 * 2^52)); L is clamped at
+// 1100 / a by ONE v_min_f64 — a NaN is restored by the caller's own test on u (rq_pow's).
+__device__ __forceinline__ double exp2_neg_prod_lds(double L, double a) {
+    const double lc = __builtin_fmin(L, 1100.0 / a);
+    double magic = 0x1.8p52, c256 = -256.0 * a;
+    asm("" : "+v"(magic));
+    const double nb = __builtin_fma(lc, c256, magic);
+    const int ni = __double2loint(nb);
+    const double n = nb - magic;
+    const double r = __builtin_fma(lc, c256, -n);
+    const double tj = exp_tab_lds()[ni & 255];
+    double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+    q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
+    q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
+    return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
+}
+// exp(-t / 2), t >= 0 or NaN, on the LDS table (the gamma-exponential profile's outer exponential): -128 log2(e) in two parts
+__device__ __forceinline__ double exp_neg_half_lds(double t) {
+    const double tc = __hiloint2double(t > 1525.0 ? 0x4097D400 : __double2hiint(t), __double2loint(t));
+    const double clo = -0x1.777d0ffda0d24p-49;
+    double magic = 0x1.8p52, chi = -0x1.71547652b82fep+7;
+    asm("" : "+v"(magic));
+    asm("" : "+s"(chi));
+    const double nb = __builtin_fma(tc, chi, magic);
+    const int ni = __double2loint(nb);
+    const double n = nb - magic;
+    const double f = __builtin_fma(tc, clo, __builtin_fma(tc, chi, -n));
+    const double tj = exp_tab_lds()[ni & 255];
+    double q = __builtin_fma(f, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+    q = __builtin_fma(q, f, 0x1.ebfbdff82c58fp-19);
+    q = __builtin_fma(q, f, 0x1.62e42fefa39efp-9);
+    return __builtin_ldexp(__builtin_fma(tj, f * q, tj), ni >> 8);
+}
 // what the sum of squares starts from: 2^-1000 for the fp64 MaternP profile (its square root then needs no zero test: profiles.hpp), else 0
 template <int FAM, typename T> constexpr T dense_s0 = (FAM == COVGRAM_MATERNP && sizeof(T) == 8) ? (T)0x1p-1000 : (T)0;
 template <int FAM, typename T, bool POW>
@@ -46,7 +81,15 @@ __device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::typ
         T v;
         if constexpr (FAM == COVGRAM_EQ) v = exp2_neg_tab(s, exp_tab_lds());
         else if constexpr (FAM == COVGRAM_MATERNP) v = Phi<COVGRAM_MATERNP, T, true>::template eval_tab<true>(s, kp, exp_tab_lds());   // s starts from 2^-1000: dense_s0
-        else v = exp_neg_tab(cg_sqrt(s), exp_tab_lds());
+        else if constexpr (FAM == COVGRAM_EXP) v = exp_neg_tab(cg_sqrt(s), exp_tab_lds());
+        else if constexpr (FAM == COVGRAM_RQ) {                    // (1 + s / (2 alpha))^(-alpha), as Phi<RQ> / rq_pow with the table exponential
+            const T u = cg_fma(s, kp.c0, (T)1);
+            const T w = exp2_neg_prod_lds(log2_ge1(u), kp.param);
+            v = u <= 1.7e308 ? w : (u > 1.7e308 ? (T)0 : u);       // u = inf: 0; NaN: NaN
+        } else {                                                   // exp(-s^(gamma/2) / 2), as Phi<GAMMAEXP> with the outer exponential on the table
+            const T t = (kp.param == (T)0) ? (T)1 : pow_pos(s, kp.param);
+            v = exp_neg_half_lds(t);
+        }
         if constexpr (POW) v = ipow(v, kp.power);
         return v;
     } else {
