@@ -169,7 +169,7 @@ def other_configs(cg, dev):
     out["C1"] = {"what": "MaternP(2) dense Gramian mul!, d=3 n=4096 fp64", "ms": ms, "mvm_per_s": 1e3 / ms,
                  "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy(), o.mul(None, o.Kernel(o.MATERNP, p=2), Xh, Xh, ah)),
                  "roofline": {"bound": "valu_fp64", "achieved": fl / (ms * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) * 1e-12 / 78.6,
-                              "note": "1.7e7 pairs = 4096 waves of 64 rows x 64 columns, half of the chip's wave slots for ONE round: the kernel is ~25 of the 32 us (its floor at the large-n rate of this profile, 0.85e12 pairs/s, is 20 us), pack + reduction launches the rest"}}
+                              "note": "1.7e7 pairs = 4096 waves of 64 rows x 64 columns, half of the chip's wave slots for ONE round: the kernel is ~21 of the 29 us (its floor at the large-n rate of this profile, 1.07e12 pairs/s since the table exponential of round 3, is 16 us), pack + reduction launches the rest"}}
     # The reference README's own dense case (lazy dense mul!, MaternP(2), d=3, n=16384, Float64: 0.584813 s on its unstated
     # CPU, README.md:26-38), not one of BASELINE.json's configs: all n^2 entries (dense_sym = 0) and the library's default for
     # gramian(k, x) in fp64, the symmetric direct-difference kernel (upper triangle once, exact differences).  Reporting only.
