@@ -56,6 +56,23 @@ __device__ __forceinline__ double exp2_neg_prod_lds(double L, double a) {
     q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
     return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
 }
+// 2^(L c) for finite L, either sign, |L c| <= ~1100 (the gamma-exponential's s^(gamma/2) with L = log2 s in [-1074, 1024] and
+// c = gamma / 2 <= 1): no clamp — ldexp takes the whole exponent range, the caller's own tests on s replace the specials
+// (pow_pos's: 0 -> 0, inf -> inf, NaN -> NaN).  12 instructions against the 23 of exp2_scaled_nonpos.
+__device__ __forceinline__ double exp2_prod_lds(double L, double c) {
+    double magic = 0x1.8p52, c256 = 256.0 * c;
+    asm("" : "+v"(magic));
+    const double nb = __builtin_fma(L, c256, magic);
+    const int ni = __double2loint(nb);
+    const double n = nb - magic;
+    const double r = __builtin_fma(L, c256, -n);
+    const double tj = exp_tab_lds()[ni & 255];
+    // (here r = 256 L c - n carries the POSITIVE sign convention: exp2(x) = 2^(n >> 8) T[n & 255] exp(r ln2 / 256))
+    double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+    q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
+    q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
+    return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
+}
 // exp(-t / 2), t >= 0 or NaN, on the LDS table (the gamma-exponential profile's outer exponential): -128 log2(e) in two parts
 __device__ __forceinline__ double exp_neg_half_lds(double t) {
     const double tc = __hiloint2double(t > 1525.0 ? 0x4097D400 : __double2hiint(t), __double2loint(t));
@@ -87,7 +104,9 @@ __device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::typ
             const T w = exp2_neg_prod_lds(log2_ge1(u), kp.param);
             v = u <= 1.7e308 ? w : (u > 1.7e308 ? (T)0 : u);       // u = inf: 0; NaN: NaN
         } else {                                                   // exp(-s^(gamma/2) / 2), as Phi<GAMMAEXP> with the outer exponential on the table
-            const T t = (kp.param == (T)0) ? (T)1 : pow_pos(s, kp.param);
+            const T w = exp2_prod_lds(log2_ge1(s), kp.param);
+            const T t0 = (s > (T)0 && s <= 1.7e308) ? w : (s == (T)0 ? (T)0 : s);   // pow_pos: 0 -> 0, inf -> inf, NaN -> NaN
+            const T t = (kp.param == (T)0) ? (T)1 : t0;
             v = exp_neg_half_lds(t);
         }
         if constexpr (POW) v = ipow(v, kp.power);
