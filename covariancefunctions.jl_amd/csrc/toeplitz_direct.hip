@@ -2,13 +2,15 @@
 // (:77-98) and Trench (:57-71) for the symmetric positive definite Toeplitz matrix K = SymmetricToeplitz([1; r]) (unit diagonal).
 //
 // Durbin / Levinson are chains of n - 1 DEPENDENT steps, each a reversed dot product and a reversed axpy of length k
-// (reverse_dot :114-122, reverse_increment! :125-145): there is no parallelism across steps, so ONE workgroup of 1024 threads
-// walks the chain — every step is two strided passes over the first k entries (the two dot products fused into one pass, the
-// two updates into the other: x and y are read as the pair (i, k-1-i) so that the in-place reversed update of y needs no
-// temporary, exactly as the reference's x === y branch) and a fixed-order block reduction.  The vectors live in global
-// memory (L2-resident; a workgroup's own stores are visible to it after its barrier).  O(n^2 / 1024) thread steps + 2 barriers
-// per step: n = 16384 takes tens of milliseconds against the reference's 0.17 s (README.md:141-142); for large n the PCG over
-// the FFT MVM (covgram.solve.toeplitz_solve, O(n log n) per iteration) is the faster path and stays the default `\`.
+// (reverse_dot :114-122, reverse_increment! :125-145): there is no parallelism across steps, so ONE workgroup walks the chain.
+// Two kernels.  n <= 16384 (levinson_reg_kernel, round 3): x, y and the r operand in registers, an LDS copy of y for the reversed
+// reads, nothing in global memory inside the chain — n = 16384 fp64 in 28 ms against the reference's 0.17 s (README.md:141-142).
+// Above it, up to COVGRAM_TOEPLITZ_DIRECT_MAX_N (levinson_kernel, round 2): 1024 threads, every step two strided passes over the
+// first k entries (the two dot products fused into one pass, the two updates into the other: x and y are read as the pair
+// (i, k-1-i) so that the in-place reversed update of y needs no temporary, exactly as the reference's x === y branch) and a
+// fixed-order block reduction; the vectors live in global memory (L2-resident; a workgroup's own stores are visible to it after
+// its barrier), ~8 us a step.  For large n the PCG over the FFT MVM (covgram.solve.toeplitz_solve, O(n log n) per iteration) is
+// the faster path and stays the default `\`.
 //
 // Trench: B = inv(K) from the Durbin solution; the reference's double loop B[i,j] = B[i-1,j-1] + (v[n+1-j] v[n+1-i] -
 // v[i-1] v[j-1]) / gamma is a running sum along each diagonal, so a thread owns a diagonal and walks it in the reference's
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(LV_THREADS) void levinson_kernel(const T* __restric
 //   * the reversed dot products are taken over the OWN entries, sum_e x[e] r[k-1-e]: the r operand slides by one entry per step,
 //     so each thread keeps rs[e] = r[k-1-e] in registers and shifts it (register renames within the thread, one lane shuffle
 //     for its first entry, one LDS word per wave for the wave boundary, r[k] enters at e = 0).  The sums touch no memory at all,
-//     and the loop no global memory but two scalar loads (r[k+1], b[k+1]) issued a step ahead;
+//     and the loop no global memory but the 64-entry blocks of r and b, loaded 64 steps ahead and read across lanes;
 //   * a step: sums (registers) | barrier (the reduction's) | partner reads from the LDS copy + update of x and y in registers |
 //     barrier | own y -> LDS copy.  The copy's writes of step k and its reads of step k + 1 are separated by that step's
 //     reduction barrier: two barriers a step.
