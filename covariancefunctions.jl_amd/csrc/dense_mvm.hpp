@@ -39,6 +39,31 @@ constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, s
 // fill first (profiles.hpp: exp_tab_lds); everything else is phi_value.
 template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP || FAM == COVGRAM_RQ ||
                                                    FAM == COVGRAM_GAMMAEXP);
+// log2(u) for positive finite u (normal or denormal) by table, read from an LDS copy (exp2_table.hpp: LOG2_TAB128): u = m 2^E with m in
+// [1/2, 1) (v_frexp_mant / _exp), j = the top 7 mantissa bits of m, r = m * RN(1 / c_j) - 1 in one fma (|r| <= 2^-8, exact), and
+// log2 m = -log2(RN(1 / c_j)) + log2(1 + r) with the degree-6 series of log(1 + r) (remainder 2.8e-18).  Absolute error ~1e-16 + one
+// rounding at the magnitude of the result — what 2^(c log2 u) needs (the entry-wise tests of the RQ / gamma-exponential profiles hold
+// it to (4 + |c log2 u|) ulp).  15 instructions + one ds_read_b128 against the 28 of log2_ge1 (reciprocal with two Newton steps +
+// an atanh series).  0, inf, NaN: garbage — the callers' own tests on their argument replace those.
+__device__ __forceinline__ double (*log_tab_lds())[2] { __shared__ __attribute__((aligned(16))) double t[128][2]; return t; }
+__device__ __forceinline__ void log_tab_lds_fill() {
+    double (*t)[2] = log_tab_lds();
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) { t[i][0] = LOG2_TAB128[i][0]; t[i][1] = LOG2_TAB128[i][1]; }
+    __syncthreads();
+}
+__device__ __forceinline__ double log2_lds(double u) {
+    const double m = __builtin_amdgcn_frexp_mant(u);
+    const int e = __builtin_amdgcn_frexp_exp(u);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 ent = *reinterpret_cast<const d2*>(log_tab_lds()[(__double2hiint(m) >> 13) & 127]);
+    const double r = __builtin_fma(m, ent.x, -1.0);
+    double q = __builtin_fma(r, -0x1.5555555555555p-3, 0x1.999999999999ap-3);      // -1/6, 1/5
+    q = __builtin_fma(q, r, -0.25);
+    q = __builtin_fma(q, r, 0x1.5555555555555p-2);                                  // 1/3
+    q = __builtin_fma(q, r, -0.5);
+    q = __builtin_fma(q, r, 1.0);
+    return __builtin_fma(r * q, 0x1.71547652b82fep+0, ent.y + (double)e);          // log2(e) ln(1 + r) + (log2 c_j + E)
+}
 // 2^(-L a) for L >= 0 and a uniform a > 0 on the LDS table (the rational-quadratic profile's u^(-alpha) with L = log2 u, 13 instructions
 // against the 23 of exp2_scaled_nonpos): L a = n / 256 + r exactly (n from the low word of fma(L, -256 a, 1.5 * 2^52)); L is clamped at
 // 1100 / a by ONE v_min_f64 — a NaN is restored by the caller's own test on u (rq_pow's).
@@ -101,10 +126,10 @@ __device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::typ
         else if constexpr (FAM == COVGRAM_EXP) v = exp_neg_tab(cg_sqrt(s), exp_tab_lds());
         else if constexpr (FAM == COVGRAM_RQ) {                    // (1 + s / (2 alpha))^(-alpha), as Phi<RQ> / rq_pow with the table exponential
             const T u = cg_fma(s, kp.c0, (T)1);
-            const T w = exp2_neg_prod_lds(log2_ge1(u), kp.param);
+            const T w = exp2_neg_prod_lds(log2_lds(u), kp.param);
             v = u <= 1.7e308 ? w : (u > 1.7e308 ? (T)0 : u);       // u = inf: 0; NaN: NaN
         } else {                                                   // exp(-s^(gamma/2) / 2), as Phi<GAMMAEXP> with the outer exponential on the table
-            const T w = exp2_prod_lds(log2_ge1(s), kp.param);
+            const T w = exp2_prod_lds(log2_lds(s), kp.param);
             const T t0 = (s > (T)0 && s <= 1.7e308) ? w : (s == (T)0 ? (T)0 : s);   // pow_pos: 0 -> 0, inf -> inf, NaN -> NaN
             const T t = (kp.param == (T)0) ? (T)1 : t0;
             v = exp_neg_half_lds(t);
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     // cloud's extent, not to its distance from the origin (the reference subtracts first and scales after, src/util.jl:40-47).
     constexpr bool ISO = fam_is_iso<FAM>;
     if constexpr (sizeof(T) == 8 && dense_lds_tab<FAM>) exp_tab_lds_fill();
+    if constexpr (sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP)) log_tab_lds_fill();
     using Body = DenseBody<T, FAM, D, NR, R, POW, ISO>;
     using PK = Pk<T>;
     using V = typename PK::V;
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_sym_kernel(
     using T = double;
     constexpr bool ISO = fam_is_iso<FAM>;
     if constexpr (dense_lds_tab<FAM>) exp_tab_lds_fill();          // before the early return below: every thread reaches the barrier
+    if constexpr (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP) log_tab_lds_fill();
     using Body = DenseBody<T, FAM, D, 1, 1, false, ISO>;
     constexpr int S = D + 1;
     const int lane = threadIdx.x;
