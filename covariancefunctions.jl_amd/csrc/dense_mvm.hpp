@@ -39,82 +39,6 @@ constexpr int DENSE_INNER = 512;  // inner accumulation chunk (columns); even, s
 // fill first (profiles.hpp: exp_tab_lds); everything else is phi_value.
 template <int FAM> constexpr bool dense_lds_tab = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || FAM == COVGRAM_EXP || FAM == COVGRAM_RQ ||
                                                    FAM == COVGRAM_GAMMAEXP);
-// log2(u) for positive finite u (normal or denormal) by table, read from an LDS copy (exp2_table.hpp: LOG2_TAB128): u = m 2^E with m in
-// [1/2, 1) (v_frexp_mant / _exp), j = the top 7 mantissa bits of m, r = m * RN(1 / c_j) - 1 in one fma (|r| <= 2^-8, exact), and
-// log2 m = -log2(RN(1 / c_j)) + log2(1 + r) with the degree-6 series of log(1 + r) (remainder 2.8e-18).  Absolute error ~1e-16 + one
-// rounding at the magnitude of the result — what 2^(c log2 u) needs (the entry-wise tests of the RQ / gamma-exponential profiles hold
-// it to (4 + |c log2 u|) ulp).  15 instructions + one ds_read_b128 against the 28 of log2_ge1 (reciprocal with two Newton steps +
-// an atanh series).  0, inf, NaN: garbage — the callers' own tests on their argument replace those.
-__device__ __forceinline__ double (*log_tab_lds())[2] { __shared__ __attribute__((aligned(16))) double t[128][2]; return t; }
-__device__ __forceinline__ void log_tab_lds_fill() {
-    double (*t)[2] = log_tab_lds();
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) { t[i][0] = LOG2_TAB128[i][0]; t[i][1] = LOG2_TAB128[i][1]; }
-    __syncthreads();
-}
-__device__ __forceinline__ double log2_lds(double u) {
-    const double m = __builtin_amdgcn_frexp_mant(u);
-    const int e = __builtin_amdgcn_frexp_exp(u);
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2 ent = *reinterpret_cast<const d2*>(log_tab_lds()[(__double2hiint(m) >> 13) & 127]);
-    const double r = __builtin_fma(m, ent.x, -1.0);
-    double q = __builtin_fma(r, -0x1.5555555555555p-3, 0x1.999999999999ap-3);      // -1/6, 1/5
-    q = __builtin_fma(q, r, -0.25);
-    q = __builtin_fma(q, r, 0x1.5555555555555p-2);                                  // 1/3
-    q = __builtin_fma(q, r, -0.5);
-    q = __builtin_fma(q, r, 1.0);
-    return __builtin_fma(r * q, 0x1.71547652b82fep+0, ent.y + (double)e);          // log2(e) ln(1 + r) + (log2 c_j + E)
-}
-// 2^(-L a) for L >= 0 and a uniform a > 0 on the LDS table (the rational-quadratic profile's u^(-alpha) with L = log2 u, 13 instructions
-// against the 23 of exp2_scaled_nonpos): L a = n / 256 + r exactly (n from the low word of fma(L, -256 a, 1.5 * 2^52)); L is clamped at
-// 1100 / a by ONE v_min_f64 — a NaN is restored by the caller's own test on u (rq_pow's).
-__device__ __forceinline__ double exp2_neg_prod_lds(double L, double a) {
-    const double lc = __builtin_fmin(L, 1100.0 / a);
-    double magic = 0x1.8p52, c256 = -256.0 * a;
-    asm("" : "+v"(magic));
-    const double nb = __builtin_fma(lc, c256, magic);
-    const int ni = __double2loint(nb);
-    const double n = nb - magic;
-    const double r = __builtin_fma(lc, c256, -n);
-    const double tj = exp_tab_lds()[ni & 255];
-    double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
-    q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
-    q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
-    return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
-}
-// 2^(L c) for finite L, either sign, |L c| <= ~1100 (the gamma-exponential's s^(gamma/2) with L = log2 s in [-1074, 1024] and
-// c = gamma / 2 <= 1): no clamp — ldexp takes the whole exponent range, the caller's own tests on s replace the specials
-// (pow_pos's: 0 -> 0, inf -> inf, NaN -> NaN).  12 instructions against the 23 of exp2_scaled_nonpos.
-__device__ __forceinline__ double exp2_prod_lds(double L, double c) {
-    double magic = 0x1.8p52, c256 = 256.0 * c;
-    asm("" : "+v"(magic));
-    const double nb = __builtin_fma(L, c256, magic);
-    const int ni = __double2loint(nb);
-    const double n = nb - magic;
-    const double r = __builtin_fma(L, c256, -n);
-    const double tj = exp_tab_lds()[ni & 255];
-    // (here r = 256 L c - n carries the POSITIVE sign convention: exp2(x) = 2^(n >> 8) T[n & 255] exp(r ln2 / 256))
-    double q = __builtin_fma(r, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
-    q = __builtin_fma(q, r, 0x1.ebfbdff82c58fp-19);
-    q = __builtin_fma(q, r, 0x1.62e42fefa39efp-9);
-    return __builtin_ldexp(__builtin_fma(tj, r * q, tj), ni >> 8);
-}
-// exp(-t / 2), t >= 0 or NaN, on the LDS table (the gamma-exponential profile's outer exponential): -128 log2(e) in two parts
-__device__ __forceinline__ double exp_neg_half_lds(double t) {
-    const double tc = __hiloint2double(t > 1525.0 ? 0x4097D400 : __double2hiint(t), __double2loint(t));
-    const double clo = -0x1.777d0ffda0d24p-49;
-    double magic = 0x1.8p52, chi = -0x1.71547652b82fep+7;
-    asm("" : "+v"(magic));
-    asm("" : "+s"(chi));
-    const double nb = __builtin_fma(tc, chi, magic);
-    const int ni = __double2loint(nb);
-    const double n = nb - magic;
-    const double f = __builtin_fma(tc, clo, __builtin_fma(tc, chi, -n));
-    const double tj = exp_tab_lds()[ni & 255];
-    double q = __builtin_fma(f, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
-    q = __builtin_fma(q, f, 0x1.ebfbdff82c58fp-19);
-    q = __builtin_fma(q, f, 0x1.62e42fefa39efp-9);
-    return __builtin_ldexp(__builtin_fma(tj, f * q, tj), ni >> 8);
-}
 // what the sum of squares starts from: 2^-1000 for the fp64 MaternP profile (its square root then needs no zero test: profiles.hpp), else 0
 template <int FAM, typename T> constexpr T dense_s0 = (FAM == COVGRAM_MATERNP && sizeof(T) == 8) ? (T)0x1p-1000 : (T)0;
 template <int FAM, typename T, bool POW>

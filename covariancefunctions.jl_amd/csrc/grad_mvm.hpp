@@ -82,6 +82,37 @@ constexpr int grad_min_waves() {
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 
+// The jets of the gradient kernel.  fp64 rational-quadratic and gamma-exponential: their log2 / exp2 on the LDS tables the kernel fills
+// first (profiles.hpp: log2_lds, exp2_neg_prod_lds, exp2_prod_lds, exp_neg_half_lds — 15 + 13 instructions for the 28 + 23 of the
+// polynomial forms; these profiles' arithmetic, not the scalar stream, is what separates their MVM from EQ's); everything else: phi_jet.
+template <int FAM, typename T> constexpr bool grad_lds_tab = sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP);
+template <int FAM, typename T, bool POW, int PFIX>
+__device__ __forceinline__ void grad_jet(T s, const typename ParamsOf<FAM, T>::type& kp, T& v, T& d1, T& d2) {
+    if constexpr (grad_lds_tab<FAM, T> && FAM == COVGRAM_RQ) {                   // DPhi<RQ> with the table power
+        const T a = kp.param;
+        const T u = cg_fma(s, kp.c0, (T)1);
+        const T iu = cg_rcp(u);
+        const T w = exp2_neg_prod_lds(log2_lds(u), a);
+        v = u <= 1.7e308 ? w : (u > 1.7e308 ? (T)0 : u);                       // u = inf: 0; NaN: NaN (rq_pow)
+        d1 = (T)-0.5 * v * iu;
+        d2 = (a + (T)1) * ((T)0.5 * kp.c0) * v * iu * iu;
+        if constexpr (POW) power_jet(kp.power, v, d1, d2);
+    } else if constexpr (grad_lds_tab<FAM, T> && FAM == COVGRAM_GAMMAEXP) {      // DPhi<GAMMAEXP> with the table power and exponential
+        const T g = kp.param;
+        const T w = exp2_prod_lds(log2_lds(s), g);
+        const T p0 = (s > (T)0 && s <= 1.7e308) ? w : (s == (T)0 ? (T)0 : s);   // pow_pos: 0 -> 0, inf -> inf, NaN -> NaN
+        const T sg = (g == (T)0) ? (T)1 : p0;
+        const T is = cg_rcp(s);
+        v = exp_neg_half_lds(sg);
+        const T hg = (T)0.5 * g;
+        d1 = -hg * sg * is * v;
+        d2 = v * (hg * hg * sg * sg * is * is - hg * (g - (T)1) * sg * is * is);
+        if constexpr (POW) power_jet(kp.power, v, d1, d2);
+    } else {
+        phi_jet<FAM, T, POW, PFIX>(s, kp, v, d1, d2);
+    }
+}
+
 // VG = true is the ValueGradientKernel Gramian (src/gradient.jl:400-474, block mul! :319-351): blocks of d+1 with a value
 // row/column.  In the pre-scaled coordinates (a_j = (a0, av), t = r'.av or x'.av):
 //   isotropic:    bv = -2 gamma^2 (psi' av + (2 psi'' t - psi' a0 / gamma) r'),   b0 = psi a0 - 2 gamma psi' t
@@ -100,6 +131,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM, NR
                                                                 const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp,
                                                                 const T* __restrict__ Ex, int64_t ldy) {
     constexpr bool ISO = fam_is_iso<FAM>;
+    if constexpr (grad_lds_tab<FAM, T>) { exp_tab_lds_fill(); log_tab_lds_fill(); }
     constexpr int RS = (1 + NR) * D;                                             // scalars per column record
     static_assert(!EXPD || (ISO && !KEEP_R), "the expanded form is an isotropic variant that keeps no r");
     // dims per chunk: one 64-byte s_load per operand; 32-byte loads with two right-hand sides — a chunk is (1 + NR) operands and two chunks
@@ -236,14 +268,14 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM, NR
         T k1, k2, c2[NR];
         if constexpr (VG) {
             T v;
-            phi_jet<FAM, T, POW, PFIX>(s, kp, v, k1, k2);
+            grad_jet<FAM, T, POW, PFIX>(s, kp, v, k1, k2);
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 c2[rr] = cg_fma(vg_c * k1, a0[rr], ISO ? (T)2 * k2 * t[rr] : k2 * t[rr]);
                 b0[rr] = cg_fma(v, a0[rr], cg_fma(vg_b * k1, t[rr], b0[rr]));
             }
         } else {
-            phi_derivs<FAM, T, POW, PFIX>(s, kp, k1, k2);
+            { T v_; grad_jet<FAM, T, POW, PFIX>(s, kp, v_, k1, k2); }
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 if constexpr (FAM == COVGRAM_EQ && !POW) c2[rr] = -k1 * t[rr];       // EQ: 2 k2 = -k1 (both exact scalings of the same exponential)
