@@ -85,7 +85,7 @@ constexpr int grad_min_waves() {
 // The jets of the gradient kernel.  fp64 rational-quadratic and gamma-exponential: their log2 / exp2 on the LDS tables the kernel fills
 // first (profiles.hpp: log2_lds, exp2_neg_prod_lds, exp2_prod_lds, exp_neg_half_lds — 15 + 13 instructions for the 28 + 23 of the
 // polynomial forms; these profiles' arithmetic, not the scalar stream, is what separates their MVM from EQ's); everything else: phi_jet.
-template <int FAM, typename T> constexpr bool grad_lds_tab = sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP);
+template <int FAM, typename T> constexpr bool grad_lds_tab = sizeof(T) == 8 && (FAM == COVGRAM_RQ || FAM == COVGRAM_GAMMAEXP || FAM == COVGRAM_MATERNP);
 template <int FAM, typename T, bool POW, int PFIX>
 __device__ __forceinline__ void grad_jet(T s, const typename ParamsOf<FAM, T>::type& kp, T& v, T& d1, T& d2) {
     if constexpr (grad_lds_tab<FAM, T> && FAM == COVGRAM_RQ) {                   // DPhi<RQ> with the table power
@@ -107,6 +107,9 @@ __device__ __forceinline__ void grad_jet(T s, const typename ParamsOf<FAM, T>::t
         const T hg = (T)0.5 * g;
         d1 = -hg * sg * is * v;
         d2 = v * (hg * hg * sg * sg * is * is - hg * (g - (T)1) * sg * is * is);
+        if constexpr (POW) power_jet(kp.power, v, d1, d2);
+    } else if constexpr (grad_lds_tab<FAM, T> && FAM == COVGRAM_MATERNP) {         // DPhi<MATERNP> with exp(-r) on the table
+        DPhi<FAM, T>::template eval<PFIX, true>(s, kp, v, d1, d2);
         if constexpr (POW) power_jet(kp.power, v, d1, d2);
     } else {
         phi_jet<FAM, T, POW, PFIX>(s, kp, v, d1, d2);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(GRAD_THREADS, (grad_min_waves<T, D, KEEP_R, FAM, NR
                                                                 const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp,
                                                                 const T* __restrict__ Ex, int64_t ldy) {
     constexpr bool ISO = fam_is_iso<FAM>;
-    if constexpr (grad_lds_tab<FAM, T>) { exp_tab_lds_fill(); log_tab_lds_fill(); }
+    if constexpr (grad_lds_tab<FAM, T>) { exp_tab_lds_fill(); if constexpr (FAM != COVGRAM_MATERNP) log_tab_lds_fill(); }
     constexpr int RS = (1 + NR) * D;                                             // scalars per column record
     static_assert(!EXPD || (ISO && !KEEP_R), "the expanded form is an isotropic variant that keeps no r");
     // dims per chunk: one 64-byte s_load per operand; 32-byte loads with two right-hand sides — a chunk is (1 + NR) operands and two chunks

@@ -663,11 +663,13 @@ template <typename T>
 struct DPhi<COVGRAM_MATERNP, T> {
     // PFIX >= 0: the order is a compile-time constant (the callers branch on kp.p ONCE, outside their column loops, so that the
     // loop they run carries only that order's code and registers)
-    template <int PFIX = -1>
+    // LDSTAB: exp(-r) on the exponential's table read from the kernel's LDS copy (the kernel fills it first; fp64 only)
+    template <int PFIX = -1, bool LDSTAB = false>
     static __device__ __forceinline__ void eval(T s, const KParams<T>& kp, T& v, T& d1, T& d2) {
         const int p = PFIX >= 0 ? PFIX : kp.p;
         T r = cg_sqrt(kp.mp_c * s);
-        T e = cg_exp_neg(r);
+        T e;
+        if constexpr (LDSTAB && sizeof(T) == 8) e = exp_neg_tab(r, exp_tab_lds()); else e = cg_exp_neg(r);
         if (p == 0) {                                     // Exp profile (singular at 0)
             T ir = cg_rcp(r);
             v = e;
