@@ -5,6 +5,11 @@
                                                                      the file has no shebang, so nothing re-execs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts the second command line as a CHILD
+(one rank per GPU over RCCL), forwards the child's one JSON line and exits with its return code.  Every rank asserts
+WORLD_SIZE == --gpus, and the line carries `rccl_ranks`.  `--dry-launch` runs the same launch with backend gloo and no GPU work
+(a CPU-tier check that N ranks really start and meet in a collective).
+
 One "step" = one full MVM b = G a with the points, a and b resident in HBM.  The contract run follows SURVEY.md §8d: y == x,
 symmetry NOT exploited — all n*m entries are evaluated (general matrix-core kernel); for N > 1 the rows of G are sharded over
 the ranks and ONE RCCL all-gather completes b on every rank (covgram.dist); n stays 131072, so scaling is "strong".
@@ -263,6 +268,57 @@ def other_configs(cg, dev):
     return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """`bench.py --gpus N` run by hand (no WORLD_SIZE): start N ranks of this file under torch.distributed.run as a CHILD process
+    — this process has made no GPU call (torch.cuda.device_count() does not initialise the runtime on this image) and is never
+    replaced —, forward the ONE JSON line rank 0 prints and return the child's exit code."""
+    if not args.dry_launch:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible\n")
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            sys.stderr.write(ln + "\n")
+    if r.returncode == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from the {args.gpus} ranks, got {len(lines)}\n")
+        return 3
+    if lines:
+        sys.stdout.write(lines[-1] + "\n"); sys.stdout.flush()
+    return r.returncode
+
+
+def dry_launch(args, world, rank) -> None:
+    """--dry-launch: the ranks meet over gloo, no GPU work — every rank contributes (rank, pid) to one all-gather and rank 0 prints a
+    line in the contract's shape with value null.  What it proves: N distinct processes were started by `--gpus N` and share a group."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.tensor([rank, os.getpid()], dtype=torch.int64)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    ranks = [int(t[0]) for t in allr]; pids = [int(t[1]) for t in allr]
+    assert ranks == list(range(world)) and len(set(pids)) == world, (ranks, pids)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (dry launch: no GPU work)", "value": None, "unit": "MVM/s",
+                          "n_gpus": world, "rccl_ranks": 0, "gloo_ranks": world, "backend": "gloo", "dry_launch": True, "ranks": ranks, "pids": pids,
+                          "steps": 0, "warmup": 0}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,7 +326,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C4 / C5 block (N = 1)")
+    ap.add_argument("--dry-launch", action="store_true", help="start the --gpus N ranks over gloo, one all-gather, no GPU work (CPU-tier launch check)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE={os.environ.get('WORLD_SIZE')} but --gpus {args.gpus}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)\n")
+        sys.exit(2)
+    if args.dry_launch:
+        dry_launch(args, int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")))
+        return
 
     # RCCL prints its version banner and warnings on fd 1; keep the contract's ONE JSON line clean by routing every other
     # write to stdout (C libraries included) to stderr and printing the result on the saved descriptor.
@@ -281,6 +350,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus
 
     rng = np.random.default_rng(SEED)                       # identical on every rank: replicated inputs
     Xh = rng.standard_normal((N_POINTS, DIM)).astype(np.float32)
@@ -297,8 +367,12 @@ def main():
     if world > 1 or os.environ.get("COVGRAM_FORCE_COLLECTIVE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible\n")
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -530,7 +604,7 @@ def main():
         achieved_tflops = flops_launch / kern_s * 1e-12
         traffic = None
         pmc = None
-        for rnd in ("r03", "r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
+        for rnd in ("r04", "r03", "r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
             cand = os.path.join(ROOT, "profiles", f"{rnd}_" + (("dense_mfma_sym_pmc.json" if sym_path else "dense_mfma_pmc.json") if dense_path == 2
                                                                else "dense_pmc.json"))
             if os.path.exists(cand):
@@ -569,8 +643,9 @@ def main():
             cycles64 = 8.0 + 4.0 + mfma_hold
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
                     "products), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' is the reference's algorithmic 3d+3 flops per "
-                    "pair over the measured kernel time; 'peak' is the kernel's VALU issue ceiling in the same flops (v_exp_f32 8 + v_fma_f32 4 + "
-                    "MFMA hold 1 cycle per 64 pairs per SIMD at the 2.4 GHz peak clock), so 'frac' is the utilisation of the binding pipe; "
+                    "pair over the measured kernel time; 'peak' is the fixed FP32 vector peak, so 'frac' is the round-to-round comparable throughput ratio; "
+                    "'issue_roofline_frac' is the utilisation of the binding pipe: the kernel's VALU issue ceiling (v_exp_f32 8 + v_fma_f32 4 + "
+                    "MFMA hold 1 cycle per 64 pairs per SIMD at the 2.4 GHz peak clock); "
                     "'issue_roofline_frac_at_sustained_clock' prices the same ceiling at the clock measured in this run with the kernel's "
                     "stamping build; 'reference_flops_frac' is the flop ratio against the FP32 vector peak of SURVEY.md \u00a78d(i) (most of those "
                     "flops run on the matrix pipe: a throughput ratio, not a utilisation). 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")
@@ -583,14 +658,16 @@ def main():
         ceiling_sustained = 1024 * clock_ghz * 1e9 * 64 / cycles64 if clock_ghz else None
         flops_per_pair = flops_launch / evaluated_pairs
         on_matrix_cores = dense_path == 2
-        # roofline: for the matrix-core kernels the bound is the VALU issue stream (exp + fma + MFMA hold), so `peak` is that issue
-        # ceiling expressed in the algorithm's flops per pair and frac = achieved / peak = evaluated pairs per second over the ceiling
-        # (never > 1); the reference's flop count against the FP32 vector peak (SURVEY.md \u00a78d(i)) is reference_flops_frac.
-        peak_tflops = ceiling * flops_per_pair * 1e-12 if on_matrix_cores else FP32_VECTOR_PEAK_TFLOPS
+        # roofline.frac is the SAME definition in every round's BENCH file (SURVEY.md \u00a78d(i)): the reference's algorithmic 3d+3 flops per
+        # pair over the measured kernel time against the FIXED FP32 vector peak of the chip.  The utilisation of the pipe that actually
+        # binds the matrix-core kernels — the VALU issue stream (exp + fma + MFMA hold) — is a different question with a kernel-specific
+        # ceiling; it lives under its own keys (issue_roofline_frac, issue_peak_tflops) and never replaces frac.
+        peak_tflops = FP32_VECTOR_PEAK_TFLOPS
+        issue_peak_tflops = ceiling * flops_per_pair * 1e-12
         step_stats = _stats(step_ms)
         line = {
             "metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (+ achieved HBM GB/s in roofline.hbm_*)",
-            "value": mvms, "unit": "MVM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": mvms, "unit": "MVM/s", "n_gpus": world, "rccl_ranks": world if dist.is_initialized() else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_median": step_stats["ms_median"], "ms_min": step_stats["ms_min"], "ms_max": step_stats["ms_max"],
             "timing_note": "value / ms_per_step: wall clock over the K steps between barrier + synchronize (the contract); ms_median / ms_min: one HIP event pair "
                            "per step on the launch stream, same K steps",
@@ -608,12 +685,15 @@ def main():
             "direct_difference_variant": dd,
             "incl_h2d_d2h": incl,
             "roofline": {
-                "bound": "valu_issue" if on_matrix_cores else "valu", "kernel": kname,
+                "bound": "valu", "binding_pipe": "valu_issue" if on_matrix_cores else "valu", "kernel": kname,
                 "achieved": achieved_tflops, "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak_tflops,
-                "peak_note": ("the VALU issue ceiling of this kernel's stream — " + f"{cycles64:g}" + " issue cycles per 64 pairs per SIMD (v_exp_f32 8, v_fma_f32 4, MFMA hold; "
-                              "MI355X_MICROARCH.md) on 1024 SIMDs at 2.4 GHz — times the algorithm's flops per pair" if on_matrix_cores
-                              else "FP32 vector peak (MI355X_MICROARCH.md)"),
+                "frac_definition": "v1 (rounds 1, 2, 4+): algorithmic flops per launch / kernel_avg_ms / the fixed FP32 vector peak; round 3's file "
+                                   "carried the issue-ceiling ratio here, which is issue_roofline_frac in every round",
+                "peak_note": "FP32 vector peak (MI355X_MICROARCH.md)",
+                "issue_peak_tflops": issue_peak_tflops,
+                "issue_peak_note": ("the VALU issue ceiling of this kernel's stream — " + f"{cycles64:g}" + " issue cycles per 64 pairs per SIMD (v_exp_f32 8, v_fma_f32 4, "
+                                    "MFMA hold; MI355X_MICROARCH.md) on 1024 SIMDs at 2.4 GHz — times the algorithm's flops per pair; issue_roofline_frac = achieved / that"),
                 "reference_flops_frac": float(n_local) * m * (3 * d + 3) / kern_s * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
                 "vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,

@@ -1,6 +1,6 @@
 // api.hip — C-ABI entry points of libcovgram.so (include/covgram.h): context / points handles,
 // kernel-parameter construction, and the dense, dense-instantiate and gradient MVM drivers.
-// Structured MVMs live in toeplitz.hip and structured.hip.
+// Structured MVMs live in toeplitz.hip (Toeplitz / Circulant), kron.hip (Kronecker) and lowrank.hip (low rank).
 #include <math.h>
 #include <stdarg.h>
 

@@ -188,7 +188,7 @@ struct covgram_ctx {
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
-    void* blas = nullptr;        // rocblas_handle of the Kronecker mode products (structured.hip), created on first use
+    void* blas = nullptr;        // rocblas_handle of the compute-bound Kronecker mode products (kron.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix cores, 3 wide rows, 4 factored dot product X (Y' a)
     int64_t last_jsplit = 0;     // column split of the last lane-per-row dense launch (tools)

@@ -144,3 +144,39 @@ def test_symmetric_cyclic_panels_allreduce_world2():
     res = _run(n=37, m=37, d=2, nrhs=1, worker=_sym_worker)
     for rank, (r, ncalls, first, shape, err) in enumerate(res):
         assert r == rank and ncalls == 2 and first == (rank, 2) and shape == (37,) and err < 1e-13
+
+
+def _clean_env():
+    """No torchrun variables: the way the driver (or a user) types `python3 bench.py --gpus N`."""
+    return {k: v for k, v in os.environ.items()
+            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID")}
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE must start TWO ranks (round 3 parsed --gpus and never read it).
+    --dry-launch runs exactly that launch path with backend gloo and no GPU work: two distinct processes meet in one all-gather and rank 0's
+    single line comes back through the launcher."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gloo_ranks"] == 2 and line["ranks"] == [0, 1] and len(set(line["pids"])) == 2
+    assert os.getpid() not in line["pids"]                      # the launcher itself is not a rank (it never touches a GPU)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """One process told it is one rank of one (WORLD_SIZE=1) while --gpus says 2: exit code 2, no JSON line — never a silent 1-GPU run
+    labelled as N.  Likewise --gpus 2 on a box with fewer than two GPUs (this container has none)."""
+    import subprocess
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and not r.stdout.strip()
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_clean_env(),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and not r.stdout.strip()

@@ -131,6 +131,33 @@ def test_bench_runs_its_rccl_collectives_at_world_one():
     assert "row-shard" in line["config"]["parallelism"] or "1 GPU" in line["config"]["parallelism"]
 
 
+def test_bench_gpus_one_with_no_environment_at_all():
+    """`python3 bench.py --gpus 1` the way the driver types it — no WORLD_SIZE / RANK / MASTER_* in the environment: one process, no
+    process group (rccl_ranks 0), the contract line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "COVGRAM_FORCE_COLLECTIVE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 0 and line["value"] > 50 and line["rel_err_vs_fp64_oracle"] <= 1e-5
+    assert line["roofline"]["peak"] == 157.3 and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["issue_roofline_frac"] < 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_gpus_two_launches_two_rccl_ranks():
+    """`python3 bench.py --gpus 2` with no environment: the launcher starts two ranks over RCCL; the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["per_rank"]) == 2 and line["rel_err_vs_fp64_oracle"] <= 1e-5
+
+
 def _run_rccl_worker(nproc):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_worker.py")]

@@ -28,7 +28,7 @@ def _cases(cg, o):
 def test_gradient_matrix_right_hand_sides(cg, oracle, dtype, value):
     o = oracle
     npdt = np.float32 if dtype == torch.float32 else np.float64
-    tol = 2e-5 if dtype == torch.float32 else 1e-12
+    tol = 1e-5 if dtype == torch.float32 else 1e-12          # BASELINE.json's tolerances
     rng = np.random.default_rng(71 + int(value))
     ref_mul = o.valgrad_mul if value else o.grad_mul
     for d in (3, 8, 32, 40, 70):                        # 40: fp64 keeps one column per pass (registers); 70: the wide-row path

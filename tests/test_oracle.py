@@ -293,3 +293,17 @@ def test_c_oracle_f32_and_baseline_kernels():
     Xd = X.astype(np.float64); ad = a.astype(np.float64)
     assert rel(c_oracle.eq_rows(Xd, Xd, ad, 0, 500, lib), o.mul(None, o.Kernel(o.EQ), Xd, Xd, ad)) < 1e-13
     assert c_oracle.num_threads(lib) >= 1
+
+
+def test_cpu_baseline_object_leaves_denormals_alone():
+    """bench.py dlopen()s the -ffast-math build of the C restatement as its timed CPU baseline and afterwards runs oracle spot checks in
+    the same process.  A shared object LINKED with -ffast-math carries gcc's crtfastmath constructor, which sets FTZ / DAZ in MXCSR for
+    the loading thread (round 3's bench ran its checks that way).  oracle/Makefile therefore compiles with the flag and links without it:
+    loading the object must leave subnormal arithmetic intact."""
+    tiny = np.array([1e-310])
+    assert (tiny * 1.0)[0] != 0.0
+    lib = c_oracle._load("libcovgram_cpubaseline.so")
+    X = np.random.default_rng(0).standard_normal((64, 3)).astype(np.float32)
+    c_oracle.eq_rows(X, X, X[:, 0].copy(), 0, 64, lib)
+    assert (tiny * 1.0)[0] != 0.0, "the CPU-baseline object switched on flush-to-zero"
+    assert np.finfo(np.float32).smallest_subnormal > 0
