@@ -116,7 +116,7 @@ class ShardedGramian:
             elif local_factory_is_default and (symmetric is True or self.n * (self.n / 2.0) / self.world >=
                                                (SYM_MIN_PAIRS_PER_RANK_F64 if x.dtype == torch.float64 else SYM_MIN_PAIRS_PER_RANK)):
                 full = local_factory(k, x)
-                if hasattr(full, "sym_partial_supported") and full.sym_partial_supported():
+                if hasattr(full, "sym_partial_supported") and full.sym_partial_supported(self.world):
                     self._full_op = full
                     self.sym_partial = full.sym_partial_
 

@@ -320,9 +320,11 @@ class Gramian(LazyOperator):
         return y
 
     # -- multi-GPU symmetric form (include/covgram.h: covgram_mvm_sym_partial) ---------------------
-    def sym_partial_supported(self) -> bool:
-        """True when rank r of P can take the cyclic 256-row panels of the upper triangle (fp32 EQ on the matrix cores, one
-        point set on both sides); depends on the kernel and the points only, so every rank answers alike."""
+    def sym_partial_supported(self, world: int = 1) -> bool:
+        """True when rank r of `world` can take its cyclic panels / row blocks of the upper triangle (one point set on both sides: the
+        symmetric matrix-core kernels in fp32, the direct-difference symmetric kernels in fp64 and for what the matrix cores refuse);
+        depends on the kernel, the points and the world size only, so every rank answers alike — and sym_partial_ raises
+        UnsupportedKernel exactly when this says False."""
         if self._px is not self._py and not (self._px.t.data_ptr() == self._py.t.data_ptr() and self.shape[0] == self.shape[1]):
             return False
         try:
@@ -330,7 +332,7 @@ class Gramian(LazyOperator):
         except Exception:
             return False
         ok = C.c_int32(0)
-        _ffi.check(_ffi.lib().covgram_mvm_sym_supported(self._px.ctx.bind_stream(), _ffi.kref(spec), self._px.handle, C.byref(ok)))
+        _ffi.check(_ffi.lib().covgram_mvm_sym_supported(self._px.ctx.bind_stream(), _ffi.kref(spec), self._px.handle, int(world), C.byref(ok)))
         return bool(ok.value)
 
     def sym_partial_(self, y, a, rank: int, world: int):

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "dense_mvm.hpp"
+#include "dense_sym32.hpp"
 #include "dense_wide.hpp"
 #include "grad_mvm.hpp"
 #include "grad_wide.hpp"
@@ -153,6 +154,13 @@ int make_host_kernel(const covgram_kernel* k, int dtype, bool for_gradient, Host
 
 static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradient, HostKernel* out) {
     CG_REQUIRE(k->family >= 0 && k->family < COVGRAM_NFAMILY, COVGRAM_EUNSUPPORTED, "unknown kernel family %d", k->family);
+    if (k->family == COVGRAM_MATERNP && k->p == 0 && !for_gradient) {
+        // MaternP(0)(s) = exp(-sqrt(s)) IS the Exponential profile (src/stationary.jl:117-158 with p = 0; tests/golden closed forms): the
+        // value-only kernels run it as such instead of through the general MaternP body (fp32 n = 32768: 436 -> 293 us, profiles/r04_sym32_sweep.txt)
+        covgram_kernel e = *k;
+        e.family = COVGRAM_EXP; e.p = 0; e.param = 0.0;
+        return make_simple_kernel(&e, dtype, for_gradient, out);
+    }
     const bool dotfam = (k->family == COVGRAM_DOT || k->family == COVGRAM_EXPDOT || k->family == COVGRAM_ASINDOT);
     const int trait = dotfam ? COVGRAM_DOTPRODUCT : COVGRAM_ISOTROPIC;
     CG_REQUIRE(k->trait == trait, COVGRAM_EINVAL, "kernel trait %d does not match family %d (input_trait would be %d)",
@@ -179,6 +187,10 @@ static int make_simple_kernel(const covgram_kernel* k, int dtype, bool for_gradi
                 kp.gamma = inv_l * sqrt(0.5 * LOG2E);
                 out->eq_folded = true;
             }
+            break;
+        case COVGRAM_EXP:
+            // fp32 dense path: fold log2(e) into the coordinate pre-scale, exp(-r) = exp2(-sqrt(s')) (profiles.hpp: dense_folded)
+            if (!for_gradient && dtype == COVGRAM_F32) { kp.gamma = inv_l * LOG2E; out->eq_folded = true; }
             break;
         case COVGRAM_RQ:
             CG_REQUIRE(k->param > 0, COVGRAM_EINVAL, "DomainError: alpha not positive");
@@ -281,6 +293,23 @@ int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out) {
         w.bytes = want;
     }
     *out = w.ptr;
+    return COVGRAM_OK;
+}
+
+int tickets_reserve(covgram_ctx* ctx, size_t count, unsigned** out) {
+    if (ctx->tickets_cap < count) {
+        if (ctx->tickets) {
+            CG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            CG_CHECK_HIP(hipFree(ctx->tickets));
+            ctx->tickets = nullptr; ctx->tickets_cap = 0;
+        }
+        const size_t want = std::max<size_t>(count, 16384);
+        hipError_t e = hipMalloc((void**)&ctx->tickets, want * sizeof(unsigned));
+        if (e != hipSuccess) { ctx->tickets = nullptr; set_error("hipMalloc(%zu) failed: %s", want * sizeof(unsigned), hipGetErrorString(e)); return COVGRAM_ENOMEM; }
+        CG_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, want * sizeof(unsigned), ctx->stream));
+        ctx->tickets_cap = want;
+    }
+    *out = ctx->tickets;
     return COVGRAM_OK;
 }
 
@@ -472,6 +501,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
     if (ctx->sym_map) (void)hipFree(ctx->sym_map);
     if (ctx->stamp_buf) (void)hipFree(ctx->stamp_buf);
+    if (ctx->tickets) (void)hipFree(ctx->tickets);
     for (auto& t : ctx->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -508,6 +538,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
     else if (!strcmp(key, "dense_sym")) ctx->dense_sym = value;
     else if (!strcmp(key, "mfma_stamp")) ctx->mfma_stamp = value;
+    else if (!strcmp(key, "inkernel_reduce")) ctx->inkernel_reduce = value;
     else if (!strcmp(key, "matrix_variant")) ctx->matrix_variant = value;
     else if (!strcmp(key, "mfma_mrhs")) ctx->mfma_mrhs = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
@@ -523,6 +554,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
+    else if (!strcmp(key, "last_inkernel_reduce")) *value = ctx->last_inkernel_reduce;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
@@ -641,6 +673,28 @@ static int check_pair(const covgram_ctx* ctx, const covgram_points* X, const cov
     CG_REQUIRE(X->dtype == Y->dtype, COVGRAM_EINVAL, "x and y have different dtypes");
     CG_REQUIRE(X->d == Y->d, COVGRAM_EINVAL, "DimensionMismatch: inputs have to have the same length: %d, %d", X->d, Y->d);
     return COVGRAM_OK;
+}
+
+// The direct-difference symmetric kernels (dense_sym_kernel: fp64, 64-row blocks; dense_sym32_kernel: fp32, 64 R-row blocks) on
+// gramian(k, x) for `world` ranks (1: the whole triangle in one launch): a single profile without a Power wrapper, d <= 64, and the
+// column-sum slab — ceil(row blocks / world) x npad scalars, held in workspace slot 4 for the life of the ctx — within `cap_gib` GiB.
+// ONE predicate for covgram_mvm, covgram_mvm_sym_supported and covgram_mvm_sym_partial (the three disagreed on the cap).
+struct DenseSymShape { int64_t blk, blocks, mine, npad; size_t slab_bytes; };
+static bool dense_sym_shape(const HostKernel& hk, const covgram_points* X, int world, int cap_gib, DenseSymShape* out) {
+    if (X->n <= 0 || hk.tu_family >= COVGRAM_NFAMILY || hk.k.power != 1 || world < 1) return false;
+    if (X->d > kDims[kNumDims - 1]) return false;
+    const int D = pad_dim(X->d);
+    if (D < 0 || rows_per_lane_for(D) != 1) return false;
+    DenseSymShape sh;
+    const bool f64 = X->dtype == COVGRAM_F64;
+    sh.blk = f64 ? 64 : 64 * dense_sym32_rows(D);
+    sh.blocks = (X->n + sh.blk - 1) / sh.blk;
+    sh.mine = (sh.blocks + world - 1) / world;
+    sh.npad = f64 ? ((X->n + 63) / 64) * 64 : ((X->n + 511) / 512) * 512;
+    sh.slab_bytes = (size_t)sh.mine * (size_t)sh.npad * dtype_size(X->dtype);
+    if (sh.slab_bytes > ((size_t)cap_gib << 30)) return false;
+    if (out) *out = sh;
+    return true;
 }
 
 // choose the J split: enough workgroups to fill the chip, chunks aligned to the inner accumulation block
@@ -841,14 +895,19 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // slab n^2 / 8 bytes — held in workspace slot 4 for the life of the ctx — stays within 1 GiB (n <= 92681) when the choice is automatic,
     // 2 GiB (n <= 131072) when option "dense_sym" = 1 asks for it; R = 1 row per lane (64-row blocks) is what the kernel is written for.
     const bool cheap_profile = hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ || hk.tu_family == COVGRAM_DOT;
-    // covgram_mvm_sym_partial (fp64): rank r of P evaluates the 64-row blocks r, r + P, ... only (sym_part_world > 0)
+    // covgram_mvm_sym_partial (direct-difference form): rank r of P evaluates the row blocks r, r + P, ... only (sym_part_world > 0)
+    // fp32 (dense_sym32_kernel, round 4): the same form for what the matrix-core path refuses — Exponential, gamma-exponential, MaternP(0),
+    // clouds that fail its radius gate, dense_variant = 1 — from n = 24576 (32768 for the cheap profiles).
     const int sp_world = ctx->sym_part_world, sp_rank = ctx->sym_part_rank;
-    const int64_t sym_blocks = sp_world > 0 ? (rowblocks + sp_world - 1) / sp_world : rowblocks;
-    const bool dsym = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && (ctx->dense_sym != 0 || sp_world > 0) && X->dptr == Y->dptr && n == m &&
-                      hk.tu_family < COVGRAM_NFAMILY && hk.k.power == 1 &&
-                      (ctx->dense_sym == 1 || sp_world > 0 || n >= (cheap_profile ? 16384 : 8192)) &&
-                      R == 1 && (size_t)sym_blocks * (size_t)npad * ts <= ((size_t)((ctx->dense_sym == 1 || sp_world > 0) ? 2 : 1) << 30);
-    if (sp_world > 0 && !dsym) { set_error("the fp64 symmetric direct-difference kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
+    const bool sym_forced = ctx->dense_sym == 1 || sp_world > 0;
+    DenseSymShape symsh{};
+    // fp32 break-even measured at n ~ 22000 (profiles/r04_sym32_sweep.txt: x0.85-0.9 at 16384, x1.2-1.5 at 32768, x1.5-1.85 from 65536)
+    const int64_t sym_min_n = dtype == COVGRAM_F64 ? (cheap_profile ? 16384 : 8192) : (cheap_profile ? 32768 : 24576);
+    const bool dsym = !mfma && !wide && m > 0 && nrhs == 1 && (ctx->dense_sym != 0 || sp_world > 0) && X->dptr == Y->dptr && n == m &&
+                      (sym_forced || n >= sym_min_n) && R == 1 &&
+                      dense_sym_shape(hk, X, sp_world > 0 ? sp_world : 1, sym_forced ? 2 : 1, &symsh);
+    if (sp_world > 0 && !dsym) { set_error("the symmetric direct-difference kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
+    const bool dsym32 = dsym && dtype == COVGRAM_F32;
     ctx->last_dense_sym = dsym ? 1 : 0;
     for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
@@ -867,7 +926,8 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             continue;
         }
         void* P;
-        int64_t mp = ((m + PKN - 1) / PKN) * PKN;           // stream padded to whole column groups
+        const int PADTO = dsym32 ? 8 : PKN;                 // dense_sym32_kernel reduces eight columns at a time
+        int64_t mp = ((m + PADTO - 1) / PADTO) * PADTO;     // stream padded to whole column groups
         if (wide) {                                         // ... or to whole column blocks of the wide kernel
             const int64_t bc = 32 * PKN;
             mp = ((m + bc - 1) / bc) * bc;
@@ -883,10 +943,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
                                    (const double*)Y->dptr, m, Y->d, D, (const double*)a_c, lda_d, nr, 0, (double*)P, NRpad, PKN, 32, hk.kp.gamma, (const double*)Cn);
         } else if (dtype == COVGRAM_F32)
             hipLaunchKernelGGL(dense_pack_kernel<float>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma, (const float*)Cn);
+                               (const float*)Y->dptr, m, Y->d, (const float*)a_c, lda_d, nr, 0, (float*)P, D, NRpad, PKN, (float)hk.kp.gamma, (const float*)Cn, PADTO);
         else
             hipLaunchKernelGGL(dense_pack_kernel<double>, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma, (const double*)Cn);
+                               (const double*)Y->dptr, m, Y->d, (const double*)a_c, lda_d, nr, 0, (double*)P, D, NRpad, PKN, hk.kp.gamma, (const double*)Cn, PADTO);
         int64_t jchunk; int jsplit;
         // chunks are multiples of 64 columns (whole packed pairs); small problems split finer than the 512-column
         // inner accumulation block so that they still expose thousands of waves
@@ -897,6 +957,28 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         da.X = X->dptr; da.n = n; da.d = X->d; da.P = P; da.m = m; da.npad = npad; da.ldy = ldy_d; da.nrhs = nr;
         da.Dpad = D; da.NRpad = NRpad; da.jchunk = jchunk; da.jsplit = jsplit; da.rows_per_lane = R;
         da.variant = (int)ctx->dense_variant; da.lds_pad = (int)ctx->lds_pad; da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
+        if (dsym32) {
+            // fp32: 64 R-row blocks (R rows per lane), chunks of whole 512-column inner blocks; ~64 k workgroups, half of them (left of
+            // the diagonal) leave at once, so that the triangle's long and short rows even out over several rounds of resident waves
+            const int64_t want = std::max<int64_t>(1, std::min<int64_t>((m + 511) / 512, (65536 + symsh.mine - 1) / symsh.mine));
+            const int64_t per = ((m + 511) / 512 + want - 1) / want;
+            da.jchunk = jchunk = per * 512;
+            da.jsplit = jsplit = (int)((((m + 7) & ~(int64_t)7) + jchunk - 1) / jchunk);
+            da.npad = symsh.npad;
+            da.sym = 1;
+            if (sp_world > 0) { da.sym_first = sp_rank; da.sym_stride = sp_world; }
+            ctx->last_jsplit = jsplit;
+            rc = ws_reserve(ctx, 1, (size_t)jsplit * symsh.npad * ts, &da.out); if (rc) return rc;
+            rc = ws_reserve(ctx, 4, symsh.slab_bytes, &da.colslab); if (rc) return rc;
+            auto* tms = timer_next(ctx);
+            if (tms) (void)hipEventRecord(tms->first, ctx->stream);
+            rc = launch(da, dtype); if (rc) return rc;
+            if (tms) (void)hipEventRecord(tms->second, ctx->stream);
+            hipLaunchKernelGGL(dense_sym32_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, (const float*)da.out,
+                               (const float*)da.colslab, symsh.npad, jsplit, (float*)y_c, n, (float)alpha_eff, (float)beta, da.sym_first, da.sym_stride,
+                               (int32_t)symsh.blk);
+            continue;
+        }
         if (dsym) {
             // chunks of whole 64-column blocks; about twice the workgroups of the all-entries launch, half of them (left of the
             // diagonal) leave at once
@@ -908,7 +990,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
             da.sym = 1;
             if (sp_world > 0) { da.sym_first = sp_rank; da.sym_stride = sp_world; }
             rc = ws_reserve(ctx, 1, (size_t)jsplit * npad * ts, &da.out); if (rc) return rc;
-            rc = ws_reserve(ctx, 4, (size_t)std::max<int64_t>(sym_blocks, 1) * npad * ts, &da.colslab); if (rc) return rc;
+            rc = ws_reserve(ctx, 4, symsh.slab_bytes, &da.colslab); if (rc) return rc;
             auto* tms = timer_next(ctx);
             if (tms) (void)hipEventRecord(tms->first, ctx->stream);
             rc = launch(da, dtype); if (rc) return rc;
@@ -919,11 +1001,15 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         }
         if (jsplit == 1) da.out = y_c;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
+        // the lane-per-row kernel sums its own split-J slab (last-arriving workgroup of each 64-row block, fixed order: pack.hpp)
+        const bool ikr = jsplit > 1 && !wide && ctx->inkernel_reduce != 0;
+        ctx->last_inkernel_reduce = ikr ? 1 : 0;
+        if (ikr) { rc = tickets_reserve(ctx, (size_t)rowblocks, &da.tickets); if (rc) return rc; da.yfinal = y_c; }
         auto* tm = timer_next(ctx);
         if (tm) (void)hipEventRecord(tm->first, ctx->stream);
         rc = launch(da, dtype); if (rc) return rc;
         if (tm) (void)hipEventRecord(tm->second, ctx->stream);
-        if (jsplit > 1) {
+        if (jsplit > 1 && !ikr) {
             if (dtype == COVGRAM_F32)
                 hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), nr), dim3(256), 0, ctx->stream,
                                    (const float*)da.out, npad, NRpad, jsplit, (float*)y_c, n, ldy_d, nr, (float)alpha_eff, (float)beta);
@@ -1226,24 +1312,24 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     return COVGRAM_OK;
 }
 
-// fp64: the direct-difference symmetric kernel (dense_sym_kernel) in its partial form — any single profile without a Power wrapper, d <= 64
-static bool dense_sym_partial_ok(const covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X) {
-    if (X->dtype != COVGRAM_F64 || X->n <= 0 || k == nullptr || k->family == COVGRAM_COMPOSITE || k->power != 1) return false;
-    if (X->d > kDims[kNumDims - 1] || pad_dim(X->d) < 0 || rows_per_lane_for(pad_dim(X->d)) != 1) return false;
-    return true;
-}
-
-int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported) {
+int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t world, int32_t* supported) {
     CG_REQUIRE(supported != nullptr, COVGRAM_EINVAL, "NULL argument");
     *supported = 0;
+    CG_REQUIRE(world >= 1, COVGRAM_EINVAL, "world = %d", world);
     int rc = check_pair(ctx, X, X);
     if (rc) return rc;
     if (k == nullptr || k->family == COVGRAM_COMPOSITE) return COVGRAM_OK;
     HostKernel hk;
     rc = make_host_kernel(k, X->dtype, false, &hk);
     if (rc) return rc;
-    if (X->dtype == COVGRAM_F64) { *supported = dense_sym_partial_ok(ctx, k, X) ? 1 : 0; return COVGRAM_OK; }
-    *supported = (X->n > 0 && (mfma_eq_sym_eligible(ctx, hk, X, X, 1) || mfma_gen_sym_eligible(ctx, hk, X, X, 1))) ? 1 : 0;
+    if (X->n <= 0) return COVGRAM_OK;
+    // fp64 (the reference's default element type), and fp32 where no matrix-core kernel takes the pair (profile, cloud): the direct-
+    // difference symmetric kernels over cyclic row blocks, with the SAME shape / slab predicate covgram_mvm applies to the partial call
+    // (it depends on world: a rank's column-sum slab is ceil(row blocks / world) x n scalars, capped at 2 GiB)
+    if (X->dtype == COVGRAM_F64) { *supported = dense_sym_shape(hk, X, world, 2, nullptr) ? 1 : 0; return COVGRAM_OK; }
+    if (mfma_eq_sym_eligible(ctx, hk, X, X, 1) || mfma_gen_sym_eligible(ctx, hk, X, X, 1)) { *supported = 1; return COVGRAM_OK; }
+    if (mfma_eq_eligible(ctx, hk, X, X, 1) || mfma_gen_eligible(ctx, hk, X, X)) return COVGRAM_OK;   // the general matrix-core kernel is the better row shard
+    *supported = dense_sym_shape(hk, X, world, 2, nullptr) ? 1 : 0;
     return COVGRAM_OK;
 }
 
@@ -1252,21 +1338,22 @@ int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const cov
     CG_REQUIRE(world >= 1 && rank >= 0 && rank < world, COVGRAM_EINVAL, "rank %d outside [0, %d)", rank, world);
     CG_REQUIRE(a != nullptr && y != nullptr, COVGRAM_EINVAL, "a or y is NULL");
     int32_t ok = 0;
-    int rc = covgram_mvm_sym_supported(ctx, k, X, &ok);
+    int rc = covgram_mvm_sym_supported(ctx, k, X, world, &ok);
     if (rc) return rc;
-    if (!ok) { set_error("no symmetric kernel applies to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
-    if (X->dtype == COVGRAM_F64) {
-        // the reference's default element type: rank r takes the 64-row blocks r, r + P, ... of the upper triangle on the direct-
-        // difference kernel; the partials of all ranks add up to G a
+    if (!ok) { set_error("no symmetric kernel applies to this kernel / point set / world size"); return COVGRAM_EUNSUPPORTED; }
+    HostKernel hk;
+    rc = make_host_kernel(k, X->dtype, false, &hk);
+    if (rc) return rc;
+    const bool mc = X->dtype == COVGRAM_F32 && (mfma_eq_sym_eligible(ctx, hk, X, X, 1) || mfma_gen_sym_eligible(ctx, hk, X, X, 1));
+    if (!mc) {
+        // rank r takes the row blocks r, r + P, ... of the upper triangle on the direct-difference kernel of the data's precision;
+        // the partials of all ranks add up to G a
         ctx->sym_part_rank = rank; ctx->sym_part_world = world;
         rc = covgram_mvm(ctx, k, X, X, a, X->n, y, X->n, 1, 1.0, 0.0, COVGRAM_DEVICE);
         ctx->sym_part_rank = 0; ctx->sym_part_world = 0;
         return rc;
     }
     CG_DEVICE(ctx);
-    HostKernel hk;
-    rc = make_host_kernel(k, X->dtype, false, &hk);
-    if (rc) return rc;
     ctx->last_dense_path = 2; ctx->last_mfma_sym = 1;
     const bool fast = mfma_eq_sym_eligible(ctx, hk, X, X, 1);
     return mvm_eq_mfma_sym(ctx, hk, X, (const float*)a, (float*)y, 1.0, 0.0, rank, world, fast ? nullptr : k);

@@ -176,6 +176,10 @@ struct covgram_ctx {
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
     int64_t last_dense_sym = 0;
+    int64_t inkernel_reduce = -1; // split-J partials of the dense kernels summed by the last-arriving workgroup of each row block (-1 / 1: yes, 0: the separate reduce launch)
+    int64_t last_inkernel_reduce = 0;
+    unsigned* tickets = nullptr;  // one arrival counter per row block, zero between launches (pack.hpp: last_arrival)
+    size_t tickets_cap = 0;
     int32_t sym_part_rank = 0, sym_part_world = 0;   // set by covgram_mvm_sym_partial around its fp64 call of covgram_mvm: world > 0 = partial form
     int64_t mfma_sym = -1;       // matrix-core EQ path on gramian(k, x): evaluate the upper triangle once (-1 auto, 0 never, 1 always)
     int64_t mfma_lds = -1;       // matrix-core EQ path: 4 waves share the column tiles through LDS (-1 auto, 0 never, 1 always)
@@ -236,6 +240,8 @@ struct covgram_points {
 namespace covgram {
 
 int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out);
+// >= count zeroed arrival counters (grown stream-ordered; they return to zero by themselves after every launch that uses them)
+int tickets_reserve(covgram_ctx* ctx, size_t count, unsigned** out);
 // returns an event pair to record around the dominant kernel, or nullptr when timing is off / the pool is full
 std::pair<hipEvent_t, hipEvent_t>* timer_next(covgram_ctx* ctx);
 inline size_t dtype_size(int dtype) { return dtype == COVGRAM_F64 ? 8 : 4; }
@@ -250,6 +256,7 @@ struct DenseArgs {
     int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
     int32_t lds_pad = 0;                   // dynamic LDS bytes requested only to cap waves per CU (occupancy experiments)
     const void* C = nullptr;               // common centre (d scalars on the device) subtracted from both sides by isotropic kernels
+    unsigned* tickets = nullptr; void* yfinal = nullptr;   // jsplit > 1: the last workgroup of a row block sums the slab into yfinal (pack.hpp: last_arrival)
     int32_t sym = 0; void* colslab = nullptr;   // fp64 gramian(k, x): dense_sym_kernel (upper triangle once) + its [row blocks of this launch][npad] column-sum slab
     int32_t sym_first = 0, sym_stride = 1;      // ... over the 64-row blocks first, first + stride, ... (covgram_mvm_sym_partial: rank, world)
     double alpha, beta;

@@ -1,6 +1,7 @@
 // dense_fam.hip — compiled once per kernel family (-DCOVGRAM_FAM=<covgram_family>) so the nine families
 // build in parallel; exports launch_dense_family_<FAM>.
 #include "dense_mvm.hpp"
+#include "dense_sym32.hpp"
 #include "dense_wide.hpp"
 
 #ifndef COVGRAM_FAM

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
                                                            float alpha, float beta, int32_t final_store, const float* __restrict__ Cn,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps, unsigned* __restrict__ tickets,
+                                                           float* __restrict__ yfinal) {
     // WPB waves per workgroup take consecutive row tiles and walk the SAME column tiles at the same pace (no barrier,
     // nothing shared explicitly): their fragment loads coalesce in the CU's vector L1 instead of each going to L2
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
@@ -295,6 +296,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             out[i] = v;
         } else {
             out[(int64_t)blockIdx.y * npad + i] = res;
+        }
+    }
+    // column split with tickets: the LAST workgroup of this row block to arrive adds the block's partials in dense_reduce_kernel's
+    // order and applies alpha / beta (pack.hpp: last_arrival) — no reduce launch, no dependent-launch gap behind the kernel
+    if (!final_store && tickets != nullptr) {
+        if (!last_arrival(tickets + blockIdx.x, gridDim.y)) return;
+        const int64_t r0 = (int64_t)blockIdx.x * (WPB * 32 * RT);
+        for (int idx = threadIdx.x; idx < WPB * 32 * RT; idx += 64 * WPB) {
+            const int64_t i = r0 + idx;
+            if (i >= n) continue;
+            float v = alpha * ordered_split_sum<float>(out + i, npad, (int)gridDim.y);
+            if (beta != 0.0f) v = __builtin_fmaf(beta, yfinal[i], v);
+            yfinal[i] = v;
         }
     }
 }
@@ -490,23 +504,23 @@ static int mfma_blocks(int rt) {
 template <int K2>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
                         int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn,
-                        unsigned long long* stamps, dim3* launched) {
+                        unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal) {
     constexpr bool NARROW = K2 <= MFMA_NARROW_MAXK2;
     unsigned long long* const ns = nullptr;
     if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         *launched = dim3((grid.x + 7) / 8, grid.y);
-        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
-        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     }
 }
 
@@ -615,11 +629,16 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
         CG_CHECK_HIP(hipMemsetAsync(ctx->stamp_buf, 0, need, ctx->stream));
         stamps = (unsigned long long*)ctx->stamp_buf;
     }
+    // js > 1: the kernel sums its own split-J slab (the last workgroup of each row block to arrive, fixed order; pack.hpp)
+    unsigned* tickets = nullptr;
+    const bool ikr = js > 1 && ctx->inkernel_reduce != 0;
+    ctx->last_inkernel_reduce = ikr ? 1 : 0;
+    if (ikr) { rc = tickets_reserve(ctx, (size_t)rowtiles, &tickets); if (rc) return rc; }
     auto* tm = timer_next(ctx);
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
     ctx->last_mfma_lds = lds4 ? 1 : 0;
     dim3 launched;
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched); break;
+#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
@@ -627,7 +646,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 #undef CG_MFMA_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     if (stamps) ctx->stamp_count = (size_t)launched.x * launched.y;
-    if (js > 1)
+    if (js > 1 && !ikr)
         hipLaunchKernelGGL(dense_reduce_kernel<float>, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float*)out, npad, 1,
                            (int)js, y, n, n, 1, (float)alpha_eff, (float)beta);
     hipError_t e = hipGetLastError();

@@ -61,7 +61,7 @@ __device__ __forceinline__ T dense_phi(T s, const typename ParamsOf<FAM, T>::typ
         if constexpr (POW) v = ipow(v, kp.power);
         return v;
     } else {
-        return phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), POW>(s, kp);
+        return phi_value<FAM, T, dense_folded<FAM, T>, POW>(s, kp);
     }
 }
 
@@ -149,7 +149,8 @@ template <typename T, int FAM, int D, int NR, int R, bool POW>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
     const T* __restrict__ X, int64_t n, int32_t d, const typename Pk<T>::V* __restrict__ P, int64_t m,
     T* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs, int64_t jchunk, T alpha, T beta,
-    int32_t final_store, const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp) {
+    int32_t final_store, const T* __restrict__ Cn, const typename ParamsOf<FAM, T>::type kp, unsigned* __restrict__ tickets,
+    T* __restrict__ yfinal) {
     // Cn: the common centre c (d scalars, the column point set's reference point) that isotropic kernels subtract from BOTH
     // sides before the pre-scale: (x - c) gamma - (y - c) gamma keeps the rounding of the scaled coordinates relative to the
     // cloud's extent, not to its distance from the origin (the reference subtracts first and scales after, src/util.jl:40-47).
@@ -256,6 +257,26 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
 #pragma unroll
             for (int c = 0; c < NR; ++c)
                 out[((int64_t)blockIdx.y * NR + c) * npad + row] = tot[r][c];
+        }
+    }
+    // jsplit > 1 with tickets: the LAST workgroup of this row block to arrive adds the block's partials in dense_reduce_kernel's order
+    // and applies alpha / beta (pack.hpp: last_arrival) — the separate reduce launch and its dependent-launch gap are gone
+    if (!final_store && tickets != nullptr) {
+        if (!last_arrival(tickets + blockIdx.x, gridDim.y)) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row_base + (int64_t)r * DENSE_THREADS + tid;
+            if (row >= n) continue;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if (c < nrhs) {
+                    const T sum = ordered_split_sum<T>(out + (int64_t)c * npad + row, (int64_t)NR * npad, (int)gridDim.y);
+                    T* yp = yfinal + row + (int64_t)c * ldy;
+                    T v = alpha * sum;
+                    if (beta != (T)0) v = cg_fma(beta, *yp, v);
+                    *yp = v;
+                }
+            }
         }
     }
 }
@@ -494,9 +515,10 @@ static int launch_dense_sym_one(const DenseArgs& a) {
 template <typename T>
 __global__ __launch_bounds__(256) void dense_pack_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ A,
                                                          int64_t lda, int32_t nrhs, int32_t c0, T* __restrict__ P, int32_t D,
-                                                         int32_t NR, int32_t PKN, T gamma, const T* __restrict__ Cn) {
+                                                         int32_t NR, int32_t PKN, T gamma, const T* __restrict__ Cn, int32_t PADTO) {
+    // PADTO: a multiple of PKN — the stream ends on a whole group of PADTO columns (dense_sym32_kernel: 8)
     const int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // padded column index
-    const int64_t mp = ((m + PKN - 1) / PKN) * PKN;
+    const int64_t mp = ((m + PADTO - 1) / PADTO) * PADTO;
     if (jj >= mp) return;
     const bool pad = jj >= m;
     const int64_t j = pad ? (m - 1) : jj;
@@ -518,7 +540,7 @@ static int launch_dense_one(const DenseArgs& a) {
     const int final_store = (a.jsplit == 1) ? 1 : 0;
     hipLaunchKernelGGL((dense_mvm_kernel<T, FAM, D, NR, R, POW>), grid, dim3(DENSE_THREADS), (size_t)a.lds_pad, a.stream, (const T*)a.X, a.n,
                        a.d, (const typename Pk<T>::V*)a.P, a.m, (T*)a.out, a.npad, a.ldy, a.nrhs, a.jchunk, (T)a.alpha,
-                       (T)a.beta, final_store, (const T*)a.C, kp);
+                       (T)a.beta, final_store, (const T*)a.C, kp, a.tickets, (T*)a.yfinal);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mvm launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
     return COVGRAM_OK;
@@ -530,11 +552,15 @@ static int launch_dense_one(const DenseArgs& a) {
 template <int D> struct RowsFor { static constexpr int value = 1; };
 inline int rows_per_lane_for(int) { return 1; }
 
+template <int FAM, int D> static int launch_dense_sym32_one(const DenseArgs& a);   // dense_sym32.hpp
+
 template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {
     constexpr int R = RowsFor<D>::value;
     if constexpr (sizeof(T) == 8 && NR == 1 && !fam_is_expr<FAM>)
         if (a.sym) return launch_dense_sym_one<FAM, D>(a);
+    if constexpr (sizeof(T) == 4 && NR == 1 && !fam_is_expr<FAM>)
+        if (a.sym) return launch_dense_sym32_one<FAM, D>(a);
     const bool pow = a.hk->k.power != 1;
     if constexpr (!fam_is_expr<FAM>)   // composites apply Power per factor
         if (pow) return launch_dense_one<T, FAM, D, NR, R, true>(a);

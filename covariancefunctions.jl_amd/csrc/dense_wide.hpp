@@ -120,7 +120,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wide_kernel(const T* __re
         const V* __restrict__ pa = pb + (int64_t)dpad * JG;
 #pragma unroll
         for (int g = 0; g < JG; ++g) {
-            const V kv = PK::map(s[g], [&](T sv) { return phi_value<FAM, T, (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP), POW>(sv, kp); });
+            const V kv = PK::map(s[g], [&](T sv) { return phi_value<FAM, T, dense_folded<FAM, T>, POW>(sv, kp); });
 #pragma unroll
             for (int c = 0; c < NR; ++c) acc[c] = PK::fma(pa[g * NR + c], kv, acc[c]);
         }

@@ -33,4 +33,39 @@ template <> struct Pk<double> {
     template <class F> static __device__ __forceinline__ void map3(V s, F f, V& v, V& d1, V& d2) { f(s, v, d1, d2); }
 };
 
+// ---- split-J partials summed by the LAST workgroup to arrive (round 4) ------------------------------------------------------
+// The dense kernels leave their column-split partials in a slab [split][...][npad]; a second launch used to add them in fixed order.
+// Instead every workgroup of a row block takes a ticket after its slab stores (release fence -> atomic increment at device scope);
+// the one that draws the last ticket (acquire fence) reads all partials of the block — its own included — and sums them in the SAME
+// fixed order the reduce kernel used, so the result is bit-identical and deterministic whatever the arrival order; it also puts the
+// ticket back to 0 for the next launch (kernel boundaries order that).  No float atomics.  One launch and one dependent-launch gap
+// less per MVM: what a small problem or a row shard of a multi-GPU step spends a tenth of its time on.
+__device__ __forceinline__ bool last_arrival(unsigned* __restrict__ ticket, unsigned expected) {
+    __shared__ unsigned flag;
+    __threadfence();                                   // this thread's slab stores are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(ticket, 1u);
+        const unsigned last = (old == expected - 1u) ? 1u : 0u;
+        if (last) atomicExch(ticket, 0u);
+        flag = last;
+    }
+    __syncthreads();
+    const bool last = flag != 0u;
+    if (last) __threadfence();                         // the other workgroups' stores are visible to the loads that follow
+    return last;
+}
+// sum_s partial[s * stride] over s < count in dense_reduce_kernel's order: four chains s = q (mod 4), then (c0 + c1) + (c2 + c3)
+template <typename T>
+__device__ __forceinline__ T ordered_split_sum(const T* __restrict__ partial, int64_t stride, int count) {
+    T c[4] = {(T)0, (T)0, (T)0, (T)0};
+    int s = 0;
+    for (; s + 4 <= count; s += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] += partial[(int64_t)(s + q) * stride];
+    }
+    for (int q = 0; s + q < count; ++q) c[q] += partial[(int64_t)(s + q) * stride];
+    return (c[0] + c[1]) + (c[2] + c[3]);
+}
+
 }  // namespace covgram

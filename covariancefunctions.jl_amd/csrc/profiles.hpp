@@ -338,6 +338,14 @@ template <typename T, bool F>
 struct Phi<COVGRAM_EXP, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>&) { return exp_neg_tab(cg_sqrt(s)); }   // (fp64: the table form, 15 + 1 load; the polynomial cg_exp_neg measured 6 % slower than the library exp here)
 };
+// FOLDED, fp32 dense kernels (round 4): the host pre-scales the coordinates by log2(e) / l, so sqrt(s) IS r log2(e) and
+// exp(-r) = exp2(-sqrt(s)) — v_sqrt_f32 + v_exp_f32 with a free negate, one multiplication fewer per pair (make_host_kernel)
+template <>
+struct Phi<COVGRAM_EXP, float, true> {
+    static __device__ __forceinline__ float eval(float s, const KParams<float>&) { return cg_exp2(-cg_sqrt(s)); }
+};
+// which profiles the dense (value-only) kernels evaluate in their folded form: must agree with make_host_kernel(for_gradient = false)
+template <int FAM, typename T> constexpr bool dense_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP || (FAM == COVGRAM_EXP && sizeof(T) == 4));
 template <typename T, bool F>
 struct Phi<COVGRAM_RQ, T, F> {
     static __device__ __forceinline__ T eval(T s, const KParams<T>& kp) {

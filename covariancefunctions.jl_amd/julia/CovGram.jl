@@ -23,7 +23,7 @@ using LinearAlgebra
 using CovarianceFunctions
 using CovarianceFunctions: Gramian, GradientKernel, ValueGradientKernel, IsotropicInput, DotProductInput, StationaryInput,
                            GenericInput, input_trait, EQ, RQ, Exp, γExp, Cauchy, InverseMultiQuadratic, MaternP, Dot,
-                           ExponentialDot, Lengthscale, Power, Product, Sum, Constant, SeparableProduct, LazyGrid, FiniteBasis
+                           ExponentialDot, Lengthscale, Power, Product, Sum, Constant, SeparableProduct, SeparableKernel, LazyGrid, FiniteBasis
 import CovarianceFunctions: gramian
 import BlockFactorizations
 
@@ -57,7 +57,7 @@ const F_EQ, F_EXP, F_RQ, F_GAMMAEXP, F_CAUCHY, F_IMQ, F_MATERNP, F_DOT, F_EXPDOT
 const F_CONSTANT, F_COMPOSITE = Int32(100), Int32(101)
 const ISO, DOTP = Int32(1), Int32(2)
 const HOST, DEVICE = Int32(0), Int32(1)
-const ABI_VERSION = 111              # COVGRAM_VERSION of the header these ccall signatures mirror
+const ABI_VERSION = 112              # COVGRAM_VERSION of the header these ccall signatures mirror
 dtype_code(::Type{Float32}) = Int32(0); dtype_code(::Type{Float64}) = Int32(1)
 const DevFloat = Union{Float32, Float64}
 
@@ -258,17 +258,50 @@ function LinearAlgebra.mul!(y::StridedVector{T}, B::BlockFactorizations.BlockFac
     spec === nothing ? invoke(mul!, Tuple{AbstractVector, BlockFactorizations.BlockFactorization, AbstractVector, Real, Real}, y, B, a, α, β) :
                        device_blockmul!(:valgrad, y, G, a, α, β, spec)
 end
+function LinearAlgebra.mul!(Y::StridedMatrix{T}, B::BlockFactorizations.BlockFactorization{T, <:Gramian{<:Any, <:ValueGradientKernel}},
+                            A::StridedMatrix{T}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    G = B.A
+    spec = device_kernel_for(G.k.k)
+    spec === nothing ? invoke(mul!, Tuple{AbstractMatrix, BlockFactorizations.BlockFactorization, AbstractMatrix, Real, Real}, Y, B, A, α, β) :
+                       device_blockmul!(:valgrad, Y, G, A, α, β, spec)
+end
+
+# --- src/separable.jl:38-42: mul!(y, G::Gramian{<:AbstractMatrix, <:SeparableKernel}, x) on vectors of vectors -----------------
+# The reference multiplies by kronecker(G) = gramian(k.k, x, y) ⊗ k.B (:33-35): block i of the result is B Σ_j k(x_i, y_j) a_j.  With
+# the blocks of `a` as the ROWS of an m × q matrix that is (G_scalar A) Bᵀ: ONE covgram_mvm with q right-hand sides (every entry of
+# the scalar Gramian evaluated once, O(n) memory — the Kronecker factor is never densified) and an n × q by q × p host product.
+function LinearAlgebra.mul!(y::AbstractVector{<:AbstractVector{T}}, G::Gramian{<:AbstractMatrix, <:SeparableKernel},
+                            a::AbstractVector{<:AbstractVector{T}}) where {T <: DevFloat}
+    spec = device_kernel_for(G.k.k)
+    spec === nothing && return invoke(mul!, Tuple{CovarianceFunctions.AbstractVecOfVec, Gramian{<:AbstractMatrix, <:SeparableKernel}, CovarianceFunctions.AbstractVecOfVec}, y, G, a)
+    n, m = length(G.x), length(G.y); Bm = G.k.B; p, q = size(Bm)
+    (length(a) == m && length(y) == n) || throw(DimensionMismatch("mul!: $(length(y)) / $(length(a)) blocks for a $n × $m block Gramian"))
+    A = Matrix{T}(undef, m, q)
+    for j in 1:m
+        length(a[j]) == q || throw(DimensionMismatch("mul!: block $j of a has length $(length(a[j])) ≠ $q"))
+        A[j, :] .= a[j]
+    end
+    GA = Matrix{T}(undef, n, q)
+    device_mul!(GA, Gramian(G.k.k, G.x, G.y), A, 1, 0, spec)
+    for i in 1:n
+        mul!(y[i], Bm, view(GA, i, :))
+    end
+    return y
+end
 
 # --- multi-GPU symmetric form (one Julia process per GPU, e.g. under MPI.jl; x and a replicated) -----------------------
-# rank r of `world` evaluates the upper-triangle tiles of gramian(k, x) in the 256-row panels p % world == r and returns the
-# partial product of those entries and their mirror images in `part` (device memory); an all-reduce (sum) of `part` over the
-# ranks is G * a.  `covgram_mvm_sym_supported` tells whether the symmetric matrix-core kernel serves (k, x) — it depends on k
-# and x only, so all ranks take the same branch; otherwise shard rows and all-gather (covgram_mvm on X[lo:hi] × X).
-function sym_partial!(part::Ptr{Cvoid}, G::Gramian, a::Ptr{Cvoid}, rank::Integer, world::Integer)
+# rank r of `world` evaluates its cyclic share of the upper triangle of gramian(k, x) — 256-row panels on the symmetric matrix-core
+# kernels (Float32), 64-row / 64 R-row blocks on the direct-difference symmetric kernels (Float64, and Float32 where the matrix cores
+# do not apply) — and returns the partial product of those entries and their mirror images in `part` (device memory); an all-reduce
+# (sum) of `part` over the ranks is G * a.  `covgram_mvm_sym_supported` tells whether a symmetric kernel serves (k, x) at this world
+# size — it depends on k, x and world only, so all ranks take the same branch; otherwise shard rows and all-gather (covgram_mvm on
+# X[lo:hi] × X).  The element type is the Gramian's own (src/gramian.jl:27-33).
+function sym_partial!(part::Ptr{Cvoid}, G::Gramian{T}, a::Ptr{Cvoid}, rank::Integer, world::Integer) where {T <: DevFloat}
     spec = device_kernel(G.k); spec === nothing && return false
-    X = points(G.x, Float32)
+    X = points(G.x, T)
     ok = Ref{Int32}(0)
-    check(ccall((:covgram_mvm_sym_supported, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}), ctx(), kref(spec), X.handle, ok))
+    check(ccall((:covgram_mvm_sym_supported, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Int32}),
+                ctx(), kref(spec), X.handle, Int32(world), ok))
     ok[] == 1 || return false
     check(ccall((:covgram_mvm_sym_partial, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32),
                 ctx(), kref(spec), X.handle, a, part, Int32(rank), Int32(world)))
@@ -342,14 +375,20 @@ function device_trench(r::Vector{T}) where {T <: DevFloat}
 end
 device_levinson(A::DeviceToeplitz{T}, b::Vector{T}) where {T} = device_levinson(A.vc[2:end] ./ A.vc[1], b) ./ A.vc[1]
 device_trench(A::DeviceToeplitz) = Symmetric(parent(device_trench(A.vc[2:end] ./ A.vc[1])) ./ A.vc[1])
-# `\`: Levinson is ONE launch of n - 1 dependent O(n) steps on one workgroup (n <= 16384: state in registers and LDS, 28 ms at n = 16384
-# fp64; above that the vectors live in global memory, ~8 us a step, growing with n²; the library refuses
-# it above COVGRAM_TOEPLITZ_DIRECT_MAX_N = 65536), so it serves the small systems only; larger ones go to conjugate gradients over the FFT
-# MVM (`mul!` above: covgram_toeplitz_mvm), the reference's own solver for lazy operators (src/gramian.jl:229-238).
-const LEVINSON_MAX_N = 16384
+# `\`: the reference's `\` on a SymmetricToeplitz is a DIRECT solve, and so is this one wherever the library serves it: Levinson is ONE
+# launch of n - 1 dependent O(n) steps on one workgroup (n <= 16384: state in registers and LDS, 28 ms at n = 16384 fp64; above that the
+# vectors live in global memory, ~8 us a step), up to COVGRAM_TOEPLITZ_DIRECT_MAX_N = 65536.  Beyond it the library returns
+# COVGRAM_EUNSUPPORTED and the solve is conjugate gradients over the FFT MVM (`mul!` above: covgram_toeplitz_mvm; the reference's own
+# solver for lazy operators, src/gramian.jl:229-238) with an explicit tolerance, and it ERRORS when CG did not converge — noise-free
+# Gramians are ill-conditioned, and IterativeSolvers.cg returns its last iterate silently (ADVICE r3).
+const TOEPLITZ_DIRECT_MAX_N = 65536          # COVGRAM_TOEPLITZ_DIRECT_MAX_N
 function LinearAlgebra.:\(A::DeviceToeplitz{T}, b::Vector{T}) where {T}
     issymmetric(A) || error("only symmetric Toeplitz solves are served")
-    length(b) <= LEVINSON_MAX_N ? device_levinson(A, b) : CovarianceFunctions.IterativeSolvers.cg(A, b)
+    length(b) <= TOEPLITZ_DIRECT_MAX_N && return device_levinson(A, b)
+    x, hist = CovarianceFunctions.IterativeSolvers.cg(A, b; reltol = eps(T)^(2 / 3), maxiter = 4 * ceil(Int, sqrt(length(b))) + 200, log = true)
+    hist.isconverged || error("Toeplitz solve of order $(length(b)): CG over the FFT MVM did not converge in $(hist.iters) iterations " *
+                              "(relative tolerance $(eps(T)^(2 / 3))); add a noise term or use a preconditioned solver")
+    x
 end
 
 # --- Kronecker (src/algebra.jl:91-95, src/separable.jl:33-42): dense factors, mode products on the matrix cores (csrc/kron.hip) --

@@ -45,8 +45,10 @@
 extern "C" {
 #endif
 
-#define COVGRAM_VERSION 111 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); 111 adds
-                               covgram_cg_step_shifted.  A binding checks covgram_version() against the header it mirrors at load time */
+#define COVGRAM_VERSION 112 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); 111 adds
+                               covgram_cg_step_shifted; 112: covgram_mvm_sym_supported takes `world` (the symmetric partial form's
+                               column-sum slab depends on it), fp32 direct-difference symmetric partials.
+                               A binding checks covgram_version() against the header it mirrors at load time */
 
 typedef enum covgram_status {
     COVGRAM_OK = 0,
@@ -152,12 +154,15 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
  * gamma^2 R^2 <= 1000 of their common centre, 0 = never, 1 = always),
+ * "inkernel_reduce" (the dense kernels' column-split partials: -1 / 1 = summed inside the kernel by the last workgroup of each row block
+ * to arrive — fixed order, bit-identical to the separate launch, one launch and one dependent-launch gap less per MVM —, 0 = the separate
+ * reduce launch),
  * "mfma_stamp" (1 = the general matrix-core EQ kernel runs its clock-stamping DIAGNOSTIC build — s_memtime / s_memrealtime
  * around every workgroup's column loop, for bench.py's sustained-clock figure; never set in production). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran the fp64 direct-difference symmetric kernel), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_jsplit" (the column split of the last lane-per-row dense launch), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_jsplit" (the column split of the last lane-per-row dense launch), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
@@ -190,13 +195,16 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
  * evaluates the upper-triangle tiles of gramian(k, x) whose 256-row panel p satisfies p % world == r — cyclic, so every rank
  * gets the same share of the triangle — and returns in y (n scalars, device) the partial product of those entries AND their
  * mirror images; the partials of all ranks add up to G a, so ONE all-reduce (RCCL) completes b on every rank
- * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).  fp64 (the reference's default element type): the
- * direct-difference symmetric kernel over the cyclic 64-row blocks p % world == rank — any single profile without a Power wrapper, d <= 64.
- * fp32: only where the symmetric
- * matrix-core kernels apply (fp32, EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm gate, n from 12500 ... 18000 by profile or option "mfma_sym" = 1): `*supported` of
- * covgram_mvm_sym_supported says so (identically on every rank: it depends on k and x only), and
- * covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED otherwise — callers then shard rows and all-gather (covgram_mvm). */
-int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t* supported);
+ * (the rows of src/gramian.jl:81 are independent, and so are the unordered pairs {i, j}).
+ * fp32: the symmetric matrix-core kernels where they apply (EQ / RQ / Cauchy / IMQ / MaternP(p >= 1) / Dot^p / ExponentialDot, d <= 32, norm
+ * gate, n from 12500 ... 18000 by profile or option "mfma_sym" = 1).  Where NO matrix-core kernel takes the pair (Exponential,
+ * gamma-exponential, MaternP(0), clouds outside the norm gate) and in fp64 (the reference's default element type): the direct-difference
+ * symmetric kernels over the cyclic row blocks p % world == rank (64 rows in fp64, 64 R rows in fp32, R = 4 / 2 / 1 for d <= 8 / 32 / 64) —
+ * any single profile without a Power wrapper, d <= 64, as long as one rank's column-sum slab, ceil(row blocks / world) x n scalars, stays
+ * within 2 GiB (it lives in the ctx's workspace).  `*supported` of covgram_mvm_sym_supported says so for the given `world` (identically on
+ * every rank: it depends on k, x and world only), and covgram_mvm_sym_partial returns COVGRAM_EUNSUPPORTED exactly when it says 0 —
+ * callers then shard rows and all-gather (covgram_mvm). */
+int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t world, int32_t* supported);
 int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y,
                             int32_t rank, int32_t world);
 

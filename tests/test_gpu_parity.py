@@ -848,7 +848,7 @@ def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
                     tot += part
                 assert relerr(tot.cpu().numpy(), want) <= 1e-5, (n, d, world, relerr(tot.cpu().numpy(), want))
         assert cg.gramian(cg.MaternP(2), Xd).sym_partial_supported()             # every smooth matrix-core profile
-        assert not cg.gramian(cg.Exp(), Xd).sym_partial_supported()                # not differentiable in s at 0: direct differences only
+        assert cg.gramian(cg.Exp(), Xd).sym_partial_supported()                    # not differentiable in s at 0: the DIRECT-difference symmetric kernel (round 4, tests/test_gpu_sym32.py)
         assert cg.gramian(cg.EQ(), Xd.double()).sym_partial_supported()          # fp64: 64-row blocks of the direct-difference kernel (tests/test_gpu_sym_partial64.py)
         assert not cg.gramian(cg.EQ(), Xd, Xd.clone()).sym_partial_supported()
         cg.set_option("mfma_sym", -1)
