@@ -11,6 +11,7 @@
 #include "dense_sym32.hpp"
 #include "dense_wide.hpp"
 #include "grad_mvm.hpp"
+#include "grad_bcast.hpp"
 #include "grad_wide.hpp"
 
 namespace covgram {
@@ -448,6 +449,12 @@ using namespace covgram;
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// the automatic choice of the broadcast kernel by padded dimension (tools/c4_bcast_ab.py, profiles/r04_c4_bcast_ab.txt: n = 16384, EQ,
+// scalar stream -> broadcast, four waves per workgroup: d = 8 x0.91, 16 x0.95, 24 x1.23, 32 (C4) x1.25, 48 x1.83)
+#ifndef GRAD_BCAST_AUTO
+#define GRAD_BCAST_AUTO(D) ((D) >= 24 ? 4 : 0)
+#endif
+
 extern "C" {
 
 int covgram_version(void) { return COVGRAM_VERSION; }
@@ -533,6 +540,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "target_wgs")) ctx->target_wgs = value;
     else if (!strcmp(key, "grad_keep_r")) ctx->grad_keep_r = value;
     else if (!strcmp(key, "grad_expand")) ctx->grad_expand = value;
+    else if (!strcmp(key, "grad_bcast")) ctx->grad_bcast = value;
     else if (!strcmp(key, "lds_pad")) ctx->lds_pad = value;
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
@@ -556,6 +564,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
     else if (!strcmp(key, "last_inkernel_reduce")) *value = ctx->last_inkernel_reduce;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
+    else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
         // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none
@@ -1001,8 +1010,10 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         }
         if (jsplit == 1) da.out = y_c;
         else { rc = ws_reserve(ctx, 1, (size_t)jsplit * NRpad * npad * ts, &da.out); if (rc) return rc; }
-        // the lane-per-row kernel sums its own split-J slab (last-arriving workgroup of each 64-row block, fixed order: pack.hpp)
-        const bool ikr = jsplit > 1 && !wide && ctx->inkernel_reduce != 0;
+        // the lane-per-row kernel can sum its own split-J slab (last-arriving workgroup of each 64-row block, fixed order: pack.hpp) — only
+        // on request: its column splits are fine (64 at C1's size), and 64 tickets on one counter plus the uncached re-read cost more than
+        // the launch they save (profiles/r04_inkernel_reduce_ab.txt: C1 27.1 -> 39.0 us, n = 16384 259 -> 262)
+        const bool ikr = jsplit > 1 && !wide && ctx->inkernel_reduce == 1;
         ctx->last_inkernel_reduce = ikr ? 1 : 0;
         if (ikr) { rc = tickets_reserve(ctx, (size_t)rowblocks, &da.tickets); if (rc) return rc; da.yfinal = y_c; }
         auto* tm = timer_next(ctx);
@@ -1156,8 +1167,25 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     const int64_t npad = rowblocks * GRAD_THREADS;
     // two right-hand sides per pass where the lane-per-row kernel is compiled for it (grad_mvm.hpp: r, s, phi', phi'' once per pair)
     const bool two_ok = !wide && m > 0 && hk.k.power == 1 && grad_two_rhs_ok(ts, D, hk.tu_family);
+    // expanded form (grad_mvm.hpp): fp64 isotropic simple profiles whose pre-scaled clouds lie within the radius gate
+    const bool expd_ok = !wide && m > 0 && iso && dtype == COVGRAM_F64 && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 &&
+                          (ctx->grad_expand == 1 ||
+                           // measured (tools/c4_expand_ab.py, profiles/r02_c4_expand_ab.txt): pays from d = 8 (C4 0.86x, d = 8 0.95x,
+                           // d = 3 +4 %); MaternP(p >= 1) 0.89x since its exp(-r) is the library's own (it was +3 % with the
+                           // 34-instruction one).  Never by default for the profiles that are singular at s = 0 (exponential,
+                           // gamma-exponential, MaternP(0)): their diagonal blocks are NaN in the reference (inf * 0), which the
+                           // exact zero of a direct difference reproduces and the rounded zero of the expanded form would not
+                           (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
+                            hk.tu_family != COVGRAM_GAMMAEXP && !(hk.tu_family == COVGRAM_MATERNP && hk.k.p == 0) &&
+                            hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
+    // round 4: the expanded form with the column records in VGPRs (grad_bcast.hpp; option "grad_bcast": -1 auto, 0 never, 1 / 4 = with
+    // that many waves per workgroup).  One right-hand side per pass: where it applies, matrix right-hand sides run column by column on it
+    // (C4 shape: 2 x 1.36 ms against 3.30 ms for the scalar-stream kernel's two-column pass)
+    int bcast_sel = 0;
+    if (expd_ok && hk.k.power == 1 && grad_bcast_ok(D) && hk.tu_family != COVGRAM_MATERN && ctx->grad_bcast != 0)
+        bcast_sel = ctx->grad_bcast == 1 ? 1 : (ctx->grad_bcast == 4 ? 4 : GRAD_BCAST_AUTO(D));
     for (int c0 = 0; c0 < nrhs;) {
-    const int nr = (two_ok && c0 + 1 < nrhs) ? 2 : 1;
+    const int nr = (two_ok && !bcast_sel && c0 + 1 < nrhs) ? 2 : 1;
     const void* a_dev = (const char*)a_all + (size_t)c0 * lda_d * ts;
     void* y_dev = (char*)y_all + (size_t)c0 * ldy_d * ts;
     const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)bd, (unsigned)nr);
@@ -1226,16 +1254,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         void* P;
         // + 1 prefetch-only record; the value weights A0[0..m] of the value-gradient variant follow the stream
         // expanded form (grad_mvm.hpp): fp64 isotropic simple profiles whose pre-scaled clouds lie within the radius gate
-        const bool expd = iso && dtype == COVGRAM_F64 && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 &&
-                          (ctx->grad_expand == 1 ||
-                           // measured (tools/c4_expand_ab.py, profiles/r02_c4_expand_ab.txt): pays from d = 8 (C4 0.86x, d = 8 0.95x,
-                           // d = 3 +4 %); MaternP(p >= 1) 0.89x since its exp(-r) is the library's own (it was +3 % with the
-                           // 34-instruction one).  Never by default for the profiles that are singular at s = 0 (exponential,
-                           // gamma-exponential, MaternP(0)): their diagonal blocks are NaN in the reference (inf * 0), which the
-                           // exact zero of a direct difference reproduces and the rounded zero of the expanded form would not
-                           (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
-                            hk.tu_family != COVGRAM_GAMMAEXP && !(hk.tu_family == COVGRAM_MATERNP && hk.k.p == 0) &&
-                            hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
+        const bool expd = expd_ok;
         rc = ws_reserve(ctx, 0, (size_t)(m + 1) * ((1 + nr) * D + nr * vg + (expd ? 1 + nr : 0)) * ts, &P); if (rc) return rc;
         void* A0 = vg ? (void*)((char*)P + (size_t)(m + 1) * (1 + nr) * D * ts) : nullptr;
         void* Ex = expd ? (void*)((char*)P + (size_t)(m + 1) * ((1 + nr) * D + nr * vg) * ts) : nullptr;
@@ -1252,7 +1271,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
-        const int gthreads = grad_block_threads((int)ts, D, hk.tu_family);          // 64 or 256 threads per workgroup (grad_mvm.hpp)
+        // round 4: the expanded form with the column records in VGPRs (grad_bcast.hpp; option "grad_bcast": -1 auto, 0 never, 1 / 4 = with
+        // that many waves per workgroup)
+        const int bcast = bcast_sel;
+        ctx->last_grad_bcast = bcast;
+        const int bwaves = std::max(1, std::min(4, 512 / (4 * D + 4 * ((2 * D + 15) / 16) + 44)));   // grad_bcast_waves<D>()
+        const int gthreads = bcast ? 64 * bcast : grad_block_threads((int)ts, D, hk.tu_family);          // 64 or 256 threads per workgroup (grad_mvm.hpp)
         // Column split: about 64 waves per CU over the launch (round 1's sweep), then (round 2, tools/c4_jsplit_sweep.py)
         //  * capped so that the partial slabs (split x n x d results, written here and read back by the reduction) stay inside the
         //    256 MB Infinity Cache — C4 at 64 splits writes 268 MB, d = 48 403 MB: 3.86 ms against 3.61 at 48 splits —
@@ -1263,7 +1287,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         //  profiles at the C4 shape lose 1.5 % (MaternP(2) 2.33 -> 2.37, RQ 3.60 -> 3.66): their slab is the same 268 MB but a
         //  smaller share of a longer kernel.
         const int64_t growwgs = (n + gthreads - 1) / gthreads;
-        const int64_t gslots = (int64_t)ctx->num_cus * 4 * grad_waves_per_simd((int)ts, D, hk.tu_family) / (gthreads / 64);
+        const int64_t gslots = (int64_t)ctx->num_cus * 4 * (bcast ? bwaves : grad_waves_per_simd((int)ts, D, hk.tu_family)) / (gthreads / 64);
         int64_t gsplit = std::max<int64_t>(1, ((int64_t)ctx->num_cus * 64 * 64 / gthreads + growwgs - 1) / growwgs);
         gsplit = std::min(gsplit, std::max<int64_t>(1, m / 64));   // >= 64 columns per workgroup: below that its prologue and slab rows dominate
                                                                     // (tools/c4_jsplit_sweep.py small: n = 4096, d = 8: 16-column chunks 0.109 ms, 64-column 0.059)
@@ -1282,7 +1306,7 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         ga.X = X->dptr; ga.n = n; ga.d = d; ga.P = P; ga.m = m; ga.npad = npad; ga.Dpad = D; ga.jchunk = jchunk; ga.jsplit = jsplit; ga.keep_r = (int)ctx->grad_keep_r;
         ga.alpha = alpha_eff; ga.beta = beta; ga.hk = &hk; ga.stream = ctx->stream;
         ga.vg = vg; ga.A0 = A0; ga.alpha0 = alpha0;
-        ga.expd = expd ? 1 : 0; ga.Ex = Ex;
+        ga.expd = expd ? 1 : 0; ga.Ex = Ex; ga.bcast = bcast;
         ga.nr = nr; ga.ldy = ldy_d;
         ctx->last_grad_expand = ga.expd;
         ga.vg_c = (iso ? -1.0 : 1.0) / hk.kp.gamma;

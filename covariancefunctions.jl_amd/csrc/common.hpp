@@ -172,6 +172,8 @@ struct covgram_ctx {
     int64_t target_wgs = 0;      // 0 = auto (CUs * 8)
     int64_t grad_expand = -1;    // fp64 isotropic gradient Gramians in the expanded form (4 fma per dimension and pair): -1 inside the radius gate, 0 never, 1 always
     int64_t grad_keep_r = -1;    // -1 auto
+    int64_t grad_bcast = -1;     // fp64 expanded-form gradient MVM with the column records in VGPRs (v_fmac_f64_dpp row_newbcast): -1 auto, 0 never, 1 / 4 = always with that many waves per workgroup
+    int64_t last_grad_bcast = 0;
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
@@ -281,6 +283,7 @@ struct GradArgs {
     int64_t ldy = 0;                       // elements between the outputs of two right-hand sides
     int32_t expd = 0;                      // 1: expanded form (fp64 isotropic): Ex holds (|y'_j|^2, y'_j . a_j^(0..nr-1)) per column, m + 1 entries
     const void* Ex = nullptr;
+    int32_t bcast = 0;                     // expanded form with the records in VGPRs (grad_bcast.hpp): waves per workgroup (1 / 4), 0 = the scalar-stream kernel
     double alpha, beta;
     const HostKernel* hk;
     hipStream_t stream;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             if (beta != 0.0f) v = __builtin_fmaf(beta, out[i], v);
             out[i] = v;
         } else {
-            out[(int64_t)blockIdx.y * npad + i] = res;
+            slab_store(out + (int64_t)blockIdx.y * npad + i, res, tickets != nullptr);
         }
     }
     // column split with tickets: the LAST workgroup of this row block to arrive adds the block's partials in dense_reduce_kernel's
@@ -629,9 +629,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
         CG_CHECK_HIP(hipMemsetAsync(ctx->stamp_buf, 0, need, ctx->stream));
         stamps = (unsigned long long*)ctx->stamp_buf;
     }
-    // js > 1: the kernel sums its own split-J slab (the last workgroup of each row block to arrive, fixed order; pack.hpp)
+    // js > 1: the kernel can sum its own split-J slab (the last workgroup of each row block to arrive, fixed order; pack.hpp).  Measured
+    // (profiles/r04_inkernel_reduce_ab.txt, separate launch -> in-kernel): n = 2048 16.2 -> 13.2 us, 4096 16.3 -> 14.9, 8192 17.2 -> 18.8,
+    // 16384 37.9 -> 37.2, rank 0 of 8's shard of C2 214.4 -> 213.5, of 16 116.3 -> 115.0: it pays where the whole MVM is launch latency
+    // and is noise elsewhere, so the automatic rule takes it up to n = 4096 (option "inkernel_reduce" = 1 / 0 forces it on / off)
     unsigned* tickets = nullptr;
-    const bool ikr = js > 1 && ctx->inkernel_reduce != 0;
+    const bool ikr = js > 1 && (ctx->inkernel_reduce == 1 || (ctx->inkernel_reduce < 0 && n <= 4096));
     ctx->last_inkernel_reduce = ikr ? 1 : 0;
     if (ikr) { rc = tickets_reserve(ctx, (size_t)rowtiles, &tickets); if (rc) return rc; }
     auto* tm = timer_next(ctx);

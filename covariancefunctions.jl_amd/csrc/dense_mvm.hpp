@@ -256,7 +256,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_mvm_kernel(
         } else {
 #pragma unroll
             for (int c = 0; c < NR; ++c)
-                out[((int64_t)blockIdx.y * NR + c) * npad + row] = tot[r][c];
+                slab_store(out + ((int64_t)blockIdx.y * NR + c) * npad + row, tot[r][c], tickets != nullptr);
         }
     }
     // jsplit > 1 with tickets: the LAST workgroup of this row block to arrive adds the block's partials in dense_reduce_kernel's order

@@ -1,6 +1,7 @@
 // grad_fam.hip — compiled once per kernel family (-DCOVGRAM_FAM=<covgram_family>); exports
 // launch_grad_family_<FAM>.
 #include "grad_mvm.hpp"
+#include "grad_bcast.hpp"
 #include "grad_wide.hpp"
 
 #ifndef COVGRAM_FAM

@@ -444,8 +444,19 @@ __global__ __launch_bounds__(256) void grad_pack_extra_kernel(const T* __restric
     for (int rr = 0; rr < nr; ++rr) Ex[(1 + nr) * j + 1 + rr] = ya[rr];
 }
 
+template <int FAM, int D> static bool launch_grad_bcast(const GradArgs& a);   // grad_bcast.hpp
+
 template <typename T, int FAM, int D>
 static int launch_grad_one(const GradArgs& a) {
+    if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
+        if (a.bcast && a.expd && a.nr == 1 && a.hk->k.power == 1) {
+            if (launch_grad_bcast<FAM, D>(a)) {
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { set_error("grad_bcast launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
+                return COVGRAM_OK;
+            }
+        }
+    }
     const typename ParamsOf<FAM, T>::type kp = make_params<FAM, T>(*a.hk);
     const int threads = grad_block_threads((int)sizeof(T), D, FAM);
     dim3 grid((unsigned)((a.n + threads - 1) / threads), (unsigned)a.jsplit);

@@ -35,25 +35,36 @@ template <> struct Pk<double> {
 
 // ---- split-J partials summed by the LAST workgroup to arrive (round 4) ------------------------------------------------------
 // The dense kernels leave their column-split partials in a slab [split][...][npad]; a second launch used to add them in fixed order.
-// Instead every workgroup of a row block takes a ticket after its slab stores (release fence -> atomic increment at device scope);
-// the one that draws the last ticket (acquire fence) reads all partials of the block — its own included — and sums them in the SAME
-// fixed order the reduce kernel used, so the result is bit-identical and deterministic whatever the arrival order; it also puts the
-// ticket back to 0 for the next launch (kernel boundaries order that).  No float atomics.  One launch and one dependent-launch gap
-// less per MVM: what a small problem or a row shard of a multi-GPU step spends a tenth of its time on.
+// Instead every workgroup of a row block takes a ticket after its slab stores; the one that draws the last ticket reads all partials of
+// the block — its own included — and sums them in the SAME fixed order the reduce kernel used, so the result is bit-identical and
+// deterministic whatever the arrival order; it also puts the ticket back to 0 for the next launch (kernel boundaries order that).
+// No float atomics.  One launch and one dependent-launch gap less per MVM.
+// Coherence across the eight XCDs (each has its own L2): NOT by __threadfence() — at device scope that is a write-back plus an
+// invalidate of the whole L2 per workgroup, measured at +200 us on a 230 us row shard and 29 -> 90 us on C1
+// (profiles/r04_inkernel_reduce_ab.txt, first build).  The slab traffic of a ticketed launch goes AROUND the non-coherent lines
+// instead: partials are stored and re-read with device-scope relaxed atomic accesses (global_store / global_load ... sc1: written
+// through to, and read from, the memory side), the stores are waited for (s_waitcnt vmcnt(0)) before the ticket is taken, and the
+// ticket is a device-scope atomic add.
+template <typename T>
+__device__ __forceinline__ void slab_store(T* p, T v, bool ticketed) {
+    if (ticketed) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <typename T>
+__device__ __forceinline__ T slab_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ bool last_arrival(unsigned* __restrict__ ticket, unsigned expected) {
     __shared__ unsigned flag;
-    __threadfence();                                   // this thread's slab stores are visible device-wide before the ticket is taken
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's write-through slab stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = atomicAdd(ticket, 1u);
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = (old == expected - 1u) ? 1u : 0u;
-        if (last) atomicExch(ticket, 0u);
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag = last;
     }
     __syncthreads();
-    const bool last = flag != 0u;
-    if (last) __threadfence();                         // the other workgroups' stores are visible to the loads that follow
-    return last;
+    return flag != 0u;
 }
 // sum_s partial[s * stride] over s < count in dense_reduce_kernel's order: four chains s = q (mod 4), then (c0 + c1) + (c2 + c3)
 template <typename T>
@@ -62,9 +73,9 @@ __device__ __forceinline__ T ordered_split_sum(const T* __restrict__ partial, in
     int s = 0;
     for (; s + 4 <= count; s += 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] += partial[(int64_t)(s + q) * stride];
+        for (int q = 0; q < 4; ++q) c[q] += slab_load(partial + (int64_t)(s + q) * stride);
     }
-    for (int q = 0; s + q < count; ++q) c[q] += partial[(int64_t)(s + q) * stride];
+    for (int q = 0; s + q < count; ++q) c[q] += slab_load(partial + (int64_t)(s + q) * stride);
     return (c[0] + c[1]) + (c[2] + c[3]);
 }
 

@@ -154,15 +154,18 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
  * gamma^2 R^2 <= 1000 of their common centre, 0 = never, 1 = always),
- * "inkernel_reduce" (the dense kernels' column-split partials: -1 / 1 = summed inside the kernel by the last workgroup of each row block
+ * "inkernel_reduce" (the dense kernels' column-split partials: 1 = summed inside the kernel by the last workgroup of each row block
  * to arrive — fixed order, bit-identical to the separate launch, one launch and one dependent-launch gap less per MVM —, 0 = the separate
- * reduce launch),
+ * reduce launch, -1 = in the kernel only where it measured faster: the matrix-core EQ kernel up to n = 4096),
+ * "grad_bcast" (fp64 expanded-form gradient / value-gradient MVM with the column records in vector registers, read by
+ * v_fmac_f64_dpp row_newbcast — counted vector loads instead of the scalar stream: -1 = from padded d = 24, 0 = never, 1 / 4 = always,
+ * with that many waves per workgroup),
  * "mfma_stamp" (1 = the general matrix-core EQ kernel runs its clock-stamping DIAGNOSTIC build — s_memtime / s_memrealtime
  * around every workgroup's column loop, for bench.py's sustained-clock figure; never set in production). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_jsplit" (the column split of the last lane-per-row dense launch), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_jsplit" (the column split of the last lane-per-row dense launch), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);

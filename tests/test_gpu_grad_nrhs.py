@@ -93,24 +93,38 @@ def test_two_columns_share_the_pair_evaluations_at_the_c4_shape(cg):
     rng = np.random.default_rng(74)
     n, d = 16384, 32
     X = torch.from_numpy(rng.standard_normal((n, d))).cuda()
-    G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
-    a1 = torch.from_numpy(rng.standard_normal(n * d)).cuda(); A2 = torch.from_numpy(rng.standard_normal((n * d, 2))).cuda()
-    y1 = torch.empty_like(a1); Y2 = torch.empty_like(A2)
+    # (round 4: by default this shape now runs column by column on the broadcast kernel, which beats the two-column pass — 2 x 1.36 ms
+    # against 3.30; the two-column pass of the scalar-stream kernel is what this test is about, so the broadcast kernel is switched off)
+    cg.set_option("grad_bcast", 0)
+    try:
+        G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
+        a1 = torch.from_numpy(rng.standard_normal(n * d)).cuda(); A2 = torch.from_numpy(rng.standard_normal((n * d, 2))).cuda()
+        y1 = torch.empty_like(a1); Y2 = torch.empty_like(A2)
 
-    def ms(fn, reps=8):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
-    t1, t2 = float("inf"), float("inf")
-    for _ in range(3):                                              # interleaved, best of three each: clock drift between the two timings
-        t1 = min(t1, ms(lambda: G.mul_(y1, a1)))
-        t2 = min(t2, ms(lambda: G.mul_(Y2, A2)))
-    G.mul_(y1, A2[:, 1].contiguous())
-    assert float((Y2[:, 1] - y1).abs().max()) <= 1e-9 * float(y1.abs().max())
-    assert t2 <= 1.95 * t1, (t1, t2)                                # (1.82x measured; two single passes would be 2x)
-    print(f"C4 shape: one column {t1:.3f} ms, two columns in one pass {t2:.3f} ms ({t2 / t1:.2f}x)")
+        def ms(fn, reps=8):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        t1, t2 = float("inf"), float("inf")
+        for _ in range(3):                                              # interleaved, best of three each: clock drift between the two timings
+            t1 = min(t1, ms(lambda: G.mul_(y1, a1)))
+            t2 = min(t2, ms(lambda: G.mul_(Y2, A2)))
+        G.mul_(y1, A2[:, 1].contiguous())
+        assert float((Y2[:, 1] - y1).abs().max()) <= 1e-9 * float(y1.abs().max())
+        assert t2 <= 1.95 * t1, (t1, t2)                                # (1.82x measured; two single passes would be 2x)
+        print(f"C4 shape: one column {t1:.3f} ms, two columns in one pass {t2:.3f} ms ({t2 / t1:.2f}x)")
+        # the default: both columns on the broadcast kernel, one after the other — faster than the two-column pass
+        cg.set_option("grad_bcast", -1)
+        t2b = min(ms(lambda: G.mul_(Y2, A2)) for _ in range(3))
+        assert cg.get_info("last_grad_bcast") == 4
+        assert float((Y2[:, 1] - y1).abs().max()) <= 1e-9 * float(y1.abs().max())
+        assert t2b <= t2, (t2b, t2)
+        print(f"          two columns on the broadcast kernel {t2b:.3f} ms")
+
+    finally:
+        cg.set_option("grad_bcast", -1)

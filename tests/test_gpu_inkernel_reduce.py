@@ -14,7 +14,7 @@ def _both(cg, fn):
     cg.set_option("inkernel_reduce", 0)
     y0 = fn()
     assert cg.get_info("last_inkernel_reduce") == 0
-    cg.set_option("inkernel_reduce", -1)
+    cg.set_option("inkernel_reduce", 1)
     ys = [fn() for _ in range(3)]                       # repeated launches: the tickets must have gone back to zero
     used = cg.get_info("last_inkernel_reduce")
     return y0, ys, used
