@@ -224,7 +224,7 @@ def other_configs(cg, dev):
                                             "MI355X_MICROARCH.md) in the reference's 3d+3 flops per pair, so frac = achieved / peak = evaluated pairs per second over that ceiling; reference_flops_frac = the reference's 3d+3 = 27 flops per pair against the FP32 "
                                             "VECTOR peak (SURVEY.md \u00a78d(i)) — 24 of them run on the matrix pipe here, so that ratio can exceed 1 and is no utilisation"}}
     Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n, dtype=torch.float32, device=dev)
-    if Gf.sym_partial_supported():
+    if Gf.sym_partial_supported(world):
         cg.set_option("time_kernels", 1)
         ms = _timed(lambda: Gf.sym_partial_(part, a, 3, world), warm=3, reps=10, after_warm=cg.kernel_time)
         kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
@@ -236,6 +236,37 @@ def other_configs(cg, dev):
                                               "frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0)),
                                               "reference_flops_frac": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS}}
     del G, Gf, X, a, y, part
+    # Which path a caller of gramian(EQ(l), x) gets at the contract size by lengthscale (the matrix-core path needs
+    # g^2 R^2 <= 126): path, MVM/s, rel-err on 256 oracle rows; and the GP model 1.5 MaternP(2; l = 0.7) + 0.5 EQ(l = 2) on the same cloud.
+    # The library's DEFAULT choices throughout (symmetric kernels where they apply); reporting only.
+    try:
+        n, d = N_POINTS, DIM
+        rng = np.random.default_rng(SEED)
+        Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+        X = torch.from_numpy(Xh).to(dev); a = torch.from_numpy(ah).to(dev); y = torch.empty_like(a)
+        rows = np.sort(np.random.default_rng(7).choice(n, 256, replace=False))
+        Xr = Xh[rows].astype(np.float64); Xd = Xh.astype(np.float64); ad = ah.astype(np.float64)
+        names = {1: "lane-per-row direct differences", 2: "matrix cores", 3: "wide rows", 4: "factored dot product"}
+        gm = []
+        for l in (0.3, 0.5, 0.7, 1.0, 2.0):
+            G = cg.gramian(cg.Lengthscale(cg.EQ(), l), X)
+            ms = _timed(lambda: G.mul_(y, a), warm=3, reps=8, warm_s=0.05)
+            path = cg.get_info("last_dense_path")
+            sym = bool(cg.get_info("last_mfma_sym") == 1 or cg.get_info("last_dense_sym") == 1)
+            ref = c_oracle.mvm(o.Kernel(o.EQ, lengthscale=l), Xr, Xd, ad)
+            gm.append({"lengthscale": l, "path": names.get(path, str(path)) + (", upper triangle once" if sym else ", all entries"), "ms": ms, "mvm_per_s": 1e3 / ms,
+                       "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref)})
+        out["gate_map_EQ_C2_size"] = {"what": "gramian(Lengthscale(EQ, l), x) * a, d=3 n=131072 fp32, x ~ N(0, I): the library's default path by lengthscale "
+                                              "(the matrix-core path is gated on g^2 R^2 <= 126 about the cloud's centre, csrc/dense_mfma.hip)", "rows_checked": 256, "by_lengthscale": gm}
+        kc = 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
+        G = cg.gramian(kc, X)
+        ms = _timed(lambda: G.mul_(y, a), warm=3, reps=8, warm_s=0.05)
+        ref = 1.5 * c_oracle.mvm(o.Kernel(o.MATERNP, p=2, lengthscale=0.7), Xr, Xd, ad) + 0.5 * c_oracle.mvm(o.Kernel(o.EQ, lengthscale=2.0), Xr, Xd, ad)
+        out["F2_composite"] = {"what": "1.5 MaternP(2; l=0.7) + 0.5 EQ(l=2) dense Gramian mul!, d=3 n=131072 fp32: one MVM per term, each on its own default path",
+                               "ms": ms, "mvm_per_s": 1e3 / ms, "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref), "rows_checked": 256}
+        del G, X, a, y
+    except Exception as e:
+        out["gate_map_EQ_C2_size"] = {"what": "failed", "error": str(e)[:200]}
     # C4: GradientKernel(EQ), d=32, n=16384, fp64
     n, d = 16384, 32
     rng = np.random.default_rng(0xC0F + 3)
@@ -251,7 +282,8 @@ def other_configs(cg, dev):
     out["C4"] = {"what": "GradientKernel(EQ) mul!, d=32 n=16384 fp64", "ms": ms, "kernel_avg_ms": kavg, "mvm_per_s": 1e3 / ms,
                  "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy().reshape(n, d)[rows].reshape(-1), ref), "checked_rows": len(rows),
                  "roofline": {"bound": "valu_fp64", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (kavg * 1e-3) * 1e-12 / 78.6,
-                              "algorithmic_flops": fl}}
+                              "algorithmic_flops": fl, "kernel": "covgram::grad_bcast_kernel<EQ, 32, 4 waves>" if cg.get_info("last_grad_bcast") else "covgram::grad_mvm_kernel<double, EQ, 32, expanded>",
+                              "note": "round 4: column records in VGPRs (counted vector loads), operands by v_fmac_f64_dpp row_newbcast; 158 VALU instructions per wave and column, VALU-issue bound (profiles/r04_c4_bcast_pmc.txt)"}}
     del K, a, y
     # C5: Exponential on range(-1, 1, 2^22), fp64: Toeplitz MVM through the circulant embedding N = 2^23
     n = 1 << 22
@@ -503,7 +535,7 @@ def main():
     # fp32, src/util.jl:40-47, no matrix cores), all n*m entries, same protocol with fewer steps (it is ~1.7x slower)
     dd = None
     try:
-        cg.set_option("mfma_sym", 0); cg.set_option("dense_variant", 1)
+        cg.set_option("mfma_sym", 0); cg.set_option("dense_variant", 1); cg.set_option("dense_sym", 0)     # all n*m entries (no symmetric direct kernel)
         Gd = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
         bd = torch.empty_like(b)
         d_steps = max(5, min(args.steps, 20))
@@ -532,7 +564,7 @@ def main():
         dd = {"what": "failed", "error": str(e)[:200]}
         got_d = None
     finally:
-        cg.set_option("dense_variant", 0); cg.set_option("mfma_sym", -1)
+        cg.set_option("dense_variant", 0); cg.set_option("mfma_sym", -1); cg.set_option("dense_sym", -1)
 
     # ---- the contract step including the transfers of a (host -> device) and b (device -> host), pinned host buffers (SURVEY.md \u00a78d:
     # "a second number includes H2D/D2H of a, b"); never `value`

@@ -534,6 +534,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "dense_variant")) ctx->dense_variant = value;
     else if (!strcmp(key, "toeplitz_fused")) ctx->toeplitz_fused = value;
     else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
+    else if (!strcmp(key, "toeplitz_persist")) ctx->toeplitz_persist = value;
     else if (!strcmp(key, "toeplitz_real_spectrum")) ctx->toeplitz_real_spectrum = value;
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;

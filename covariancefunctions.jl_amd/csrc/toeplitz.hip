@@ -707,8 +707,13 @@ __global__ void permute16_kernel(const typename V2T<T>::type* __restrict__ S, vo
 // (Measured and not kept, round 3 — VERDICT r2 item 8: ONE row in LDS (68 KB) and the other row's spectrum in registers, 256-thread workgroups,
 //  two per CU in different phases, twiddles from the global table: C5 fp64 86.9 us against 86.1 for this kernel, fp32 62.8 / 60.5 — the row pass is
 //  not short of overlap between a CU's load, compute and store phases; profiles/r03_c5_one_row_lds_ab.txt.)
-template <typename T, bool REALS>
-__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
+// PERSIST (round 4): a workgroup walks the row pairs wg, wg + gridDim.x, ... and fetches the NEXT pair's first-stage inputs into a second
+// register set before it starts on the current pair.  With one pair per workgroup (and one or two workgroups per CU, all started together)
+// every CU loads, computes and stores in lockstep with every other: HBM idles through the twelve LDS stages and the CUs idle through the
+// transfers — the row pass moved 201 MB at 4.1 TB/s.  Now the next pair's 128 KB are in flight under the current pair's stages, and the
+// current pair's stores (issued from registers by the last inverse stage) drain under the next pair's.
+template <typename T, bool REALS, bool PERSIST = false>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 && !PERSIST ? 4 : 2)) void rowfft16_fused_kernel(typename V2T<T>::type* __restrict__ zbuf,
                                                                           const typename V2T<T>::type* __restrict__ S,
                                                                           const typename V2T<T>::type* __restrict__ tA,
                                                                           const typename V2T<T>::type* __restrict__ tB,
@@ -722,22 +727,44 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
     __shared__ V rowA[MpP];
     __shared__ V rowB[MpP];
     __shared__ V stw[Q];
-    const int tid = threadIdx.x;
-    const int wg = blockIdx.x;
-    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? n1 / 2 : n1 - wg;
-    V* __restrict__ gA = zbuf + (int64_t)kA * Mp;
-    V* __restrict__ gB = zbuf + (int64_t)kB * Mp;
+    const int tid0 = threadIdx.x;
+    const int npairs = n1 / 2;
+    // row of this thread for pair wg: A = row wg (0 for wg = 0), B = its conjugate partner n1 - wg (n1 / 2 for wg = 0)
+    auto row_of = [&](int wg) { return (tid0 >> 8) ? ((wg == 0) ? n1 / 2 : n1 - wg) : wg; };
+#pragma unroll
+    for (int i = 0; i < Q / NT; ++i) stw[tid0 + i * NT] = twr[tid0 + i * NT];
+    [[maybe_unused]] V xn[16];
+    if constexpr (PERSIST) {
+        const V* __restrict__ g0 = zbuf + (int64_t)row_of(blockIdx.x) * Mp;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xn[q] = g0[(tid0 & 255) + 256 * q];
+    }
+    for (int wg = blockIdx.x; wg < npairs; wg += gridDim.x) {
+    // the thread index is made opaque per pair: everything below depends on it alone, and the compiler otherwise hoists the address
+    // arithmetic of all six stages out of the pair loop (256 VGPRs and scratch where the one-pair kernel needs 142)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
     V* __restrict__ xr = (tid >> 8) ? rowB : rowA;          // this thread's row
-    V* __restrict__ gr = (tid >> 8) ? gB : gA;
     const int b = tid & 255;
+    const int kA = (wg == 0) ? 0 : wg, kB = (wg == 0) ? n1 / 2 : n1 - wg;
+    V* __restrict__ gr = zbuf + (int64_t)row_of(wg) * Mp;
     // the first forward stage (span 256) takes its 16 inputs b + 256 q straight from global memory — coalesced along b — and
     // the last inverse stage writes its outputs the same way: no separate load / store pass through LDS
     V x0[16];
+    if constexpr (PERSIST) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x0[q] = gr[b + 256 * q];
+        for (int q = 0; q < 16; ++q) x0[q] = xn[q];
+        const int nwg = wg + (int)gridDim.x;
+        if (nwg < npairs) {
+            const V* __restrict__ gn = zbuf + (int64_t)row_of(nwg) * Mp;
 #pragma unroll
-    for (int i = 0; i < Q / NT; ++i) stw[tid + i * NT] = twr[tid + i * NT];
-    __syncthreads();
+            for (int q = 0; q < 16; ++q) xn[q] = gn[b + 256 * q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x0[q] = gr[b + 256 * q];
+    }
+    __syncthreads();                                        // the table (first pair) / the previous pair's last stage has left the rows
     // twiddles of a butterfly: w1 = W^e from the table, W^(e q) by repeated multiplication (15 roundings at most)
     {
         dft16<V, false>(x0);
@@ -859,6 +886,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void rowfft16_fused_
             __syncthreads();
         }
     }
+    }   // row pairs of this workgroup
 }
 
 }  // namespace covgram
@@ -977,12 +1005,19 @@ static int fast_mvm(covgram_toeplitz* Tz, const T* a, T* y, double alpha, double
                                         (const V*)t.tA, (const V*)t.tB, (const V*)t.twr, Tz->n1)
         if (L == 6 && Tz->ctx->toeplitz_fused != 2)   // M' = 4096: radix-16 stages (option toeplitz_fused = 2 keeps the radix-4 kernel: A/B)
         {
-            if (Tz->sperm16_real)
-                hipLaunchKernelGGL((rowfft16_fused_kernel<T, true>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
-                                   (const void*)Tz->sperm16, (const V*)t.tB16, Tz->n1);
-            else
-                hipLaunchKernelGGL((rowfft16_fused_kernel<T, false>), fg, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, (const V*)t.tB, (const V*)t.twr,
-                                   (const void*)Tz->sperm16, (const V*)t.tB16, Tz->n1);
+            // round 4: persistent workgroups (one per CU) with the next row pair prefetched into registers (option toeplitz_persist: -1 = fp64
+            // only, 0 = never, 1 = always, k > 1 = with k workgroups).  tools/c5_persist_ab.py / c5_stagger_ab.py, profiles/r04_c5_persist_ab.txt:
+            // fp64 87.6 -> 85.3 us, results bit-identical; fp32 61.2 -> 65.3 (at 177 VGPRs the kernel loses its second workgroup per CU).  The
+            // pass is NOT short of load / compute / store overlap between workgroups: a late start of half the grid only adds its delay, and
+            // the fp32 kernel takes as long as the fp64 one on half the bytes — a workgroup's own chain (one round trip in, six butterfly stages
+            // of ~2900 DP instructions per thread at two waves per SIMD, twelve barriers, one round trip out) is what a pair costs.
+            const bool persist = Tz->ctx->toeplitz_persist > 0 || (Tz->ctx->toeplitz_persist < 0 && sizeof(T) == 8);
+            const dim3 pg((unsigned)std::min<int64_t>(Tz->n1 / 2, Tz->ctx->toeplitz_persist > 1 ? Tz->ctx->toeplitz_persist : Tz->ctx->num_cus));
+#define CG_ROW16(REALV, PV, GRID) hipLaunchKernelGGL((rowfft16_fused_kernel<T, REALV, PV>), GRID, dim3(512), 0, st, (V*)Tz->zbuf, (const V*)Tz->sperm, (const V*)t.tA, \
+                                                     (const V*)t.tB, (const V*)t.twr, (const void*)Tz->sperm16, (const V*)t.tB16, Tz->n1)
+            if (Tz->sperm16_real) { if (persist) CG_ROW16(true, true, pg); else CG_ROW16(true, false, fg); }
+            else { if (persist) CG_ROW16(false, true, pg); else CG_ROW16(false, false, fg); }
+#undef CG_ROW16
         }
         else
         switch (L) { case 3: CG_FUSED(3); break; case 4: CG_FUSED(4); break; case 5: CG_FUSED(5); break; default: CG_FUSED(6); break; }

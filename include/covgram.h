@@ -138,7 +138,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * cores whenever the shape allows), "rows_per_lane", "jsplit",
  * "target_wgs", "grad_keep_r", "time_kernels", "toeplitz_fused" (1 = fused row-FFT kernels, radix-16 stages at M' = 4096; 0 = rocFFT
  * batches; 2 = radix-4 stages everywhere), "toeplitz_colfft" (column FFT of the Toeplitz fast path: 16 = radix-16 register
- * butterflies, the default; 4 = the radix-4 LDS kernel), "toeplitz_real_spectrum" (read when a handle is created: 1 = a symmetric
+ * butterflies, the default; 4 = the radix-4 LDS kernel), "toeplitz_persist" (fused radix-16 row kernel: persistent workgroups that prefetch the next row pair into registers; -1 = fp64 only, 0 = never, 1 = always), "toeplitz_real_spectrum" (read when a handle is created: 1 = a symmetric
  * matrix keeps the row kernel's spectrum copy as reals, 0 = always complex), "mfma_lds" (matrix-core EQ path: four waves share the
  * column tiles through LDS; -1 = when the column chunks are long enough, 0 = never, 1 = whenever compiled: d <= 8),
  * "matrix_variant" (covgram_matrix: 0 = rows in registers, 64-column strips — d <= 64 —, 1 = the generic entry-by-entry kernel),
