@@ -560,6 +560,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     CG_REQUIRE(ctx && key && value, COVGRAM_EINVAL, "NULL argument");
     if (!strcmp(key, "last_dense_path")) *value = ctx->last_dense_path;
     else if (!strcmp(key, "last_jsplit")) *value = ctx->last_jsplit;
+    else if (!strcmp(key, "last_kron_path")) *value = ctx->last_kron_path;
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;

@@ -198,6 +198,7 @@ struct covgram_ctx {
     void* blas = nullptr;        // rocblas_handle of the compute-bound Kronecker mode products (kron.hip), created on first use
     int live_handles = 0;
     int64_t last_dense_path = 0; // 1 lane-per-row, 2 matrix cores, 3 wide rows, 4 factored dot product X (Y' a)
+    int64_t last_kron_path = 0;  // kernels of the last Kronecker MVM, bits: 1 fused last-two-modes pass, 2 single-mode kernel, 4 last-mode kernel, 8 rocBLAS GEMM, 16 two small trailing factors multiplied out
     int64_t last_jsplit = 0;     // column split of the last lane-per-row dense launch (tools)
     int32_t* sym_map = nullptr;  // symmetric kernel: device list of its (local panel, chunk) workgroups, keyed by sym_key
     size_t sym_map_cap = 0, sym_map_len = 0;
@@ -235,7 +236,7 @@ struct covgram_points {
     // used slot IN PLACE, ordered on the ctx stream behind the MVMs that read it — no hipFree, no stream synchronisation and no
     // allocation on the MVM path once the slots exist (a slot is allocated the first time it is needed and lives as long as the handle)
     static constexpr int FRAG_SLOTS = 4;
-    struct FragSlot { void* ptr = nullptr; size_t bytes = 0; float g = 0; int k2 = 0; uint64_t used = 0; };
+    struct FragSlot { void* ptr = nullptr; size_t bytes = 0; float g = 0; int k2 = 0; uint64_t used = 0; bool pinned = false; };   // pinned: handed out during a stream capture — a graph has its address baked in, so it is never re-packed or freed while the handle lives
     mutable FragSlot frag[FRAG_SLOTS];
     mutable uint64_t frag_clock = 0;
 };

@@ -531,14 +531,23 @@ static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
     const size_t total = fbytes + (size_t)ntile * 32 * sizeof(float);   // fragments + EF
     covgram_points::FragSlot* hit = nullptr;
-    covgram_points::FragSlot* victim = &Y->frag[0];
+    covgram_points::FragSlot* victim = nullptr;
+    // a captured graph replays the kernels with the slot's ADDRESS baked in: a slot handed out during a capture is pinned — later eager
+    // MVMs with other lengthscales evict the other slots only (the LRU re-pack silently changed what a replay reads)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = ctx->stream && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     for (auto& f : Y->frag) {
         if (f.ptr && f.bytes == total && f.g == g && f.k2 == K2) { hit = &f; break; }
+        if (f.pinned) continue;
         // reuse order: an empty slot first, then a slot of another size (its buffer is replaced), then the least recently used
         const auto rank = [&](const covgram_points::FragSlot& s) { return !s.ptr ? 0 : (s.bytes != total ? 1 : 2); };
-        if (rank(f) < rank(*victim) || (rank(f) == rank(*victim) && f.used < victim->used)) victim = &f;
+        if (!victim || rank(f) < rank(*victim) || (rank(f) == rank(*victim) && f.used < victim->used)) victim = &f;
     }
     if (!hit) {
+        CG_REQUIRE(victim != nullptr, COVGRAM_EUNSUPPORTED, "all %d fragment slots of this point set are pinned by captured graphs (one per (lengthscale, d) used "
+                   "inside a capture): destroy the handle, or keep to %d lengthscales per point set in graphs", covgram_points::FRAG_SLOTS, covgram_points::FRAG_SLOTS);
+        CG_REQUIRE(!capturing || (victim->ptr && victim->bytes == total), COVGRAM_EUNSUPPORTED,
+                   "the fragments of this (point set, lengthscale) must be packed once OUTSIDE stream capture (run one eager MVM first): packing allocates");
         if (victim->ptr && victim->bytes != total) {   // only when the handle is re-used at another K2: off the steady-state path
             CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(victim->ptr); victim->ptr = nullptr;
         }
@@ -554,6 +563,7 @@ static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float
                            (uint4*)victim->ptr, (float*)((char*)victim->ptr + fbytes), K2, g, Cn);
         hit = victim;
     }
+    if (capturing) hit->pinned = true;
     hit->used = ++Y->frag_clock;
     *PB = (const uint4*)hit->ptr;
     *EF = (const float*)((const char*)hit->ptr + fbytes);

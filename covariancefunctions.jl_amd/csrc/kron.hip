@@ -36,6 +36,13 @@ extern template int run_modet<double>(covgram_ctx*, const double*, double*, cons
 // ---------------------------------------------------------------------------------------------------------------------------
 static int blas_handle(covgram_ctx* ctx, rocblas_handle* out) {
     if (!ctx->blas) {
+        // rocblas_create_handle allocates and synchronises: not legal inside a stream capture.  A graph user runs one
+        // eager MVM of the shape first (as for every workspace of this library); inside a capture the call is refused, not crashed.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (ctx->stream && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("kron_mvm: the first library-GEMM mode on this ctx must run outside stream capture (it creates the rocBLAS handle)");
+            return COVGRAM_EUNSUPPORTED;
+        }
         rocblas_handle h = nullptr;
         if (rocblas_create_handle(&h) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return COVGRAM_EHIP; }
         rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
@@ -63,9 +70,14 @@ static rocblas_status gemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_op
 // product is S F^T; post == 1: one GEMM out (M x pre) = F (M x K) in (K x pre)
 template <typename T>
 static int run_blas(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t ld, int64_t M, int64_t K, int64_t pre, int64_t post, T alpha, T beta) {
+    // rocblas_int is 32 bits: every extent, leading dimension and the batch count must fit (they were cast unchecked)
+    const int64_t lim = ((int64_t)1 << 31) - 1;
+    CG_REQUIRE(M <= lim && K <= lim && pre <= lim && post <= lim && ld <= lim, COVGRAM_EUNSUPPORTED,
+               "kron: a mode of extents (%lld, %lld, pre %lld, post %lld) exceeds the library GEMM's 32-bit sizes", (long long)M, (long long)K, (long long)pre, (long long)post);
     rocblas_handle h;
     int rc = blas_handle(ctx, &h);
     if (rc) return rc;
+    ctx->last_kron_path |= 8;
     rocblas_status st;
     if (post == 1) st = gemm_sb(h, rocblas_operation_none, rocblas_operation_none, M, pre, K, alpha, F, ld, 0, in, K, 0, beta, out, M, 0, 1);
     else st = gemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, post, M, K, alpha, in, post, K * post, F, ld, 0, beta, out, post, M * post, pre);
@@ -97,6 +109,7 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
                     const T* a_dev, T* y_dev, T alpha, T beta, T* bufA, T* bufB, T* merged) {
     int64_t cur[16];
     for (int i = 0; i < q; ++i) cur[i] = cols[i];
+    if (merged != nullptr) ctx->last_kron_path = 0;      // (the outer call; the recursion below keeps what it has)
     const T* src = a_dev;
     T* dst = bufA;
     auto next_out = [&](bool final) -> T* { return final ? y_dev : dst; };
@@ -126,6 +139,7 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
     if (!pair && q >= 2 && rows[q - 2] * rows[q - 1] <= MERGE_MAX_SIDE && cols[q - 2] * cols[q - 1] <= MERGE_MAX_SIDE && merged != nullptr) {
         const int r1 = (int)rows[q - 2], c1 = (int)cols[q - 2], r2 = (int)rows[q - 1], c2 = (int)cols[q - 1];
         const int tot = r1 * r2 * c1 * c2;
+        ctx->last_kron_path |= 16;
         hipLaunchKernelGGL(kron_factor_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)factors[q - 2], lds[q - 2], r1, c1,
                            (const T*)factors[q - 1], lds[q - 1], r2, c2, merged);
         const void* f2[16]; int64_t rows2[16], cols2[16], lds2[16];
@@ -134,6 +148,7 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
         return kron_run<T>(ctx, f2, rows2, cols2, lds2, q - 1, batch, a_dev, y_dev, alpha, beta, bufA, bufB, nullptr);
     }
     const int nsingle = pair ? q - 2 : q;
+    if (pair) ctx->last_kron_path |= 1;
     if (pair && pair_first) {
         const bool final = (nsingle == 0);
         rc = run_pair<T>(ctx, src, next_out(final), (const T*)factors[q - 2], lds[q - 2], rows[q - 2], cols[q - 2], (const T*)factors[q - 1], lds[q - 1],
@@ -151,8 +166,8 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
         const T al = final ? alpha : (T)1, be = final ? beta : (T)0;
         const bool fits = post == 1 ? modet_ok(cols[k], lds[k]) : mode_ok(cols[k], post, lds[k]);
         if (big(k) || !fits) rc = run_blas<T>(ctx, src, out, (const T*)factors[k], lds[k], rows[k], cols[k], pre, post, al, be);
-        else if (post == 1) rc = run_modet<T>(ctx, src, out, (const T*)factors[k], lds[k], rows[k], cols[k], pre, al, be);
-        else rc = run_mode<T>(ctx, src, out, (const T*)factors[k], lds[k], rows[k], cols[k], pre, post, al, be);
+        else if (post == 1) { ctx->last_kron_path |= 4; rc = run_modet<T>(ctx, src, out, (const T*)factors[k], lds[k], rows[k], cols[k], pre, al, be); }
+        else { ctx->last_kron_path |= 2; rc = run_mode<T>(ctx, src, out, (const T*)factors[k], lds[k], rows[k], cols[k], pre, post, al, be); }
         if (rc) return rc;
         cur[k] = rows[k];
         advance();

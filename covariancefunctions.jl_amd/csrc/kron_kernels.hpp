@@ -597,7 +597,7 @@ int run_pair(covgram_ctx* ctx, const T* in, T* out, const T* F2, int64_t ld2, in
     const int strips = (int)((M1 + 15) / 16);
     a.groups = (strips + 3) / 4;
     const int64_t nblocks = ((pre + 7) / 8) * 8 * a.groups;
-    CG_REQUIRE(nblocks < ((int64_t)1 << 31), COVGRAM_EUNSUPPORTED, "kron: too many slabs (%lld)", (long long)pre);
+    CG_REQUIRE(nblocks < ((int64_t)1 << 31) && pre < ((int64_t)1 << 31), COVGRAM_EUNSUPPORTED, "kron: too many slabs (%lld)", (long long)pre);
     const dim3 grid((unsigned)nblocks);
 #ifdef KRON_DIAG
     static long long* stamp_buf = nullptr;
@@ -642,6 +642,7 @@ int run_mode(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t ld, int6
     a.in = in; a.out = out; a.F = F; a.ld = ld; a.post = post;
     a.pre = (int32_t)pre; a.K = (int32_t)K; a.M = (int32_t)M; a.alpha = alpha; a.beta = beta; a.diag = diag_env("COVGRAM_KRON_DIAG");
     CG_REQUIRE(mode_ok(K, post, ld), COVGRAM_EUNSUPPORTED, "kron: tensor rows too far apart for the mode kernel");
+    CG_REQUIRE(pre < ((int64_t)1 << 31), COVGRAM_EUNSUPPORTED, "kron: leading extent %lld does not fit the kernels' 32-bit index", (long long)pre);
     const bool vec = aligned_to(in, 16) && (post % VW == 0);
     const int strips = (int)((M + 15) / 16);
     // column tiles: 128 wide when that still gives every CU a workgroup, else 64 / 32 (more, smaller workgroups for short K measured
@@ -679,6 +680,7 @@ int run_modet(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t ld, int
     a.in = in; a.out = out; a.F = F; a.ld = ld; a.post = 1;
     a.pre = (int32_t)pre; a.K = (int32_t)K; a.M = (int32_t)M; a.alpha = alpha; a.beta = beta; a.diag = 0;
     CG_REQUIRE(modet_ok(K, ld), COVGRAM_EUNSUPPORTED, "kron: factor too large for the last-mode kernel");
+    CG_REQUIRE(pre < ((int64_t)1 << 31), COVGRAM_EUNSUPPORTED, "kron: leading extent %lld does not fit the kernels' 32-bit index", (long long)pre);
     const bool vec = aligned_to(in, modet_vb<T>()) && (K % VW == 0);
     const int strips = (int)((M + 15) / 16);
     // row tiles of 128 (few strips per workgroup position) or 32

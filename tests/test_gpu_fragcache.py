@@ -82,3 +82,37 @@ def test_sum_of_two_lengthscales_solves_under_a_captured_graph(cg, oracle):
     ko = oracle.Composite(((oracle.Kernel(oracle.EQ, lengthscale=0.7),), (oracle.Kernel(oracle.EQ, lengthscale=1.9),)), oracle.ISOTROPIC, 1.0)
     M = oracle.matrix(ko, Xh.astype(np.float64), Xh.astype(np.float64)) + 0.5 * np.eye(n)
     assert relerr(M @ x.cpu().numpy().astype(np.float64), bh) <= 1e-4
+
+
+def test_fragment_slots_used_in_a_captured_graph_are_never_repacked(cg, oracle):
+    """a captured graph bakes in the ADDRESS of the fragment slot it read; later eager MVMs at more than four other lengthscales
+    used to re-pack that slot in place, and a replay then read another lengthscale's fragments without any error.  Slots handed out during
+    a capture are pinned now: the replay after six other lengthscales reproduces the first result bit for bit."""
+    rng = np.random.default_rng(33)
+    n, d = 6000, 3
+    X = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    y = torch.empty_like(a)
+    G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.9), X)
+    G.mul_(y, a)                                            # eager first: workspaces, fragments (packing allocates)
+    assert cg.get_info("last_dense_path") == 2
+    want = y.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        G.mul_(y, a)                                        # warm on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            G.mul_(y, a)
+    torch.cuda.current_stream().wait_stream(s)
+    y.zero_(); graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    y2 = torch.empty_like(a)
+    for l in (0.5, 0.6, 0.7, 0.8, 1.1, 1.3):               # six other lengthscales on the SAME point handle: more than the four slots
+        Gl = cg.gramian(cg.Lengthscale(cg.EQ(), l), X)
+        Gl._px = Gl._py = G._px                            # ONE covgram_points handle for all of them (what the Julia shim's per-object cache and a
+        Gl.mul_(y2, a)                                      # Sum of lengthscales do): its four fragment slots turn over
+    torch.cuda.synchronize()
+    y.zero_(); graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(y, want), float((y - want).abs().max())

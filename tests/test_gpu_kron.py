@@ -135,6 +135,23 @@ def test_kron_large_factor_takes_the_library_gemm(cg, oracle):
         run_case(cg, oracle, [(12, 10), (1100, 1024)], dt, rng)
 
 
+def test_kron_paths_by_shape(cg, oracle):
+    """Which kernels a shape runs (info key "last_kron_path", round 4 — csrc/kron.hip sent shapes its kernels refuse to rocBLAS silently):
+    bit 1 = fused last-two-modes pass, 2 = single-mode kernel, 4 = last-mode kernel, 8 = rocBLAS, 16 = two small trailing factors multiplied
+    out.  The README case and everything GP-sized stays on the hand-written kernels; only compute-bound modes reach the library."""
+    rng = np.random.default_rng(16)
+    expect = [([(128, 128)] * 3, 1 | 2), ([(64, 64)] * 3, 2 | 4),          # 64 slabs are too few for the fused pass: mode by mode ([(32, 32)] * 4, None), ([(16, 16)] * 5, None), ([(40, 40), (100, 90)], None),
+              ([(300, 200)], 4), ([(1024, 1030), (24, 40)], None), ([(256, 256)] * 2, None)]
+    for shapes, want in expect:
+        run_case(cg, oracle, shapes, np.float64, rng)
+        path = cg.get_info("last_kron_path")
+        assert path != 0
+        big = any(max(sh) >= 1024 for sh in shapes)
+        assert bool(path & 8) == big, (shapes, path)            # rocBLAS exactly for the factor sides >= 1024 among these shapes
+        if want is not None:
+            assert path == want, (shapes, path, want)
+
+
 def test_kron_lazy_grid_full_size_properties(cg, oracle):
     """README.md:205-210's case (128^3 grid, three 128 x 128 Gramians) at full size: linearity and the transpose identity
     <u, K v> = <K^T u, v> (size-independent), plus 64 entries of K a against explicit rows of the Kronecker matrix."""
