@@ -9,6 +9,7 @@
 
 #include "dense_mvm.hpp"
 #include "dense_sym32.hpp"
+#include "dense_bcast.hpp"
 #include "dense_wide.hpp"
 #include "grad_mvm.hpp"
 #include "grad_bcast.hpp"
@@ -546,6 +547,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "mfma_lds")) ctx->mfma_lds = value;
     else if (!strcmp(key, "mfma_sym")) ctx->mfma_sym = value;
     else if (!strcmp(key, "dense_sym")) ctx->dense_sym = value;
+    else if (!strcmp(key, "dense_bcast")) ctx->dense_bcast = value;
     else if (!strcmp(key, "mfma_stamp")) ctx->mfma_stamp = value;
     else if (!strcmp(key, "inkernel_reduce")) ctx->inkernel_reduce = value;
     else if (!strcmp(key, "matrix_variant")) ctx->matrix_variant = value;
@@ -564,6 +566,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_mfma_lds")) *value = ctx->last_mfma_lds;
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
+    else if (!strcmp(key, "last_dense_bcast")) *value = ctx->last_dense_bcast;
     else if (!strcmp(key, "last_inkernel_reduce")) *value = ctx->last_inkernel_reduce;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;
@@ -919,8 +922,67 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
                       dense_sym_shape(hk, X, sp_world > 0 ? sp_world : 1, sym_forced ? 2 : 1, &symsh);
     if (sp_world > 0 && !dsym) { set_error("the symmetric direct-difference kernel does not apply to this kernel / point set"); return COVGRAM_EUNSUPPORTED; }
     const bool dsym32 = dsym && dtype == COVGRAM_F32;
+    // fp64, wide points (round 4, dense_bcast.hpp): |x - y|^2 expanded around cached norms — one v_fmac_f64 per dimension and pair instead of
+    // a subtraction and an fma, the column records in VGPRs (DPP broadcast) instead of the scalar stream — for the profiles that are smooth
+    // in s at 0, one right-hand side, no Power wrapper, inside the expanded form's radius gate (as the gradient kernel's: grad_mvm.hpp).
+    // Where the symmetric form applies too (gramian(k, x), n from 8192 / 16384, or covgram_mvm_sym_partial's cyclic row blocks) the two
+    // combine: dense_bcast_sym_kernel evaluates the upper triangle once WITH the one-fmac distance (profiles/r04_fp64_dense_d_sweep.txt).
+    const bool bc_family = hk.tu_family == COVGRAM_EQ || hk.tu_family == COVGRAM_RQ || hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ ||
+                           (hk.tu_family == COVGRAM_MATERNP && hk.k.p >= 1);
+    const bool dbc = !mfma && !wide && m > 0 && dtype == COVGRAM_F64 && nrhs == 1 && bc_family && hk.k.power == 1 && dense_bcast_ok(D) &&
+                     ctx->dense_bcast != 0 && ctx->dense_variant != 1 &&
+                     (ctx->dense_bcast == 1 || (D >= 16 && gate_radius2(X, Y) / (hk.k.lengthscale * hk.k.lengthscale) <= GRAD_EXPAND_GATE));
+    ctx->last_dense_bcast = dbc ? 1 : 0;
+    if (dbc) {
+        const int64_t CB = DENSE_BCAST_CB;
+        const int64_t mpad = ((m + CB - 1) / CB) * CB + CB;               // whole blocks + one prefetch-only block
+        void* Pb;
+        rc = ws_reserve(ctx, 0, (size_t)mpad * (D + 2) * ts, &Pb); if (rc) return rc;
+        double* Exb = (double*)Pb + (size_t)mpad * D;
+        hipLaunchKernelGGL(dense_bcast_pack_kernel<double>, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, Y->d,
+                           (const double*)a_dev, (double*)Pb, Exb, D, hk.kp.gamma, (const double*)Cn, mpad);
+        DenseArgs da;
+        da.C = Cn; da.X = X->dptr; da.n = n; da.d = X->d; da.P = Pb; da.Ex = Exb; da.m = m; da.ldy = ldy_d; da.nrhs = 1;
+        da.Dpad = D; da.NRpad = 1; da.rows_per_lane = 1; da.variant = 0; da.bcast = 1;
+        da.alpha = alpha_eff; da.beta = beta; da.hk = &hk; da.stream = ctx->stream;
+        ctx->last_dense_path = 1;
+        int64_t jchunk; int jsplit;
+        auto* tmb = timer_next(ctx);
+        if (dsym) {
+            // gramian(k, x): the upper triangle once on dense_bcast_sym_kernel — 64-row blocks, chunks of whole 64-column blocks, the column-sum
+            // slab and the reduce kernel of dense_sym_kernel (covgram_mvm_sym_partial's cyclic blocks included)
+            choose_split(ctx, rowblocks, m, 64, &jchunk, &jsplit);
+            const int64_t blocks = (m + 63) / 64;
+            const int64_t want = std::max<int64_t>(1, std::min<int64_t>(blocks, 2 * (int64_t)jsplit));
+            const int64_t per = (blocks + want - 1) / want;
+            da.jchunk = jchunk = per * 64;
+            da.jsplit = jsplit = (int)((blocks + per - 1) / per);
+            da.npad = npad; da.sym = 1;
+            if (sp_world > 0) { da.sym_first = sp_rank; da.sym_stride = sp_world; }
+            rc = ws_reserve(ctx, 1, (size_t)jsplit * npad * ts, &da.out); if (rc) return rc;
+            rc = ws_reserve(ctx, 4, symsh.slab_bytes, &da.colslab); if (rc) return rc;
+            if (tmb) (void)hipEventRecord(tmb->first, ctx->stream);
+            rc = launch(da, dtype); if (rc) return rc;
+            if (tmb) (void)hipEventRecord(tmb->second, ctx->stream);
+            hipLaunchKernelGGL(dense_sym_reduce_kernel<double>, dim3((unsigned)rowblocks), dim3(1024), 0, ctx->stream, (const double*)da.out,
+                               (const double*)da.colslab, npad, jsplit, (double*)y_dev, n, alpha_eff, beta, da.sym_first, da.sym_stride);
+        } else {
+            const int64_t rb256 = (n + 255) / 256, npadb = rb256 * 256;
+            choose_split(ctx, rb256, m, 64, &jchunk, &jsplit, (int64_t)ctx->num_cus * 32);
+            da.npad = npadb; da.jchunk = jchunk; da.jsplit = jsplit;
+            if (jsplit == 1) da.out = y_dev;
+            else { rc = ws_reserve(ctx, 1, (size_t)jsplit * npadb * ts, &da.out); if (rc) return rc; }
+            if (tmb) (void)hipEventRecord(tmb->first, ctx->stream);
+            rc = launch(da, dtype); if (rc) return rc;
+            if (tmb) (void)hipEventRecord(tmb->second, ctx->stream);
+            if (jsplit > 1)
+                hipLaunchKernelGGL(dense_reduce_kernel<double>, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, ctx->stream, (const double*)da.out, npadb, 1, jsplit,
+                                   (double*)y_dev, n, ldy_d, 1, alpha_eff, beta);
+        }
+        ctx->last_jsplit = jsplit;
+    }
     ctx->last_dense_sym = dsym ? 1 : 0;
-    for (int c0 = 0; c0 < nrhs && !mfma; c0 += 4) {
+    for (int c0 = 0; c0 < nrhs && !mfma && !dbc; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NRpad = (nr == 1) ? 1 : 4;
         const char* a_c = (const char*)a_dev + (size_t)c0 * lda_d * ts;

@@ -178,6 +178,8 @@ struct covgram_ctx {
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
     int64_t last_dense_sym = 0;
+    int64_t dense_bcast = -1;    // fp64 dense MVM of wide points on dense_bcast_kernel (expanded distance, v_fmac_f64_dpp): -1 = from padded d = 16 inside the radius gate, 0 never, 1 whenever compiled (d >= 8)
+    int64_t last_dense_bcast = 0;
     int64_t inkernel_reduce = -1; // split-J partials of the dense kernels summed by the last-arriving workgroup of each row block (-1 / 1: yes, 0: the separate reduce launch)
     int64_t last_inkernel_reduce = 0;
     unsigned* tickets = nullptr;  // one arrival counter per row block, zero between launches (pack.hpp: last_arrival)
@@ -260,6 +262,7 @@ struct DenseArgs {
     int64_t jchunk; int32_t jsplit; int32_t rows_per_lane; int32_t variant;
     int32_t lds_pad = 0;                   // dynamic LDS bytes requested only to cap waves per CU (occupancy experiments)
     const void* C = nullptr;               // common centre (d scalars on the device) subtracted from both sides by isotropic kernels
+    int32_t bcast = 0; const void* Ex = nullptr;   // fp64 wide points: dense_bcast_kernel (expanded distance, records in VGPRs); P = [mpad][D] points, Ex = [mpad][2] (|y'|^2, a)
     unsigned* tickets = nullptr; void* yfinal = nullptr;   // jsplit > 1: the last workgroup of a row block sums the slab into yfinal (pack.hpp: last_arrival)
     int32_t sym = 0; void* colslab = nullptr;   // fp64 gramian(k, x): dense_sym_kernel (upper triangle once) + its [row blocks of this launch][npad] column-sum slab
     int32_t sym_first = 0, sym_stride = 1;      // ... over the 64-row blocks first, first + stride, ... (covgram_mvm_sym_partial: rank, world)

@@ -2,6 +2,7 @@
 // build in parallel; exports launch_dense_family_<FAM>.
 #include "dense_mvm.hpp"
 #include "dense_sym32.hpp"
+#include "dense_bcast.hpp"
 #include "dense_wide.hpp"
 
 #ifndef COVGRAM_FAM

@@ -553,12 +553,15 @@ template <int D> struct RowsFor { static constexpr int value = 1; };
 inline int rows_per_lane_for(int) { return 1; }
 
 template <int FAM, int D> static int launch_dense_sym32_one(const DenseArgs& a);   // dense_sym32.hpp
+template <int FAM, int D> static int launch_dense_bcast_one(const DenseArgs& a);   // dense_bcast.hpp
 
 template <typename T, int FAM, int D, int NR>
 static int launch_dense_D(const DenseArgs& a) {
     constexpr int R = RowsFor<D>::value;
-    if constexpr (sizeof(T) == 8 && NR == 1 && !fam_is_expr<FAM>)
+    if constexpr (sizeof(T) == 8 && NR == 1 && !fam_is_expr<FAM>) {
+        if (a.bcast) return launch_dense_bcast_one<FAM, D>(a);
         if (a.sym) return launch_dense_sym_one<FAM, D>(a);
+    }
     if constexpr (sizeof(T) == 4 && NR == 1 && !fam_is_expr<FAM>)
         if (a.sym) return launch_dense_sym32_one<FAM, D>(a);
     const bool pow = a.hk->k.power != 1;
