@@ -892,7 +892,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     if (dotfac) mfma = true;                                     // (handled: skip the kernels below)
     else if (sym) { rc = mvm_eq_mfma_sym(ctx, hk, X, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
     else if (mfma) { rc = mvm_eq_mfma(ctx, hk, X, Y, (const float*)a_dev, (float*)y_dev, alpha, beta); if (rc) return rc; }
-    else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y)) {
+    else if (m > 0 && mfma_gen_eligible(ctx, hk, X, Y, nrhs)) {
         mfma = true;
         if (mfma_gen_sym_eligible(ctx, hk, X, Y, nrhs)) {              // gramian(k, x): upper triangle once, any matrix-core profile
             ctx->last_mfma_sym = 1;

@@ -322,7 +322,7 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
 int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const float* a, float* y, double alpha, double beta,
                     int pfirst = 0, int pstride = 1, const covgram_kernel* kgen = nullptr);
 bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
-bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs = 1);
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);
 

@@ -728,11 +728,11 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
 }
 
 static int mfma_k2_for(int dims);
-bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 // the generic profiles' symmetric form: same conditions on top of the generic matrix-core gate (hk: gamma = 1/l parameter block)
 bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
     if (ctx->mfma_sym == 0 || nrhs != 1 || X->dptr != Y->dptr || X->n != Y->n) return false;
-    if (!mfma_gen_eligible(ctx, hk, X, Y)) return false;
+    if (!mfma_gen_eligible(ctx, hk, X, Y, nrhs)) return false;
     const int k2 = mfma_k2_for(X->d + (hk.k.trait == COVGRAM_ISOTROPIC ? 1 : 0));
     if (k2 < 0) return false;
     const int tpp = k2 > MFMA_NARROW_MAXK2 ? 4 : 8;
@@ -903,10 +903,16 @@ static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coord
     return -1;
 }
 
-bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y) {
+bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
     if (ctx->dense_variant == 1 || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
     if (mfma_launcher(hk.tu_family) == nullptr) return false;
     if (hk.tu_family == COVGRAM_MATERNP && hk.k.p < 1) return false;          // MaternP(0) = Exp: not differentiable in s at 0
+    // MaternP at d <= 8: the lane-per-row kernels evaluate its profile in PACKED fp32 (two columns per instruction) and, on gramian(k, x),
+    // once per two entries (dense_sym32_kernel, round 4) — that beats the matrix-core kernels, whose 16 entries per lane run the square
+    // root, the exponential and the polynomial one by one: n = 131072, d = 3: 4.83 -> 2.61 ms, d = 8: 6.34 -> 3.85 ms; at d = 16 the distance
+    // on the matrix pipe evens it out (profiles/r04_mfma_vs_sym32.txt).  dense_variant = 2 still forces the matrix cores (tests).
+    // (up to four right-hand sides: from five on the accumulation itself is a GEMM on the matrix cores, dense_mfma_mrhs_kernel)
+    if (hk.tu_family == COVGRAM_MATERNP && X->d <= 8 && nrhs < 5 && ctx->dense_variant != 2) return false;
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
     if (hk.tu_family >= COVGRAM_NFAMILY) {
         // composite: every factor must be one of the smooth matrix-core profiles, and the relative errors of a product add up:
