@@ -58,13 +58,14 @@ def test_random_symmetric_cases(cg, oracle, seed):
         for _ in range(14):
             name, k, ko = cases[rng.integers(len(cases))]
             dt = [np.float32, np.float32, np.float64][rng.integers(3)]
-            d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16]))
+            d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17, 24, 33, 48, 64]))      # (from 16: the fp64 broadcast kernels of round 4, symmetric form)
             n = int(rng.choice([1, 2, 31, 33, 255, 256, 257, 511, 513, 1000, 2047, 2049, 2600]))
             alpha, beta = [(1.0, 0.0), (-0.7, 1.3), (2.0, 0.0)][rng.integers(3)]
             X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt)
             a = rng.standard_normal(n).astype(dt); y0 = rng.standard_normal(n).astype(dt)
             cg.set_option("mfma_sym", 1); cg.set_option("dense_variant", int(rng.choice([0, 2]))); cg.set_option("jsplit", int(rng.choice([0, 0, 2, 5])))
-            cg.set_option("dense_sym", 1)                     # fp64: the direct-difference symmetric kernel wherever it is eligible
+            cg.set_option("dense_sym", 1)                     # the direct-difference symmetric kernels (fp64, fp32) wherever they are eligible
+            cg.set_option("dense_bcast", int(rng.choice([-1, 0, 1])))   # fp64: expanded distance with broadcast records — by rule, never, from d = 8
             Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
             G = cg.gramian(k, Xd)
             yd = torch.from_numpy(y0.copy()).cuda()
@@ -83,7 +84,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
                 e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))
                 assert e <= tol, (name, d, n, world, e)
     finally:
-        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1)
+        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1); cg.set_option("dense_bcast", -1)
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -102,6 +103,7 @@ def test_random_gradient_cases(cg, oracle, seed):
         X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(dt)
         a = rng.standard_normal(m * bd).astype(dt); y0 = rng.standard_normal(n * bd).astype(dt)
         K = cg.gramian((cg.ValueGradientKernel if vg else cg.GradientKernel)(k), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+        cg.set_option("grad_bcast", int(rng.choice([-1, 0, 1, 4])))      # fp64 expanded form: scalar stream / broadcast records (round 4), by rule or forced
         yd = torch.from_numpy(y0.copy()).cuda()
         if beta == 0.0:
             yd.fill_(float("nan"))
@@ -109,6 +111,7 @@ def test_random_gradient_cases(cg, oracle, seed):
         ref = (oracle.valgrad_mul if vg else oracle.grad_mul)(y0, ko, X, Y, a, alpha, beta, dt)
         tol = 1e-5 if dt == np.float32 else 1e-12
         e = relerr(yd.cpu().numpy(), ref)
+        cg.set_option("grad_bcast", -1)
         assert e <= tol, (name, dt.__name__, d, n, m, vg, alpha, beta, e)
 
 
