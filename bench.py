@@ -311,7 +311,7 @@ def launch_ranks(args, argv) -> int:
     """`bench.py --gpus N` run by hand (no WORLD_SIZE): start N ranks of this file under torch.distributed.run as a CHILD process
     — this process has made no GPU call (torch.cuda.device_count() does not initialise the runtime on this image) and is never
     replaced —, forward the ONE JSON line rank 0 prints and return the child's exit code."""
-    if not args.dry_launch:
+    if not args.dry_launch and os.environ.get("COVGRAM_BENCH_REHEARSAL") != "1":
         ndev = torch.cuda.device_count()
         if ndev < args.gpus:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible\n")
@@ -396,18 +396,27 @@ def main():
         except Exception as e:   # the baseline is reporting only; never fail the GPU measurement for it
             cpu_line = {"value": None, "unit": "MVM/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
+    # REHEARSAL of the N > 1 code path on a box with ONE GPU (tests/test_gpu_dist.py): COVGRAM_BENCH_REHEARSAL=1 puts every rank on GPU 0
+    # and runs the collectives over gloo (covgram.dist stages the MVM's one collective through host memory then) — every line of the
+    # multi-rank path below executes, only RCCL itself does not; the line says so (`rehearsal`, `rccl_ranks` 0) and is no measurement.
+    rehearsal = world > 1 and os.environ.get("COVGRAM_BENCH_REHEARSAL") == "1"
     if world > 1 or os.environ.get("COVGRAM_FORCE_COLLECTIVE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        if torch.cuda.device_count() <= local_rank:
-            sys.stderr.write(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible\n")
-            sys.exit(2)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if rehearsal:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            if torch.cuda.device_count() <= local_rank:
+                sys.stderr.write(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible\n")
+                sys.exit(2)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
         assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    sdev = torch.device("cpu") if rehearsal else dev          # where the few statistics scalars are reduced (gloo: host tensors)
 
     import covgram as cg
 
@@ -458,12 +467,12 @@ def main():
 
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=sdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
         # every rank's own split of a step, gathered to rank 0: where the time of an N-GPU step goes
         mine = torch.tensor([kernel_ms / max(launches, 1), loc_ms / max(nsplit, 1), col_ms / max(nsplit, 1), float(G.hi - G.lo),
-                             float(np.median(step_ms)), float(min(step_ms))], dtype=torch.float64, device=dev)
+                             float(np.median(step_ms)), float(min(step_ms))], dtype=torch.float64, device=sdev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "kernel_ms": float(v[0]), "local_ms": float(v[1]), "collective_ms": float(v[2]), "shard_rows": int(v[3]),
@@ -488,7 +497,7 @@ def main():
         if ks:
             clock_ghz = float(np.median(ks)) * 1e-6
     if world > 1:
-        t = torch.tensor([clock_ghz or 0.0], dtype=torch.float64, device=dev)
+        t = torch.tensor([clock_ghz or 0.0], dtype=torch.float64, device=sdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         clock_ghz = float(t[0]) or None
 
@@ -526,7 +535,7 @@ def main():
     cg.set_option("time_kernels", 0)
     s_used = cg.get_info("last_mfma_sym") == 1
     if world > 1:
-        t = torch.tensor([s_elapsed, s_kernel_ms / max(s_launches, 1)], dtype=torch.float64, device=dev)
+        t = torch.tensor([s_elapsed, s_kernel_ms / max(s_launches, 1)], dtype=torch.float64, device=sdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         s_elapsed, s_kern_avg_ms = float(t[0]), float(t[1])
     else:
@@ -552,7 +561,7 @@ def main():
         d_elapsed = time.perf_counter() - t0
         d_path = cg.get_info("last_dense_path")
         if world > 1:
-            t = torch.tensor([d_elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([d_elapsed], dtype=torch.float64, device=sdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             d_elapsed = float(t[0])
         dd = {"what": "the same contract workload on the reference's arithmetic: direct differences per pair in fp32 on the VALU (option dense_variant = 1, "
@@ -699,7 +708,7 @@ def main():
         step_stats = _stats(step_ms)
         line = {
             "metric": "Gramian MVMs/sec, dense EQ kernel, n=131072, d=3, fp32 (+ achieved HBM GB/s in roofline.hbm_*)",
-            "value": mvms, "unit": "MVM/s", "n_gpus": world, "rccl_ranks": world if dist.is_initialized() else 0, "steps": args.steps, "warmup": args.warmup,
+            "value": mvms, "unit": "MVM/s", "n_gpus": world, "rccl_ranks": world if (dist.is_initialized() and not rehearsal) else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_median": step_stats["ms_median"], "ms_min": step_stats["ms_min"], "ms_max": step_stats["ms_max"],
             "timing_note": "value / ms_per_step: wall clock over the K steps between barrier + synchronize (the contract); ms_median / ms_min: one HIP event pair "
                            "per step on the launch stream, same K steps",
@@ -744,6 +753,8 @@ def main():
                 "hbm_frac": bytes_launch / kern_s * 1e-9 / HBM_PEAK_GBPS,
             },
         }
+        if rehearsal:
+            line["rehearsal"] = "COVGRAM_BENCH_REHEARSAL=1: all ranks on GPU 0, collectives over gloo through host memory — a code-path rehearsal, NOT a measurement"
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["per_rank_note"] = ("kernel_ms: the rank's dominant kernel by HIP events on the launch stream; local_ms / collective_ms: events on the same stream "

@@ -158,6 +158,25 @@ def test_bench_gpus_two_launches_two_rccl_ranks():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["per_rank"]) == 2 and line["rel_err_vs_fp64_oracle"] <= 1e-5
 
 
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """Every line of bench.py's N > 1 path — row shards + the ONE all-gather per MVM, the symmetric variant's partials + all-reduce, the per-rank
+    split gathered to rank 0, single_gpu_ms / ideal_ms — executed on the one GPU this box has: `--gpus 2` with COVGRAM_BENCH_REHEARSAL=1 (both ranks on GPU 0,
+    collectives over gloo through host memory).  What is NOT covered is RCCL itself (tests/rccl_worker.py at world 1, two ranks where two GPUs exist).  The
+    line must say that it is a rehearsal, carry two per-rank entries whose shards cover the rows, and both results must match the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["COVGRAM_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and "rehearsal" in line
+    assert line["rel_err_vs_fp64_oracle"] <= 1e-5 and line["symmetric_variant"]["rel_err_vs_fp64_oracle"] <= 1e-5
+    assert [p["shard_rows"] for p in line["per_rank"]] == [65536, 65536] and all(p["kernel_ms"] > 0 and p["collective_ms"] > 0 for p in line["per_rank"])
+    assert line["single_gpu_ms"] > 0 and abs(line["ideal_ms"] - line["single_gpu_ms"] / 2) < 1e-9
+    assert "row-shard x2" in line["config"]["parallelism"]
+
+
 def _run_rccl_worker(nproc):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_worker.py")]
