@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restric
 // (s_memrealtime) around the column loop of every workgroup — clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md,
 // DVFS give-back item 6).  The stamps go to a buffer of their own; no product launch ever runs this instantiation.
 template <int K2, int RT, int WPB = 1, int LDS = 0, int STAMP = 0>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS == 1 ? (K2 <= 2 ? 4 : 3) : 1, LDS == 1 ? (K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS == 1 ? (RT == 4 ? 2 : K2 <= 2 ? 4 : 3) : 1, LDS == 1 ? (RT == 4 ? 2 : K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
                                                            float alpha, float beta, int32_t final_store, const float* __restrict__ Cn,
@@ -513,6 +513,7 @@ static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const floa
         hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
+        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal); return; } }
         if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (rt == 2 && K2 <= 8) {
@@ -595,8 +596,6 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // row tiles per wave: two share every B fragment while the state fits (d <= 8); option "rows_per_lane" = 1 / 2 forces it
     int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= MFMA_NARROW_MAXK2 ? 2 : 1));
     if (K2 > 8) rt = 1;
-    const int64_t rowtiles = (n + 32 * rt - 1) / (32 * rt);
-    const int64_t npad = rowtiles * 32 * rt;
     // grid = a whole number (4) of rounds of resident waves: a fractional last round costs up to one round of idle SIMDs
     int nb = 16;
 #define CG_NB_CASE(K) case K: nb = mfma_blocks<K>(rt); break;
@@ -605,27 +604,47 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
         default: break;
     }
 #undef CG_NB_CASE
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
-    int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + rowtiles / 2) / rowtiles);
-    // GP-sized problems (n = 8k ... 32k): a wave's prologue (row fragments), pipeline fill and epilogue (shuffles, slab row) are
-    // worth ~40 column tiles of work, so the split stops at 64 tiles per wave — as long as the grid still holds >= 2048 waves,
-    // half of the chip's wave slots (tools/eq_small_sweep.py: d = 3, n = 16384 45.9 -> 37.9 us, n = 32768 118.8 -> 113.1;
-    // d = 8, n = 16384 60.9 -> 47.4, n = 32768 175 -> 152; n = 8192 17.7 -> 16.9 / 25.3 -> 21.8 us)
-    // (few rows — prediction shapes —: the 2048-wave floor itself stops at 16 tiles per wave: 256 x 65536, d = 3: 26.8 -> 22.2 us)
-    if (ctx->jsplit <= 0) js = std::max<int64_t>(std::min<int64_t>((2048 + rowtiles - 1) / rowtiles, std::max<int64_t>(1, ntile / 16)),
-                                                 std::min<int64_t>(js, std::max<int64_t>(1, ntile / 64)));
-    js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));     // >= 8 tiles (256 columns) per wave
-    const int64_t tchunk = (ntile + js - 1) / js;
-    js = (ntile + tchunk - 1) / tchunk;
+    struct Plan { int rt; int64_t rowtiles, npad, js, tchunk; bool lds4; };
+    auto plan_for = [&](int r) {
+        Plan pl; pl.rt = r;
+        pl.rowtiles = (n + 32 * r - 1) / (32 * r);
+        pl.npad = pl.rowtiles * 32 * r;
+        const int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * nb * 4;
+        int64_t js = ctx->jsplit > 0 ? ctx->jsplit : std::max<int64_t>(1, (target + pl.rowtiles / 2) / pl.rowtiles);
+        // GP-sized problems (n = 8k ... 32k): a wave's prologue (row fragments), pipeline fill and epilogue (shuffles, slab row) are
+        // worth ~40 column tiles of work, so the split stops at 64 tiles per wave — as long as the grid still holds >= 2048 waves,
+        // half of the chip's wave slots (tools/eq_small_sweep.py: d = 3, n = 16384 45.9 -> 37.9 us, n = 32768 118.8 -> 113.1;
+        // d = 8, n = 16384 60.9 -> 47.4, n = 32768 175 -> 152; n = 8192 17.7 -> 16.9 / 25.3 -> 21.8 us)
+        // (few rows — prediction shapes —: the 2048-wave floor itself stops at 16 tiles per wave: 256 x 65536, d = 3: 26.8 -> 22.2 us)
+        if (ctx->jsplit <= 0) js = std::max<int64_t>(std::min<int64_t>((2048 + pl.rowtiles - 1) / pl.rowtiles, std::max<int64_t>(1, ntile / 16)),
+                                                     std::min<int64_t>(js, std::max<int64_t>(1, ntile / 64)));
+        js = std::max<int64_t>(1, std::min<int64_t>(js, std::max<int64_t>(1, ntile / 8)));     // >= 8 tiles (256 columns) per wave
+        pl.tchunk = (ntile + js - 1) / js;
+        pl.js = (ntile + pl.tchunk - 1) / pl.tchunk;
+        // long column chunks: four waves of a workgroup share every column tile through LDS; short chunks would only pay its
+        // prologue and barriers (tools/mfma_lds_ab.py)
+        pl.lds4 = ((r >= 2 && K2 <= MFMA_NARROW_MAXK2) || (r == 1 && K2 > MFMA_NARROW_MAXK2)) &&
+                  (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && pl.tchunk >= MFMA_LDS_MIN_TILES && pl.rowtiles >= 64));
+        return pl;
+    };
+    Plan pl = plan_for(rt);
+    // d = 7, 8 (four MFMAs per tile) on the LDS-shared form: FOUR row tiles per wave, two waves per SIMD (round 4) — every column fragment
+    // read from LDS, every LDS-DMA issue and every stage barrier serves twice the pairs: C3's row shard 4.31 -> 4.13 ms, a 16384-row shard
+    // of 131072 columns 313 -> 305 us, 131072^2 at d = 7 1.565 -> 1.516 ms (tools/c3_rt_ab.py; d = 5, 6: 3.67 -> 3.66, left alone).
+    // Option "rows_per_lane" = 4 asks for it wherever the instance exists (K2 = 3, 4), 2 keeps two row tiles.
+    if ((K2 == 3 || K2 == 4) && pl.lds4 && pl.rt == 2 && (ctx->rows_per_lane == 4 || (ctx->rows_per_lane == 0 && K2 == 4 && !ctx->mfma_stamp))) {
+        const Plan p4 = plan_for(4);
+        if (p4.lds4) pl = p4;
+    }
+    rt = pl.rt;
+    const int64_t rowtiles = pl.rowtiles, npad = pl.npad, tchunk = pl.tchunk;
+    const int64_t js = pl.js;
+    const bool lds4 = pl.lds4;
     const double alpha_eff = alpha * hk.kp.scale;
     float* out = y;
     if (js > 1) { void* slab; rc = ws_reserve(ctx, 1, (size_t)js * npad * sizeof(float), &slab); if (rc) return rc; out = (float*)slab; }
     const dim3 grid((unsigned)rowtiles, (unsigned)js);
     const int fs = js == 1 ? 1 : 0;
-    // long column chunks: four waves of a workgroup share every column tile through LDS; short chunks would only pay its
-    // prologue and barriers (tools/mfma_lds_ab.py)
-    const bool lds4 = ((rt == 2 && K2 <= MFMA_NARROW_MAXK2) || (rt == 1 && K2 > MFMA_NARROW_MAXK2)) &&
-                      (ctx->mfma_lds == 1 || (ctx->mfma_lds < 0 && tchunk >= MFMA_LDS_MIN_TILES && rowtiles >= 64));
     // option "mfma_stamp": the clock-stamping diagnostic build of the two LDS-shared instances (C2's and C3's kernels)
     unsigned long long* stamps = nullptr;
     ctx->stamp_count = 0;

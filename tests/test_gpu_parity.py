@@ -743,9 +743,9 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
             ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, np.float32)
             outs = {}
             # (dense_variant, rows_per_lane, mfma_lds, jsplit): mfma_lds = 1 makes four waves share the column tiles through
-            # LDS (d <= 8 with two row tiles per wave, d > 8 with one), jsplit = 3 gives ragged column chunks (stage counts
+            # LDS (d <= 8 with two row tiles per wave — four with rows_per_lane = 4 at d = 5 ... 8 —, d > 8 with one), jsplit = 3 gives ragged column chunks (stage counts
             # not a multiple of the 4 waves / odd tile counts)
-            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 3), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (0, 0, -1, 0)):
+            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 3), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (2, 4, 1, 0), (2, 4, 1, 3), (0, 0, -1, 0)):
                 cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds); cg.set_option("jsplit", js)
                 yd = torch.from_numpy(y0.copy()).cuda()
                 cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
@@ -755,6 +755,7 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
             assert relerr(outs[(2, 2, 0, 0)], outs[(1, 0, -1, 0)]) <= 5e-6
             assert np.array_equal(outs[(2, 2, 0, 0)], outs[(2, 2, 1, 0)])      # same tiles, same order: bit-identical
             assert np.array_equal(outs[(2, 1, 0, 0)], outs[(2, 1, 1, 0)])      # (d > 8: one tile per stage, slices split over the waves)
+            assert np.array_equal(outs[(2, 4, 1, 3)], outs[(2, 2, 1, 3)])      # four row tiles per wave (d = 5 ... 8; elsewhere the option means two): same column chunks, same sums
             # beta == 0 ignores NaN in y
             cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
             yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
@@ -776,16 +777,20 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
     G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.8), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
     ad = torch.from_numpy(a).cuda()
     try:
+        cg.set_option("rows_per_lane", 2)       # d = 7: the automatic choice is four row tiles per wave (other column chunks: checked below)
         cg.set_option("mfma_lds", 0); b0 = (G @ ad).cpu().numpy()
         assert cg.get_info("last_mfma_lds") == 0
         cg.set_option("mfma_lds", -1); b1 = (G @ ad).cpu().numpy()
         assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_lds") == 1
         cg.set_option("mfma_lds", 1); b2 = (G @ ad).cpu().numpy()
+        cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); b3 = (G @ ad).cpu().numpy()
+        assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_lds") == 1
     finally:
-        cg.set_option("mfma_lds", -1)
+        cg.set_option("mfma_lds", -1); cg.set_option("rows_per_lane", 0)
     rows = np.r_[0:40, n // 2:n // 2 + 40, n - 40:n]
     want = oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.8), X[rows], Y, a, dtype=np.float32)
-    assert relerr(b1[rows], want) <= 1e-5
+    assert relerr(b1[rows], want) <= 1e-5 and relerr(b3[rows], want) <= 1e-5
+    assert np.isfinite(b3).all() and relerr(b3, b1) <= 2e-6
     assert np.array_equal(b0, b1) and np.array_equal(b1, b2)
     assert np.isfinite(b1).all()
 
@@ -1050,7 +1055,7 @@ def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
             assert rowwise_err(b, ref, absref, L) <= 1e-5, (name, d, rowwise_err(b, ref, absref, L), L.max())
             print(f"band d={d} {name}: path {path} norm-wise {relerr(b, ref):.2e} row-wise {rowwise_err(b, ref, absref):.2e} scaled {rowwise_err(b, ref, absref, L):.2e} Lmax {L.max():.1f}")
             if path == 2:      # where the gate admits the matrix cores: every variant of that kernel
-                for rpl, lds in ((1, 0), (2, 0), (2, 1), (1, 1)):
+                for rpl, lds in ((1, 0), (2, 0), (2, 1), (1, 1), (4, 1)):
                     cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds)
                     b2 = (G @ ad).cpu().numpy()
                     assert cg.get_info("last_dense_path") == 2
