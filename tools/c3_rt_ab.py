@@ -15,8 +15,8 @@ def timed(fn, reps):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-cases = [(524288, 65536, 8, 5), (524288, 65536, 6, 5), (131072, 16384, 8, 20), (131072, 131072, 7, 5), (32768, 32768, 8, 20)]
-opts = [int(v) for v in sys.argv[1:]] or [0, 4]
+cases = [(524288, 65536, 8, 5), (524288, 65536, 6, 5), (131072, 16384, 8, 20), (131072, 131071, 7, 5), (32768, 32767, 8, 20), (131072, 131071, 3, 5), (131072, 16384, 3, 20), (65536, 65535, 2, 10), (131072, 131071, 4, 5)]
+opts = [int(v) for v in sys.argv[1:]] or [2, 0, 4]
 for n, per, d, reps in cases:
     X = torch.from_numpy(np.random.default_rng(0xC0F + 2).standard_normal((n, d)).astype(np.float32)).cuda()
     a = torch.from_numpy(np.random.default_rng(3).standard_normal(n).astype(np.float32)).cuda()
