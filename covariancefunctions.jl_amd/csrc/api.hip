@@ -536,6 +536,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "toeplitz_fused")) ctx->toeplitz_fused = value;
     else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
     else if (!strcmp(key, "toeplitz_persist")) ctx->toeplitz_persist = value;
+    else if (!strcmp(key, "mfma_f16")) ctx->mfma_f16 = value;
     else if (!strcmp(key, "toeplitz_real_spectrum")) ctx->toeplitz_real_spectrum = value;
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;
@@ -567,6 +568,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_mfma_sym")) *value = ctx->last_mfma_sym;
     else if (!strcmp(key, "last_dense_sym")) *value = ctx->last_dense_sym;
     else if (!strcmp(key, "last_dense_bcast")) *value = ctx->last_dense_bcast;
+    else if (!strcmp(key, "last_mfma_f16")) *value = ctx->last_mfma_f16;
     else if (!strcmp(key, "last_inkernel_reduce")) *value = ctx->last_inkernel_reduce;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;

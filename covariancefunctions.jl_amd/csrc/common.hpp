@@ -194,6 +194,8 @@ struct covgram_ctx {
     int64_t mfma_mrhs = -1;         // matrix right-hand sides on the fp32 matrix cores (dense_mfma_mrhs_kernel): -1 from 5 (9: cheap profiles, d <= 3) columns, 0 never, 1 from 2
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
+    int64_t mfma_f16 = -1;         // general matrix-core EQ kernel: the fp16 two-way split (half the MFMAs per tile): -1 / 1 = within MFMA_F16_GATE, 0 = never, 2 = within MFMA_GATE (measurements only)
+    int64_t last_mfma_f16 = 0;
     int64_t toeplitz_persist = -1; // fused radix-16 row kernel: persistent workgroups (one per CU; a value > 1 = that many) that prefetch the next row pair into registers: -1 = fp64 only (measured), 0 = one pair per workgroup, 1 = always
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     int num_cus = 256;
@@ -238,7 +240,7 @@ struct covgram_points {
     // used slot IN PLACE, ordered on the ctx stream behind the MVMs that read it — no hipFree, no stream synchronisation and no
     // allocation on the MVM path once the slots exist (a slot is allocated the first time it is needed and lives as long as the handle)
     static constexpr int FRAG_SLOTS = 4;
-    struct FragSlot { void* ptr = nullptr; size_t bytes = 0; float g = 0; int k2 = 0; uint64_t used = 0; bool pinned = false; };   // pinned: handed out during a stream capture — a graph has its address baked in, so it is never re-packed or freed while the handle lives
+    struct FragSlot { void* ptr = nullptr; size_t bytes = 0; float g = 0; int k2 = 0; int fmt = 0; uint64_t used = 0; bool pinned = false; };   // pinned: handed out during a stream capture — a graph has its address baked in, so it is never re-packed or freed while the handle lives
     mutable FragSlot frag[FRAG_SLOTS];
     mutable uint64_t frag_clock = 0;
 };
@@ -311,6 +313,10 @@ constexpr int64_t MFMA_SYM_MIN_N_EQ = 18000;        // EQ, d <= 4
 constexpr int64_t MFMA_SYM_MIN_N_EQ_WIDE = 15000;   // EQ, d > 4, and the cheap generic profiles (Cauchy, IMQ, Dot^p, ...)
 constexpr int64_t MFMA_SYM_MIN_N_HEAVY = 12500;     // MaternP, RQ, composites
 constexpr double MFMA_GATE = 126.0;
+// the fp16 two-way split of the general EQ kernel (dense_mfma.hip, "Which split"): admitted up to this g^2 R^2.  Its worst case — both clouds
+// on the gate's sphere and aligned (tests: "wide aligned") — measured 1.09e-5 row-wise at g^2 R^2 = 96 against the bf16 split's 7.2e-6, growing
+// linearly with the bound: 8.2e-6 at 72, what the bf16 split shows at 110 of its 126 (tools/f16_split_ab.py: typical clouds differ by < 10 %)
+constexpr double MFMA_F16_GATE = 72.0;
 constexpr double GRAD_EXPAND_GATE = 1000.0;   // gamma^2 R^2 up to which the fp64 gradient kernel expands |x - y|^2 (abs. error ~1e-16 R^2; grad_mvm.hpp)
 double gate_radius2(const covgram_points* X, const covgram_points* Y);
 int points_max_norm2(covgram_points* p);

@@ -55,7 +55,7 @@ namespace covgram {
 //   PB[(T * K2 + mm) * 64 + l] = that fragment (zero outside the point set / dimension)
 //   EF[32 T + r]               = exp2(f_j) in (1/2, 1]                          (0 for padding columns)
 __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict__ Y, int64_t m, int32_t d, uint4* __restrict__ PB,
-                                                        float* __restrict__ EF, int32_t K2, float g, const float* __restrict__ Cn) {
+                                                        float* __restrict__ EF, int32_t K2, float g, const float* __restrict__ Cn, int32_t fmt) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -64,6 +64,32 @@ __global__ __launch_bounds__(256) void mfma_pack_kernel(const float* __restrict_
     const int mm = (int)(q % K2);
     const int64_t T = q / K2;
     const int64_t j = 32 * T + (l & 31);
+    if (fmt == 1) {
+        // fp16 two-way split: lane (r, h) of MFMA mm holds coordinates c0 = 4 mm + 2 h and c0 + 1 of column j as
+        // [y1, y2, y1 | y1, y2, y1 | 1, k_j] — the last two slots in lane half 0 of MFMA 0 only (dense_mfma.hpp: eq_row_fragments_h)
+        const int c0 = 4 * mm + 2 * (l >> 5);
+        const bool nl = mm == 0 && (l >> 5) == 0;
+        uint4 frag = make_uint4(0, 0, 0, 0);
+        if (j < m) {
+            const float ya = c0 < d ? g * (Y[j * (int64_t)d + c0] - Cn[c0]) : 0.0f;
+            const float yb = c0 + 1 < d ? g * (Y[j * (int64_t)d + c0 + 1] - Cn[c0 + 1]) : 0.0f;
+            unsigned a1, a2, b1, b2;
+            split2h(ya, a1, a2);
+            split2h(yb, b1, b2);
+            frag = make_uint4(a1 | (a2 << 16), a1 | (b1 << 16), b2 | (b1 << 16), 0u);
+            if (nl) {
+                double ny = 0.0;
+                for (int cc = 0; cc < d; ++cc) { const double yc = (double)(g * (Y[j * (int64_t)d + cc] - Cn[cc])); ny = __builtin_fma(yc, yc, ny); }
+                const double hn = -0.5 * ny, k = __builtin_ceil(hn);
+                frag.w = F16_ONE | (f16_bits((float)k) << 16);
+                EF[j] = __builtin_amdgcn_exp2f((float)(hn - k));
+            }
+        } else if (nl) {
+            EF[j] = 0.0f;
+        }
+        PB[e] = frag;
+        return;
+    }
     const int c = 2 * mm + (l >> 5);
     uint4 frag = make_uint4(0, 0, 0, 0);
     const bool norm_lane = (d & 1) ? (c == d) : (c == 0);          // the lane that carries k_j (one per column)
@@ -100,7 +126,7 @@ __global__ __launch_bounds__(256) void mfma_pack_w_kernel(const float* __restric
 // STAMP = 1: the diagnostic build of the SAME loop that reads the shader clock (s_memtime) and the constant 100 MHz counter
 // (s_memrealtime) around the column loop of every workgroup — clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md,
 // DVFS give-back item 6).  The stamps go to a buffer of their own; no product launch ever runs this instantiation.
-template <int K2, int RT, int WPB = 1, int LDS = 0, int STAMP = 0>
+template <int K2, int RT, int WPB = 1, int LDS = 0, int STAMP = 0, int FMT = 0>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS == 1 ? (RT == 4 ? 2 : K2 <= 2 ? 4 : 3) : 1, LDS == 1 ? (RT == 4 ? 2 : K2 <= 2 ? 4 : 3) : 8))) void dense_mfma_eq_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                            const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
@@ -118,7 +144,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     for (int r = 0; r < RT; ++r) {
         int64_t row = i0 + 32 * r + t;
         if (row >= n) row = n - 1;                               // clamp: computed, never stored
-        er[r] = eq_row_fragments<K2>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
+        er[r] = eq_row_fragments_fmt<K2, FMT>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
     }
 
     unsigned long long st_c0 = 0, st_r0 = 0;
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         for (int r = 0; r < RT; ++r) {
             D[r] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int mm = 0; mm < K2; ++mm) D[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D[r], 0, 0, 0);
+            for (int mm = 0; mm < K2; ++mm) D[r] = eq_mma<FMT>(a[r][mm], f[mm], D[r]);
         }
         // all exponentials of the tile first, then the weighted accumulation: no exp -> fma wait states in between
 #pragma unroll
@@ -187,7 +213,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
                 Frag f; f.u = TF[mm][l];                                                        \
-                D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mm].v, f.v, D, 0, 0, 0);       \
+                D = eq_mma<FMT>(a[0][mm], f, D);                                                \
             }                                                                                   \
             const float w = TW[t];                                                              \
             _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]); \
@@ -501,7 +527,7 @@ static int mfma_blocks(int rt) {
     return mfma_blocks_per_cu<K2, 1>();
 }
 
-template <int K2>
+template <int K2, int FMT = 0>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
                         int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn,
                         unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal) {
@@ -509,25 +535,25 @@ static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const floa
     unsigned long long* const ns = nullptr;
     if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         *launched = dim3((grid.x + 7) / 8, grid.y);
-        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
-        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal); return; } }
-        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2)>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal); return; } }
+        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     }
 }
 
 // the column fragments and norm fraction factors of point set Y for (g, K2): packed once into the handle and reused by every
 // later MVM (they depend on the points and the lengthscale only; the kernels form the weights a_j EF[j] themselves)
-static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float g, const float* Cn, const uint4** PB, const float** EF) {
+static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float g, const float* Cn, const uint4** PB, const float** EF, int fmt = 0) {
     const int64_t m = Y->n, ntile = (m + 31) / 32;
     const size_t fbytes = (size_t)ntile * K2 * 64 * sizeof(uint4);
     const size_t total = fbytes + (size_t)ntile * 32 * sizeof(float);   // fragments + EF
@@ -538,7 +564,7 @@ static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = ctx->stream && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     for (auto& f : Y->frag) {
-        if (f.ptr && f.bytes == total && f.g == g && f.k2 == K2) { hit = &f; break; }
+        if (f.ptr && f.bytes == total && f.g == g && f.k2 == K2 && f.fmt == fmt) { hit = &f; break; }
         if (f.pinned) continue;
         // reuse order: an empty slot first, then a slot of another size (its buffer is replaced), then the least recently used
         const auto rank = [&](const covgram_points::FragSlot& s) { return !s.ptr ? 0 : (s.bytes != total ? 1 : 2); };
@@ -558,10 +584,10 @@ static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float
             victim->bytes = total;
         }
         // in place, stream-ordered behind every MVM that still reads this slot
-        victim->g = g; victim->k2 = K2;
+        victim->g = g; victim->k2 = K2; victim->fmt = fmt;
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, Y->d,
-                           (uint4*)victim->ptr, (float*)((char*)victim->ptr + fbytes), K2, g, Cn);
+                           (uint4*)victim->ptr, (float*)((char*)victim->ptr + fbytes), K2, g, Cn, fmt);
         hit = victim;
     }
     if (capturing) hit->pinned = true;
@@ -576,14 +602,24 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
                 double alpha, double beta) {
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
-    const int K2 = eq_k2_for(d);
+    // Which split (round 4).  The bf16 three-way split is exact to 2^-24 |x~_c y~_c| per coordinate and costs one MFMA per TWO coordinates.  The
+    // fp16 two-way split (x~ = h1 + h2, 11 + 11 bits; products h1 h1, h1 h2, h2 h1) drops terms of ~2^-22 |x~_c y~_c| — the size of ONE fp32 rounding
+    // of the dot product itself, which the accumulator commits anyway — and covers FOUR coordinates per MFMA: half the matrix-core work per pair.
+    // The d = 5 ... 8 kernels are power-bound (2.0 GHz under C3's shard kernel, profiles/r04_c3_power_bound.txt), so that is both fewer cycles and a
+    // higher clock.  Taken while BOTH clouds lie within g^2 R^2 <= MFMA_F16_GATE (the added exponent error grows with the radius like the
+    // accumulator's own: common.hpp); beyond it, up to MFMA_GATE, the bf16 split serves as before.  Option "mfma_f16": -1 / 1 = this rule,
+    // 0 = never, 2 = wherever the matrix-core gate admits the cloud (measurements: tools/f16_split_ab.py).
+    const double g2r2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale) * gate_radius2(X, Y);
+    const int fmt = (ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? MFMA_GATE : MFMA_F16_GATE)) ? 1 : 0;
+    ctx->last_mfma_f16 = fmt;
+    const int K2 = fmt ? eq_k2_for(2 * ((d + 3) / 4)) : eq_k2_for(d);      // fp16: one MFMA per four coordinates
     CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma: d = %d has no matrix-core instance", d);
     const int64_t ntile = (m + 31) / 32;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)Y->center;                    // both sides are taken relative to the column side's centre
     const uint4* PB;
     const float* EF;
-    int rc = eq_fragments(ctx, Y, K2, g, Cn, &PB, &EF);
+    int rc = eq_fragments(ctx, Y, K2, g, Cn, &PB, &EF, fmt);
     if (rc) return rc;
     // the weights a_j exp2(f_j) of THIS right-hand side (the in-kernel product — two loads and a multiply per column tile in
     // place of this 4 us launch — measured 3 % slower on C2 in round 2, as in round 1)
@@ -670,7 +706,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
     ctx->last_mfma_lds = lds4 ? 1 : 0;
     dim3 launched;
-#define CG_MFMA_CASE(K) case K: launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); break;
+#define CG_MFMA_CASE(K) case K: if (fmt) { if constexpr (K <= 8) launch_mfma<K, 1>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); } else launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;

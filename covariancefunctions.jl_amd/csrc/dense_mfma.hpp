@@ -30,10 +30,31 @@ __device__ __forceinline__ void split3(float f, unsigned& p1, unsigned& p2, unsi
     p3 = bf16_bits(r2);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union Frag {
     uint4 u;
     bf16x8 v;
+    f16x8 hv;
 };
+
+// ---- the fp16 two-way split of the general EQ kernel (round 4; dense_mfma.hip, "Which split") ----------------------------------
+// f = h1 + h2 (+ O(2^-23 f)) with fp16 pieces (11 significant bits each; |f| <= sqrt(126): no overflow, and pieces below 6e-5 are fp16
+// subnormals with an ABSOLUTE resolution of 6e-8 — the exponent's error budget is absolute)
+__device__ __forceinline__ unsigned f16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ void split2h(float f, unsigned& h1, unsigned& h2) {
+    const _Float16 a = (_Float16)f;
+    h1 = (unsigned)__builtin_bit_cast(unsigned short, a);
+    h2 = f16_bits(f - (float)a);
+}
+constexpr unsigned F16_ONE = 0x3C00u;
+// MFMAs per tile: a lane's 8 K-slots hold TWO coordinates x 3 products (x1 y1, x1 y2, x2 y1) + two slots for the norms' integer parts
+// (used by lane half 0 of MFMA 0 only), so one v_mfma_f32_32x32x16_f16 covers four coordinates
+template <int FMT> constexpr int eq_coords_per_mfma = FMT == 1 ? 4 : 2;
+template <int FMT>
+__device__ __forceinline__ f32x16 eq_mma(const Frag& a, const Frag& b, f32x16 c) {
+    if constexpr (FMT == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hv, b.hv, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
 
 
 constexpr unsigned BF16_ONE = 0x3F80u;
@@ -85,6 +106,36 @@ __device__ __forceinline__ float eq_row_fragments(const float* __restrict__ xr, 
         a[0].u.w = s.kbits | (BF16_ONE << 16);
     }
     return s.ef;
+}
+
+// the same for the fp16 two-way split: lane (t, h) of MFMA mm holds coordinates 4 mm + 2 h and 4 mm + 2 h + 1 as [x1, x1, x2 | x1, x1, x2 | k_i, 1]
+// (the last two slots in lane half 0 of MFMA 0 only, zero elsewhere), against the column side's [y1, y2, y1 | y1, y2, y1 | 1, k_j]
+template <int K2>
+__device__ __forceinline__ float eq_row_fragments_h(const float* __restrict__ xr, const float* __restrict__ Cn, int d, float g, int h,
+                                                    Frag (&a)[K2]) {
+    double part = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < K2; ++mm) {
+        const int c0 = 4 * mm + 2 * h;
+        const float xa = (c0 < d) ? g * (xr[c0] - Cn[c0]) : 0.0f;
+        const float xb = (c0 + 1 < d) ? g * (xr[c0 + 1] - Cn[c0 + 1]) : 0.0f;
+        part = __builtin_fma((double)xa, (double)xa, part);
+        part = __builtin_fma((double)xb, (double)xb, part);
+        unsigned a1, a2, b1, b2;
+        split2h(xa, a1, a2);
+        split2h(xb, b1, b2);
+        a[mm].u = make_uint4(a1 | (a1 << 16), a2 | (b1 << 16), b1 | (b2 << 16), 0u);
+    }
+    const double n2 = part + __shfl_xor(part, 32);
+    const double hn = -0.5 * n2;
+    const double k = __builtin_ceil(hn);
+    if (h == 0) a[0].u.w = f16_bits((float)k) | (F16_ONE << 16);
+    return __builtin_amdgcn_exp2f((float)(hn - k));
+}
+template <int K2, int FMT>
+__device__ __forceinline__ float eq_row_fragments_fmt(const float* __restrict__ xr, const float* __restrict__ Cn, int d, float g, int h, Frag (&a)[K2]) {
+    if constexpr (FMT == 1) return eq_row_fragments_h<K2>(xr, Cn, d, g, h, a);
+    else return eq_row_fragments<K2>(xr, Cn, d, g, h, a);
 }
 
 // EQ and MaternP take the dense path's FOLDED parameter block here too (log2(e) and sqrt(2p+1) in the coordinate pre-scale,

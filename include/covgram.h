@@ -163,12 +163,15 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "dense_bcast" (the same register-broadcast scheme for the fp64 dense value MVM of the isotropic kernels, one right-hand side:
  * |x - y|^2 expanded around cached norms, one v_fmac_f64_dpp per dimension and pair, all-entries and upper-triangle-once kernels:
  * -1 = from padded d = 16 up to d = 64 inside the gamma^2 R^2 <= 1000 gate of "grad_expand", 0 = never, 1 = wherever it applies, d >= 8),
+ * "mfma_f16" (the general matrix-core EQ kernel's split of the coordinates: -1 / 1 = the fp16 two-way split — 3 products per coordinate, one MFMA per
+ * FOUR coordinates, half the matrix-core work of the bf16 three-way split — while both clouds lie within g^2 R^2 <= 72 and the bf16 split beyond,
+ * 0 = always the bf16 split, 2 = the fp16 split up to the matrix-core gate of 126: measurements only),
  * "mfma_stamp" (1 = the general matrix-core EQ kernel runs its clock-stamping DIAGNOSTIC build — s_memtime / s_memrealtime
  * around every workgroup's column loop, for bench.py's sustained-clock figure; never set in production). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_mfma_f16" (1: the last general matrix-core EQ MVM ran the fp16 two-way split), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);

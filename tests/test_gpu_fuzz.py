@@ -65,6 +65,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
             a = rng.standard_normal(n).astype(dt); y0 = rng.standard_normal(n).astype(dt)
             cg.set_option("mfma_sym", 1); cg.set_option("dense_variant", int(rng.choice([0, 2]))); cg.set_option("jsplit", int(rng.choice([0, 0, 2, 5])))
             cg.set_option("dense_sym", 1)                     # the direct-difference symmetric kernels (fp64, fp32) wherever they are eligible
+            cg.set_option("mfma_f16", int(rng.choice([-1, 0, 1])))      # fp32 EQ on the matrix cores: fp16 two-way / bf16 three-way split of the coordinates
             cg.set_option("dense_bcast", int(rng.choice([-1, 0, 1])))   # fp64: expanded distance with broadcast records — by rule, never, from d = 8
             Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
             G = cg.gramian(k, Xd)
@@ -84,7 +85,7 @@ def test_random_symmetric_cases(cg, oracle, seed):
                 e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))
                 assert e <= tol, (name, d, n, world, e)
     finally:
-        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1); cg.set_option("dense_bcast", -1)
+        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1); cg.set_option("dense_bcast", -1); cg.set_option("mfma_f16", -1)
 
 
 @pytest.mark.parametrize("seed", range(4))

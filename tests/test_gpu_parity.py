@@ -742,16 +742,24 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
             G = cg.gramian(k, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
             ref = oracle.mul(y0, ko, X, Y, a, -0.7, 1.3, np.float32)
             outs = {}
-            # (dense_variant, rows_per_lane, mfma_lds, jsplit): mfma_lds = 1 makes four waves share the column tiles through
+            # both splits of the coordinates (round 4): the sweep below under the fp16 two-way split (option mfma_f16 = 1: one MFMA per four
+            # coordinates), then, last, under the bf16 three-way split (0); the comparisons behind the sweep see the bf16 results
+            for f16 in (1, 0):
+              cg.set_option("mfma_f16", f16)
+              # (dense_variant, rows_per_lane, mfma_lds, jsplit): mfma_lds = 1 makes four waves share the column tiles through
             # LDS (d <= 8 with two row tiles per wave — four with rows_per_lane = 4 at d = 5 ... 8 —, d > 8 with one), jsplit = 3 gives ragged column chunks (stage counts
             # not a multiple of the 4 waves / odd tile counts)
-            for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 3), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (2, 4, 1, 0), (2, 4, 1, 3), (0, 0, -1, 0)):
+              for variant, rpl, lds, js in ((1, 0, -1, 0), (2, 1, 0, 0), (2, 1, 1, 0), (2, 1, 1, 3), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 3), (2, 4, 1, 0), (2, 4, 1, 3), (0, 0, -1, 0)):
                 cg.set_option("dense_variant", variant); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds); cg.set_option("jsplit", js)
                 yd = torch.from_numpy(y0.copy()).cuda()
                 cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
                 assert cg.get_info("last_dense_path") == (1 if variant == 1 else 2), (variant, d)
-                outs[(variant, rpl, lds, js)] = yd.cpu().numpy()
-                assert relerr(yd.cpu().numpy(), ref) <= 1e-5, (variant, rpl, lds, js, d, n, m, relerr(yd.cpu().numpy(), ref))
+                assert variant == 1 or cg.get_info("last_mfma_f16") == f16, (variant, d, f16)
+                outs[(("h",) if f16 else ()) + (variant, rpl, lds, js)] = yd.cpu().numpy()
+                assert relerr(yd.cpu().numpy(), ref) <= 1e-5, (f16, variant, rpl, lds, js, d, n, m, relerr(yd.cpu().numpy(), ref))
+            assert np.array_equal(outs[("h", 2, 2, 0, 0)], outs[("h", 2, 2, 1, 0)]) and np.array_equal(outs[("h", 2, 1, 0, 0)], outs[("h", 2, 1, 1, 0)])
+            assert np.array_equal(outs[("h", 2, 4, 1, 3)], outs[("h", 2, 2, 1, 3)])
+            assert relerr(outs[("h", 2, 2, 0, 0)], outs[(2, 2, 0, 0)]) <= 2e-6      # the two splits agree far inside the tolerance
             assert relerr(outs[(2, 2, 0, 0)], outs[(1, 0, -1, 0)]) <= 5e-6
             assert np.array_equal(outs[(2, 2, 0, 0)], outs[(2, 2, 1, 0)])      # same tiles, same order: bit-identical
             assert np.array_equal(outs[(2, 1, 0, 0)], outs[(2, 1, 1, 0)])      # (d > 8: one tile per stage, slices split over the waves)
@@ -762,7 +770,7 @@ def test_eq_matrix_core_path_matches_direct_differences(cg, oracle, d):
             cg.mul_(yn, G, torch.from_numpy(a).cuda(), 1.0, 0.0)
             assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, Y, a, 1.0, 0.0, np.float32)) <= 1e-5
     finally:
-        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0)
+        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("jsplit", 0); cg.set_option("mfma_f16", -1)
 
 
 @pytest.mark.parametrize("d", [3, 7, 20])
@@ -777,6 +785,9 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
     G = cg.gramian(cg.Lengthscale(cg.EQ(), 0.8), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
     ad = torch.from_numpy(a).cuda()
     try:
+        # d = 20 under the bf16 three-way split: K2 = 12, the one-tile-per-stage LDS form (under the fp16 split d = 20 is K2 = 6 and the planner
+        # keeps its shorter column chunks off LDS at this size); d = 3, 7 run the default, the fp16 two-way split
+        cg.set_option("mfma_f16", 0 if d == 20 else -1)
         cg.set_option("rows_per_lane", 2)       # d = 7: the automatic choice is four row tiles per wave (other column chunks: checked below)
         cg.set_option("mfma_lds", 0); b0 = (G @ ad).cpu().numpy()
         assert cg.get_info("last_mfma_lds") == 0
@@ -786,7 +797,7 @@ def test_eq_matrix_core_lds_sharing_at_size(cg, oracle, d):
         cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); b3 = (G @ ad).cpu().numpy()
         assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_lds") == 1
     finally:
-        cg.set_option("mfma_lds", -1); cg.set_option("rows_per_lane", 0)
+        cg.set_option("mfma_lds", -1); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_f16", -1)
     rows = np.r_[0:40, n // 2:n // 2 + 40, n - 40:n]
     want = oracle.mul(None, oracle.Kernel(oracle.EQ, lengthscale=0.8), X[rows], Y, a, dtype=np.float32)
     assert relerr(b1[rows], want) <= 1e-5 and relerr(b3[rows], want) <= 1e-5
@@ -1023,6 +1034,7 @@ def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
         return u
 
     e1 = np.zeros(d); e1[0] = 1.0
+    f16_seen = False
     cases = []
     # (name, X~, Y~, expected path under dense_variant 0: 1 direct differences, 2 matrix cores)
     for off, ry in ((14.0, 7.0), (16.0, 7.0), (18.0, 5.0), (17.5, 6.9)):
@@ -1038,6 +1050,11 @@ def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
     cases.append(("wide aligned", ball(400, 9.8), ball(500, 9.8), 2))
     # a compact X well inside a wide Y and vice versa
     cases.append(("compact in wide", ball(300, 2.0) + 5.0 * e1, ball(800, 9.8), 2))
+    # wide and aligned again, near the edge of the fp16 split's gate (7.5^2 = 56; the bound on the radii about the sample centres ~67 <= 72); last and from its own stream, so that the cases above keep
+    # the data they always had
+    st = rng.bit_generator.state; rng = np.random.default_rng(4300 + d)
+    cases.append(("wide aligned 7.5", ball(400, 7.5), ball(500, 7.5), 2))
+    rng = np.random.default_rng(0); rng.bit_generator.state = st
     try:
         for name, Xs, Ys, path in cases:
             X = (Xs / SQRT_LOG2E + 3.0).astype(np.float32); Y = (Ys / SQRT_LOG2E + 3.0).astype(np.float32)   # a common offset changes nothing
@@ -1055,13 +1072,14 @@ def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
             assert rowwise_err(b, ref, absref, L) <= 1e-5, (name, d, rowwise_err(b, ref, absref, L), L.max())
             print(f"band d={d} {name}: path {path} norm-wise {relerr(b, ref):.2e} row-wise {rowwise_err(b, ref, absref):.2e} scaled {rowwise_err(b, ref, absref, L):.2e} Lmax {L.max():.1f}")
             if path == 2:      # where the gate admits the matrix cores: every variant of that kernel
-                for rpl, lds in ((1, 0), (2, 0), (2, 1), (1, 1), (4, 1)):
-                    cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds)
+                for rpl, lds, f16 in ((1, 0, 0), (2, 0, 0), (2, 1, 0), (1, 1, 0), (4, 1, 0), (2, 0, 1), (2, 1, 1), (1, 1, 1), (4, 1, 1)):
+                    cg.set_option("dense_variant", 2); cg.set_option("rows_per_lane", rpl); cg.set_option("mfma_lds", lds); cg.set_option("mfma_f16", f16)
                     b2 = (G @ ad).cpu().numpy()
-                    assert cg.get_info("last_dense_path") == 2
+                    assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_f16") in (0, f16)     # fp16 split: only inside ITS gate (72)
+                    f16_seen = f16_seen or cg.get_info("last_mfma_f16") == 1
                     assert np.isfinite(b2).all() and relerr(b2, ref) <= 1e-5 and rowwise_err(b2, ref, absref, L) <= 1e-5, \
                         (name, d, rpl, lds, relerr(b2, ref), rowwise_err(b2, ref, absref, L))
-                cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1)
+                cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("mfma_f16", -1)
             else:              # forced past the gate the kernel must still be finite and lose no row (it is merely less accurate)
                 cg.set_option("dense_variant", 2)
                 b2 = (G @ ad).cpu().numpy()
@@ -1078,7 +1096,8 @@ def test_eq_matrix_core_band_far_rows_and_columns(cg, oracle, d):
                 assert ok.sum() >= len(ok) // 2 or "far X" in name
                 assert np.isfinite(bs).all() and (not ok.any() or rowwise_err(bs[ok], b.astype(np.float64)[ok], absref[ok]) <= 1e-6), (name, d, sc)
     finally:
-        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1)
+        cg.set_option("dense_variant", 0); cg.set_option("rows_per_lane", 0); cg.set_option("mfma_lds", -1); cg.set_option("mfma_f16", -1)
+    assert f16_seen
 
 
 @pytest.mark.parametrize("d", [3, 8, 12])
