@@ -214,13 +214,16 @@ def other_configs(cg, dev):
     ref = c_oracle.mvm(o.Kernel(o.EQ), Xh[rows].astype(np.float64), Xh.astype(np.float64), ah.astype(np.float64))
     fl = float(per) * n * (3 * d + 3)
     kavg = kms / max(kl, 1)
+    c3_k2 = (d + 3) // 4 if cg.get_info("last_mfma_f16") == 1 else (d + 1) // 2     # MFMAs per 32 x 32 tile: fp16 two-way split (round 4) / bf16 three-way split
+    c3_cycles64 = 8.0 + 4.0 + 8.0 * c3_k2 / 16.0
     out["C3_shard"] = {"what": "EQ dense Gramian mul!, d=8 n=524288 fp32: one rank's row shard of the 8-GPU config (65536 rows x 524288 columns, all entries)",
                        "ms": ms, "kernel_avg_ms": kavg, "pairs_per_s": float(per) * n / (ms * 1e-3), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
                        "checked_rows": len(rows),
-                       "roofline": {"bound": "valu_issue", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0) * (3 * d + 3) * 1e-12,
-                                    "unit": "TFLOP/s", "frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 4.0 + 8.0 * 4 / 16.0)),
+                       "roofline": {"bound": "valu_issue", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / c3_cycles64 * (3 * d + 3) * 1e-12,
+                                    "unit": "TFLOP/s", "frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / c3_cycles64),
+                                    "mfmas_per_tile": c3_k2, "split": "fp16 two-way (3 products per coordinate)" if c3_k2 == (d + 3) // 4 else "bf16 three-way (8 products per coordinate)",
                                     "reference_flops_frac": fl / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
-                                    "note": "peak = the VALU issue ceiling of this kernel's instruction stream (v_exp_f32 8 + v_fma_f32 4 + MFMA hold 2 cycles per 64 pairs per SIMD at 2.4 GHz, "
+                                    "note": "peak = the VALU issue ceiling of this kernel's instruction stream (v_exp_f32 8 + v_fma_f32 4 + MFMA hold " + f"{8.0 * c3_k2 / 16.0:g}" + " cycles per 64 pairs per SIMD at 2.4 GHz, "
                                             "MI355X_MICROARCH.md) in the reference's 3d+3 flops per pair, so frac = achieved / peak = evaluated pairs per second over that ceiling; reference_flops_frac = the reference's 3d+3 = 27 flops per pair against the FP32 "
                                             "VECTOR peak (SURVEY.md \u00a78d(i)) — 24 of them run on the matrix pipe here, so that ratio can exceed 1 and is no utilisation"}}
     Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n, dtype=torch.float32, device=dev)
@@ -464,6 +467,7 @@ def main():
     cg.set_option("time_kernels", 0)
     dense_path = cg.get_info("last_dense_path")
     sym_path = cg.get_info("last_mfma_sym") == 1
+    f16_split = dense_path == 2 and not sym_path and cg.get_info("last_mfma_f16") == 1      # the general kernel's fp16 two-way split (round 4)
 
     per_rank = None
     if world > 1:
@@ -660,7 +664,7 @@ def main():
         # Issue pricing (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost'): per wave-instruction and SIMD v_exp_f32 8 cycles,
         # v_fma_f32 4, and each v_mfma_f32_32x32x16_bf16 holds the SIMD's vector issue for 8 of its 32 cycles; costs add.
         evaluated_pairs = float(n_local) * m
-        k2 = (d + 1) // 2                                            # MFMAs per 32x32 tile (two coordinates each)
+        k2 = (d + 3) // 4 if f16_split else (d + 1) // 2             # MFMAs per 32x32 tile (bf16 three-way split: two coordinates each; fp16 two-way split: four)
         mfma_hold = 8.0 * k2 / 16.0                                  # per 64 pairs: k2 MFMAs serve 1024 pairs
         if dense_path == 2 and sym_path:
             # gramian(k, x) on one GPU: tiles on / above the diagonal are evaluated once and feed row AND column sums
@@ -679,14 +683,17 @@ def main():
                     "(3d+3 of SURVEY.md \u00a78d + 2 for the second weighted sum) over the measured kernel time; 'reference_algorithm_tflops' "
                     "is the reference's n^2 x (3d+3) over the same time (what the caller gets). 'hbm' does not bound this kernel.")
         elif dense_path == 2:
-            kname = ("covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=8, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+            kname = (f"covgram::dense_mfma_eq_kernel<K2={k2}, RT=2, WPB=8, LDS, fp16 two-way split> (v_mfma_f32_32x32x16_f16 + 1 v_exp_f32 + "
+                     "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)" if f16_split else
+                     "covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=8, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
                      "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)")
             cycles64 = 8.0 + 4.0 + mfma_hold
-            note = ("FP32 VALU + transcendental issue bound: the distance runs on the bf16 matrix pipe (three-way split, fp32-exact "
-                    "products), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' is the reference's algorithmic 3d+3 flops per "
+            note = ("FP32 VALU + transcendental issue bound: the distance runs on the matrix pipe (" + ("fp16 two-way split x~ = h1 + h2, products h1 h1, "
+                    "h1 h2, h2 h1: one MFMA per four coordinates; what it drops is the size of one fp32 rounding of the dot product" if f16_split else
+                    "bf16 three-way split, fp32-exact products") + "), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' is the reference's algorithmic 3d+3 flops per "
                     "pair over the measured kernel time; 'peak' is the fixed FP32 vector peak, so 'frac' is the round-to-round comparable throughput ratio; "
                     "'issue_roofline_frac' is the utilisation of the binding pipe: the kernel's VALU issue ceiling (v_exp_f32 8 + v_fma_f32 4 + "
-                    "MFMA hold 1 cycle per 64 pairs per SIMD at the 2.4 GHz peak clock); "
+                    "MFMA hold " + f"{mfma_hold:g}" + " cycle per 64 pairs per SIMD at the 2.4 GHz peak clock); "
                     "'issue_roofline_frac_at_sustained_clock' prices the same ceiling at the clock measured in this run with the kernel's "
                     "stamping build; 'reference_flops_frac' is the flop ratio against the FP32 vector peak of SURVEY.md \u00a78d(i) (most of those "
                     "flops run on the matrix pipe: a throughput ratio, not a utilisation). 'hbm' does not bound this kernel (O(n) bytes, O(n^2) work).")

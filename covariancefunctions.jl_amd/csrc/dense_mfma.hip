@@ -535,12 +535,12 @@ static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const floa
     unsigned long long* const ns = nullptr;
     if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         *launched = dim3((grid.x + 7) / 8, grid.y);
-        if constexpr (K2 == 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        if constexpr (K2 <= 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
         hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
         if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal); return; } }
-        if constexpr (K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<4, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
+        if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
         hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
@@ -684,7 +684,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // option "mfma_stamp": the clock-stamping diagnostic build of the two LDS-shared instances (C2's and C3's kernels)
     unsigned long long* stamps = nullptr;
     ctx->stamp_count = 0;
-    if (ctx->mfma_stamp && lds4 && (K2 == 2 || K2 == 4)) {
+    if (ctx->mfma_stamp && lds4 && (K2 == 1 || K2 == 2 || K2 == 4)) {
         const size_t need = (size_t)rowtiles * js * 4 * sizeof(unsigned long long);
         if (need > ctx->stamp_cap) {
             if (ctx->stamp_buf) { CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->stamp_buf); ctx->stamp_buf = nullptr; ctx->stamp_cap = 0; }
@@ -813,7 +813,12 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     const bool iso = hku.k.trait == COVGRAM_ISOTROPIC;
     const int64_t n = X->n;
     const int d = X->d;
-    const int K2 = fast ? eq_k2_for(d) : mfma_k2_for(d + (iso ? 1 : 0));
+    // EQ form: the fp16 two-way split inside its gate, as the general kernel (mvm_eq_mfma, "Which split"); every rank of a multi-GPU call sees the same
+    // cloud and lengthscale, hence the same split and the same panel size
+    const double g2r2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale) * gate_radius2(X, X);
+    const int fmt = (fast && ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? MFMA_GATE : MFMA_F16_GATE)) ? 1 : 0;
+    if (fast) ctx->last_mfma_f16 = fmt;
+    const int K2 = fast ? (fmt ? eq_k2_for(2 * ((d + 3) / 4)) : eq_k2_for(d)) : mfma_k2_for(d + (iso ? 1 : 0));
     CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: d = %d has no matrix-core instance", d);
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
@@ -828,7 +833,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     if (fast) {
         // the fragments AND the fraction factors e_j are cached in the points handle; the kernel forms a_j e_j itself, so a
         // steady-state MVM launches no pack kernel
-        rc = eq_fragments(ctx, X, K2, g, Cn, &PBu, &EF);
+        rc = eq_fragments(ctx, X, K2, g, Cn, &PBu, &EF, fmt);
         if (rc) return rc;
         W = a;
     } else {                                                       // generic fragments (norm pseudo-coordinate) + W = a, packed per MVM
@@ -902,7 +907,19 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #define CG_SYMW_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                    PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
                                                    KParams<float>{}, EF); break;
-    if (fast) {
+#define CG_SYMH_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST_H, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
+                                                   KParams<float>{}, EF); break;
+#define CG_SYMWH_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST_H, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                    PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
+                                                    KParams<float>{}, EF); break;
+    if (fast && fmt) {
+        switch (K2) {
+            CG_SYMH_CASE(1) CG_SYMH_CASE(2) CG_SYMH_CASE(3) CG_SYMH_CASE(4)
+            CG_SYMWH_CASE(6) CG_SYMWH_CASE(8)
+            default: set_error("dense_mfma_sym: K2 = %d not compiled for the fp16 split", K2); return COVGRAM_EUNSUPPORTED;
+        }
+    } else if (fast) {
         switch (K2) {
             CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
             CG_SYMW_CASE(6) CG_SYMW_CASE(8) CG_SYMW_CASE(12) CG_SYMW_CASE(16)
@@ -921,6 +938,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     }
 #undef CG_SYM_CASE
 #undef CG_SYMW_CASE
+#undef CG_SYMH_CASE
+#undef CG_SYMWH_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
     hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, n, (const float*)Rp,
                        (const float*)Sp, npad, ntile, (int)tchunk, EF, y, (float)alpha_eff, (float)beta, pfirst, pstride, tpp);

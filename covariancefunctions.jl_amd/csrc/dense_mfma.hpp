@@ -439,8 +439,10 @@ __global__ __launch_bounds__(64) void dense_mfma_mrhs_kernel(const float* __rest
 // FAM = FAM_EQFAST: the EQ form of dense_mfma.hip (exponent straight from the MFMA, norms in the weights); any other family:
 // the generic form above (the MFMA yields the profile argument s, the norms ride in a pseudo-coordinate, weights are a_j).
 constexpr int FAM_EQFAST = 1000;
+constexpr int FAM_EQFAST_H = 1001;      // the same with the fp16 two-way split of the coordinates (one MFMA per four coordinates; dense_mfma.hip, "Which split")
 template <int FAM> struct SymParamsOf { using type = typename ParamsOf<FAM, float>::type; };
 template <> struct SymParamsOf<FAM_EQFAST> { using type = KParams<float>; };
+template <> struct SymParamsOf<FAM_EQFAST_H> { using type = KParams<float>; };
 
 template <int FAM, int K2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_sym_kernel(
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // padding), and W = the caller's a itself: no per-MVM pack kernel at all
     // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
-    constexpr bool FAST = (FAM == FAM_EQFAST);
+    constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
+    constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float* __restrict__ xr = X + row * (int64_t)d;
         float part = 0.0f;
         if constexpr (FAST) {
-            er = eq_row_fragments<K2>(xr, Cn, d, g, h, a);
+            er = eq_row_fragments_fmt<K2, FMT>(xr, Cn, d, g, h, a);
         } else {
             const float gg = kp.gamma;
             if constexpr (ISO)
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr bool MASKED = decltype(masked)::value;
         f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f[mm].v, D, 0, 0, 0);
+        for (int mm = 0; mm < K2; ++mm) D = eq_mma<FMT>(a[mm], f[mm], D);
         if constexpr (fam_is_expr<FAM>) {                                           // composite: all 16 entries factor by factor
             float sv[16], kv[16];
 #pragma unroll
@@ -655,7 +658,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // padding), and W = the caller's a itself: no per-MVM pack kernel at all
     // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
-    constexpr bool FAST = (FAM == FAM_EQFAST);
+    constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
+    constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     constexpr int NW = 4;
     const int32_t wm = wgmap[blockIdx.x];
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* __restrict__ xr = X + row * (int64_t)d;
         float part = 0.0f;
         if constexpr (FAST) {
-            er = eq_row_fragments<K2>(xr, Cn, d, g, h, a);
+            er = eq_row_fragments_fmt<K2, FMT>(xr, Cn, d, g, h, a);
         } else {
             const float gg = kp.gamma;
             if constexpr (ISO)
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
                 Frag f; f.u = TF[mm][l];                                                        \
-                D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mm].v, f.v, D, 0, 0, 0);          \
+                D = eq_mma<FMT>(a[mm], f, D);                                                   \
             }                                                                                   \
             const float w = TW[t];                                                              \
             if constexpr (fam_is_expr<FAM>) {                                                   \

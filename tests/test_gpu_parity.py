@@ -826,13 +826,13 @@ def test_eq_symmetric_matrix_core_kernel(cg, oracle, d):
             cg.set_option("mfma_sym", 0)
             yf = torch.from_numpy(y0.copy()).cuda(); cg.mul_(yf, G, ad, -0.7, 1.3)
             assert cg.get_info("last_mfma_sym") == 0
-            for js in (0, 1, 3):
-                cg.set_option("mfma_sym", 1); cg.set_option("jsplit", js)
+            for js, f16 in ((0, 1), (1, 1), (3, 1), (0, 0), (1, 0), (3, 0)):      # fp16 two-way / bf16 three-way split of the coordinates (round 4)
+                cg.set_option("mfma_sym", 1); cg.set_option("jsplit", js); cg.set_option("mfma_f16", f16)
                 ys = torch.from_numpy(y0.copy()).cuda(); cg.mul_(ys, G, ad, -0.7, 1.3)
-                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 1
-                assert relerr(ys.cpu().numpy(), ref) <= 1e-5, (d, n, js, relerr(ys.cpu().numpy(), ref))
+                assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 1 and cg.get_info("last_mfma_f16") == f16
+                assert relerr(ys.cpu().numpy(), ref) <= 1e-5, (d, n, js, f16, relerr(ys.cpu().numpy(), ref))
                 assert relerr(ys.cpu().numpy(), yf.cpu().numpy()) <= 5e-6
-            cg.set_option("jsplit", 0)
+            cg.set_option("jsplit", 0); cg.set_option("mfma_f16", -1)
             yn = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
             cg.mul_(yn, G, ad, 1.0, 0.0)
             assert relerr(yn.cpu().numpy(), oracle.mul(None, ko, X, X, a, 1.0, 0.0, np.float32)) <= 1e-5
@@ -840,7 +840,7 @@ def test_eq_symmetric_matrix_core_kernel(cg, oracle, d):
             G2 = cg.gramian(k, Xd, Xd.clone()); (G2 @ ad)
             assert cg.get_info("last_mfma_sym") == 0
     finally:
-        cg.set_option("mfma_sym", -1); cg.set_option("jsplit", 0)
+        cg.set_option("mfma_sym", -1); cg.set_option("jsplit", 0); cg.set_option("mfma_f16", -1)
 
 
 def test_eq_symmetric_partial_products_sum_to_the_mvm(cg, oracle):
