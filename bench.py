@@ -233,10 +233,12 @@ def other_configs(cg, dev):
         kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
         kavg = kms / max(kl, 1)
         ev = float(n) * (n + 32) / 2 / world
+        sp_k2 = (d + 3) // 4 if cg.get_info("last_mfma_f16") == 1 else (d + 1) // 2
+        sp_cycles64 = 8.0 + 8.0 + 8.0 * sp_k2 / 16.0                   # v_exp_f32 + two v_fma_f32 (row and column sums) + the MFMA hold
         out["C3_sym_partial"] = {"what": "the same config in the symmetric form: rank 3 of 8's cyclic panels of the upper triangle (covgram_mvm_sym_partial); "
                                          "an all-reduce of the 8 partials completes b", "ms": ms, "kernel_avg_ms": kavg, "evaluated_pairs_per_s": ev / (ms * 1e-3),
-                                 "roofline": {"bound": "valu_issue", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0) * (3 * d + 5) * 1e-12, "unit": "TFLOP/s",
-                                              "frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / (8.0 + 8.0 + 8.0 * 4 / 16.0)),
+                                 "roofline": {"bound": "valu_issue", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / sp_cycles64 * (3 * d + 5) * 1e-12, "unit": "TFLOP/s",
+                                              "frac": (ev / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / sp_cycles64), "mfmas_per_tile": sp_k2,
                                               "reference_flops_frac": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS}}
     del G, Gf, X, a, y, part
     # Which path a caller of gramian(EQ(l), x) gets at the contract size by lengthscale (the matrix-core path needs
@@ -467,7 +469,7 @@ def main():
     cg.set_option("time_kernels", 0)
     dense_path = cg.get_info("last_dense_path")
     sym_path = cg.get_info("last_mfma_sym") == 1
-    f16_split = dense_path == 2 and not sym_path and cg.get_info("last_mfma_f16") == 1      # the general kernel's fp16 two-way split (round 4)
+    f16_split = dense_path == 2 and cg.get_info("last_mfma_f16") == 1      # the matrix-core EQ kernels' fp16 two-way split of the coordinates (round 4)
 
     per_rank = None
     if world > 1:
@@ -672,7 +674,7 @@ def main():
             # this algorithm's own work: per evaluated pair the reference's 3d+3 flops + the second weighted sum
             flops_launch = evaluated_pairs * (3 * d + 3 + 2)
             achieved_tflops = flops_launch / kern_s * 1e-12
-            kname = ("covgram::dense_mfma_sym_kernel<EQ, K2=2> (upper triangle only: bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
+            kname = ("covgram::dense_mfma_sym_kernel<EQ, K2=" + str(k2) + "> (upper triangle only: " + ("fp16 two-way split v_mfma_f32_32x32x16_f16" if f16_split else "bf16x3-split v_mfma_f32_32x32x16_bf16") + " + 1 v_exp_f32 + "
                      "2 v_fma_f32 per EVALUATED pair, each evaluated pair serves the entries (i,j) and (j,i); 8 waves share each column "
                      "tile through LDS)")
             cycles64 = 8.0 + 2 * 4.0 + mfma_hold
