@@ -151,11 +151,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     if constexpr (STAMP) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int64_t T0 = (int64_t)blockIdx.y * tchunk;
     const int64_t T1 = (T0 + tchunk < ntile) ? (T0 + tchunk) : ntile;
-    float acc[RT][16];
+    // the accumulators live as register PAIRS: with one or two MFMAs per tile the weighted sums are v_pk_fma_f32 (two fmas per instruction — nearly twice
+    // the rate while no MFMA executes, slower than two v_fma_f32 beside one: tools/pkfma_probe.hip; C2-shaped 1.44 -> 1.33 ms, four MFMAs per tile +2-3 %)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[RT][8];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
+        for (int v = 0; v < 8; ++v) acc2[r][v] = (f32x2){0.0f, 0.0f};
 
     // Column tiles in pairs with two operand buffers (no register copies); the prefetch of a tile past the chunk is clamped
     // to the last tile (a harmless re-read) instead of branching.  Uniform base + 32-bit lane offset -> saddr loads.
@@ -185,7 +188,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[r][v] = __builtin_fmaf(w, D[r][v], acc[r][v]);
+            for (int v = 0; v < 8; ++v) {
+                if constexpr (K2 <= 2) acc2[r][v] = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){D[r][2 * v], D[r][2 * v + 1]}, acc2[r][v]);
+                else { acc2[r][v][0] = __builtin_fmaf(w, D[r][2 * v], acc2[r][v][0]); acc2[r][v][1] = __builtin_fmaf(w, D[r][2 * v + 1], acc2[r][v][1]); }
+            }
     };
     if constexpr (LDS == 2) {
         // Long fragments (K2 KB per tile): the workgroup stages ONE tile at a time, wave w fetching the fragment slices
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             }                                                                                   \
             const float w = TW[t];                                                              \
             _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]); \
-            _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[0][v] = __builtin_fmaf(w, D[v], acc[0][v]); \
+            _Pragma("unroll") for (int v = 0; v < 8; ++v) { acc2[0][v][0] = __builtin_fmaf(w, D[2 * v], acc2[0][v][0]); acc2[0][v][1] = __builtin_fmaf(w, D[2 * v + 1], acc2[0][v][1]); } \
         }
         CG_DMA2(0, tfA)
         if (wv == 0 && h == 0) twA[t] = gw;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         float tot = 0.0f;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            float s = acc[r][v];
+            float s = acc2[r][v >> 1][v & 1];
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
             tot = (vsel == v) ? s : tot;
         }

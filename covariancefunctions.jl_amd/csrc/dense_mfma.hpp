@@ -457,6 +457,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
     constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
+    constexpr bool PK = FAST && K2 <= 2;        // packed fmas for the weighted sums (see process below)
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
@@ -561,6 +562,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+        if constexpr (PK) {
+            // two fmas per instruction (v_pk_fma_f32 on register pairs): the same sums in the same order as below.  Beside a RUNNING MFMA a packed fma
+            // costs more than the two it replaces (tools/pkfma_probe.hip: 32 of them +260 cycles next to back-to-back MFMAs), so only the
+            // kernels with one or two MFMAs per tile take it (general kernel at d = 3: 1.44 -> 1.33 ms; four MFMAs per tile: +2-3 %)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f};
+#pragma unroll
+            for (int v = 0; v < 16; v += 4) {
+                f32x2 a01 = {acc[v], acc[v + 1]}, a23 = {acc[v + 2], acc[v + 3]};
+                const f32x2 d01 = {D[v], D[v + 1]}, d23 = {D[v + 2], D[v + 3]};
+                a01 = __builtin_elementwise_fma((f32x2){wr, wr}, d01, a01);
+                a23 = __builtin_elementwise_fma((f32x2){wr, wr}, d23, a23);
+                acc[v] = a01[0]; acc[v + 1] = a01[1]; acc[v + 2] = a23[0]; acc[v + 3] = a23[1];
+                c01 = __builtin_elementwise_fma((f32x2){u[v], u[v + 1]}, d01, c01);
+                c23 = __builtin_elementwise_fma((f32x2){u[v + 2], u[v + 3]}, d23, c23);
+            }
+            c0 = c01[0]; c1 = c01[1]; c2 = c23[0]; c3 = c23[1];
+        } else {
 #pragma unroll
         for (int v = 0; v < 16; v += 4) {
             acc[v] = __builtin_fmaf(wr, D[v], acc[v]);
@@ -571,6 +590,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);
             c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
             c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
+        }
         }
         cpart = (!MASKED || J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;   // this half-wave's 16 rows; the halves meet in the flush
     };
