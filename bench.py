@@ -215,7 +215,7 @@ def other_configs(cg, dev):
     fl = float(per) * n * (3 * d + 3)
     kavg = kms / max(kl, 1)
     c3_k2 = (d + 3) // 4 if cg.get_info("last_mfma_f16") == 1 else (d + 1) // 2     # MFMAs per 32 x 32 tile: fp16 two-way split (round 4) / bf16 three-way split
-    c3_cycles64 = 8.0 + 4.0 + 8.0 * c3_k2 / 16.0
+    c3_cycles64 = 8.0 + (2.25 if c3_k2 <= 2 else 4.0) + 8.0 * c3_k2 / 16.0      # K2 <= 2: packed fmas (profiles/r04_pkfma_ab.txt)
     out["C3_shard"] = {"what": "EQ dense Gramian mul!, d=8 n=524288 fp32: one rank's row shard of the 8-GPU config (65536 rows x 524288 columns, all entries)",
                        "ms": ms, "kernel_avg_ms": kavg, "pairs_per_s": float(per) * n / (ms * 1e-3), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
                        "checked_rows": len(rows),
@@ -223,7 +223,7 @@ def other_configs(cg, dev):
                                     "unit": "TFLOP/s", "frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / c3_cycles64),
                                     "mfmas_per_tile": c3_k2, "split": "fp16 two-way (3 products per coordinate)" if c3_k2 == (d + 3) // 4 else "bf16 three-way (8 products per coordinate)",
                                     "reference_flops_frac": fl / (kavg * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
-                                    "note": "peak = the VALU issue ceiling of this kernel's instruction stream (v_exp_f32 8 + v_fma_f32 4 + MFMA hold " + f"{8.0 * c3_k2 / 16.0:g}" + " cycles per 64 pairs per SIMD at 2.4 GHz, "
+                                    "note": "peak = the VALU issue ceiling of this kernel's instruction stream (v_exp_f32 8 + " + ("half a v_pk_fma_f32 2.25" if c3_k2 <= 2 else "v_fma_f32 4") + " + MFMA hold " + f"{8.0 * c3_k2 / 16.0:g}" + " cycles per 64 pairs per SIMD at 2.4 GHz, "
                                             "MI355X_MICROARCH.md) in the reference's 3d+3 flops per pair, so frac = achieved / peak = evaluated pairs per second over that ceiling; reference_flops_frac = the reference's 3d+3 = 27 flops per pair against the FP32 "
                                             "VECTOR peak (SURVEY.md \u00a78d(i)) — 24 of them run on the matrix pipe here, so that ratio can exceed 1 and is no utilisation"}}
     Gf = cg.gramian(cg.EQ(), X); part = torch.empty(n, dtype=torch.float32, device=dev)
@@ -234,7 +234,7 @@ def other_configs(cg, dev):
         kavg = kms / max(kl, 1)
         ev = float(n) * (n + 32) / 2 / world
         sp_k2 = (d + 3) // 4 if cg.get_info("last_mfma_f16") == 1 else (d + 1) // 2
-        sp_cycles64 = 8.0 + 8.0 + 8.0 * sp_k2 / 16.0                   # v_exp_f32 + two v_fma_f32 (row and column sums) + the MFMA hold
+        sp_cycles64 = 8.0 + 2 * (2.25 if sp_k2 <= 2 else 4.0) + 8.0 * sp_k2 / 16.0                   # v_exp_f32 + two v_fma_f32 (row and column sums) + the MFMA hold
         out["C3_sym_partial"] = {"what": "the same config in the symmetric form: rank 3 of 8's cyclic panels of the upper triangle (covgram_mvm_sym_partial); "
                                          "an all-reduce of the 8 partials completes b", "ms": ms, "kernel_avg_ms": kavg, "evaluated_pairs_per_s": ev / (ms * 1e-3),
                                  "roofline": {"bound": "valu_issue", "achieved": ev * (3 * d + 5) / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / sp_cycles64 * (3 * d + 5) * 1e-12, "unit": "TFLOP/s",
@@ -677,7 +677,7 @@ def main():
             kname = ("covgram::dense_mfma_sym_kernel<EQ, K2=" + str(k2) + "> (upper triangle only: " + ("fp16 two-way split v_mfma_f32_32x32x16_f16" if f16_split else "bf16x3-split v_mfma_f32_32x32x16_bf16") + " + 1 v_exp_f32 + "
                      "2 v_fma_f32 per EVALUATED pair, each evaluated pair serves the entries (i,j) and (j,i); 8 waves share each column "
                      "tile through LDS)")
-            cycles64 = 8.0 + 2 * 4.0 + mfma_hold
+            cycles64 = 8.0 + 2 * (2.25 if k2 <= 2 else 4.0) + mfma_hold      # K2 <= 2: the two weighted sums are v_pk_fma_f32, 4.5 cycles per 128 fmas (profiles/r04_pkfma_ab.txt)
             note = ("FP32 VALU + transcendental issue bound. The Gramian of one point set is symmetric: every 32x32 tile on or above the "
                     "diagonal is evaluated once (distance on the bf16 matrix pipe, three-way split) and used for the row sums and — "
                     "strictly above the diagonal — for the column sums, so one MVM costs n(n+32)/2 exponentials instead of n^2 "
@@ -686,15 +686,15 @@ def main():
                     "is the reference's n^2 x (3d+3) over the same time (what the caller gets). 'hbm' does not bound this kernel.")
         elif dense_path == 2:
             kname = (f"covgram::dense_mfma_eq_kernel<K2={k2}, RT=2, WPB=8, LDS, fp16 two-way split> (v_mfma_f32_32x32x16_f16 + 1 v_exp_f32 + "
-                     "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)" if f16_split else
+                     "1 fma per pair as v_pk_fma_f32 on register pairs; 8 waves share each column tile through LDS)" if f16_split else
                      "covgram::dense_mfma_eq_kernel<K2=2, RT=2, WPB=8, LDS> (bf16x3-split v_mfma_f32_32x32x16_bf16 + 1 v_exp_f32 + "
                      "1 v_fma_f32 per pair; 8 waves share each column tile through LDS)")
-            cycles64 = 8.0 + 4.0 + mfma_hold
+            cycles64 = 8.0 + (2.25 if k2 <= 2 else 4.0) + mfma_hold           # K2 <= 2: the weighted sum is v_pk_fma_f32, 4.5 cycles per 128 fmas (profiles/r04_pkfma_ab.txt)
             note = ("FP32 VALU + transcendental issue bound: the distance runs on the matrix pipe (" + ("fp16 two-way split x~ = h1 + h2, products h1 h1, "
                     "h1 h2, h2 h1: one MFMA per four coordinates; what it drops is the size of one fp32 rounding of the dot product" if f16_split else
                     "bf16 three-way split, fp32-exact products") + "), the VALU does 1 v_exp_f32 + 1 v_fma_f32 per pair. 'achieved' is the reference's algorithmic 3d+3 flops per "
                     "pair over the measured kernel time; 'peak' is the fixed FP32 vector peak, so 'frac' is the round-to-round comparable throughput ratio; "
-                    "'issue_roofline_frac' is the utilisation of the binding pipe: the kernel's VALU issue ceiling (v_exp_f32 8 + v_fma_f32 4 + "
+                    "'issue_roofline_frac' is the utilisation of the binding pipe: the kernel's VALU issue ceiling (v_exp_f32 8 + " + ("half a v_pk_fma_f32 2.25" if k2 <= 2 else "v_fma_f32 4") + " + "
                     "MFMA hold " + f"{mfma_hold:g}" + " cycle per 64 pairs per SIMD at the 2.4 GHz peak clock); "
                     "'issue_roofline_frac_at_sustained_clock' prices the same ceiling at the clock measured in this run with the kernel's "
                     "stamping build; 'reference_flops_frac' is the flop ratio against the FP32 vector peak of SURVEY.md \u00a78d(i) (most of those "

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
     constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
-    constexpr bool PK = FAST && K2 <= 2;        // packed fmas for the weighted sums (see process below)
+    constexpr bool PK = K2 <= 2;                // packed fmas for the weighted sums (see process below)
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
