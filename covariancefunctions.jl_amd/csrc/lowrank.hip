@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "pack.hpp"
 
 namespace covgram {
 
@@ -41,7 +42,7 @@ constexpr int LR_RC = 32;   // columns of V carried per pass over a row slab (ac
 // shuffle + LDS reduction per column.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ V, int64_t ldv, int64_t m, int64_t r, const T* __restrict__ a,
-                                                          T* __restrict__ zpart, int64_t per) {
+                                                          T* __restrict__ zpart, int64_t per, unsigned* __restrict__ ticket, T* __restrict__ z) {
     using VT = typename VecOf<T, VEC>::type;
     const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < m) ? (j0 + per) : m;
     __shared__ T red[LR_RC][256 + 1];                           // [column][thread] (+1: the column sums read down a row)
@@ -73,9 +74,42 @@ __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 32; ++e) s += red[c][part * 32 + e];
             s += __shfl_down(s, 4, 8); s += __shfl_down(s, 2, 8); s += __shfl_down(s, 1, 8);
-            if (part == 0 && c < nc) zpart[(int64_t)blockIdx.x * r + c0 + c] = s;
+            if (part == 0 && c < nc) slab_store(zpart + (int64_t)blockIdx.x * r + c0 + c, s, ticket != nullptr);
         }
         __syncthreads();
+    }
+    // ticket != nullptr (round 4, small r): the LAST slab's workgroup to arrive sums the partials in lowrank_zsum_kernel's fixed order — no
+    // separate launch (that kernel is ONE workgroup per 32 columns walking every slab: 9.7 us of latency at r = 32, n = 2^20), eight loads in flight
+    if (ticket == nullptr || !last_arrival(ticket, gridDim.x)) return;
+    const int64_t nslab = gridDim.x;
+    const int kk = threadIdx.x & 31, part = threadIdx.x >> 5;
+    T* redz = &red[0][0];                                       // [8][32] of the LDS block above
+    for (int64_t kb = 0; kb < r; kb += 32) {
+        const int64_t k = kb + kk;
+        T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+        if (k < r) {
+            int64_t sl = part;
+            for (; sl + 56 < nslab; sl += 64) {
+                const T p0 = slab_load(zpart + sl * r + k), p1 = slab_load(zpart + (sl + 8) * r + k), p2 = slab_load(zpart + (sl + 16) * r + k),
+                        p3 = slab_load(zpart + (sl + 24) * r + k), p4 = slab_load(zpart + (sl + 32) * r + k), p5 = slab_load(zpart + (sl + 40) * r + k),
+                        p6 = slab_load(zpart + (sl + 48) * r + k), p7 = slab_load(zpart + (sl + 56) * r + k);
+                s0 += p0; s1 += p1; s2 += p2; s3 += p3; s0 += p4; s1 += p5; s2 += p6; s3 += p7;
+            }
+            for (; sl + 24 < nslab; sl += 32) {
+                s0 += slab_load(zpart + sl * r + k); s1 += slab_load(zpart + (sl + 8) * r + k); s2 += slab_load(zpart + (sl + 16) * r + k);
+                s3 += slab_load(zpart + (sl + 24) * r + k);
+            }
+            for (; sl < nslab; sl += 8) s0 += slab_load(zpart + sl * r + k);
+        }
+        __syncthreads();
+        redz[part * 32 + kk] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (part == 0 && k < r) {
+            T s = (T)0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) s += redz[p * 32 + kk];
+            z[k] = s;
+        }
     }
 }
 
@@ -134,9 +168,9 @@ __global__ __launch_bounds__(256) void lowrank_uz_kernel(const T* __restrict__ U
 
 template <typename T, int VEC>
 static void lowrank_launch(covgram_ctx* ctx, const T* U, int64_t ldu, const T* V, int64_t ldv, int64_t n, int64_t m, int64_t r, const T* a,
-                           T* y, T alpha, T beta, T* zpart, T* z, int64_t nslab, int64_t per) {
-    hipLaunchKernelGGL((lowrank_vta_kernel<T, VEC>), dim3((unsigned)nslab), dim3(256), 0, ctx->stream, V, ldv, m, r, a, zpart, per);
-    hipLaunchKernelGGL(lowrank_zsum_kernel<T>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, ctx->stream, (const T*)zpart, nslab, r, z);
+                           T* y, T alpha, T beta, T* zpart, T* z, int64_t nslab, int64_t per, unsigned* ticket) {
+    hipLaunchKernelGGL((lowrank_vta_kernel<T, VEC>), dim3((unsigned)nslab), dim3(256), 0, ctx->stream, V, ldv, m, r, a, zpart, per, ticket, z);
+    if (!ticket) hipLaunchKernelGGL(lowrank_zsum_kernel<T>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, ctx->stream, (const T*)zpart, nslab, r, z);
     const int64_t rows_per_block = 256 * VEC;
     hipLaunchKernelGGL((lowrank_uz_kernel<T, VEC>), dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(256), (size_t)r * sizeof(T),
                        ctx->stream, U, ldu, n, r, (const T*)z, y, alpha, beta);
@@ -144,11 +178,11 @@ static void lowrank_launch(covgram_ctx* ctx, const T* U, int64_t ldu, const T* V
 
 template <typename T>
 static void lowrank_run(covgram_ctx* ctx, const void* U, int64_t ldu, const void* V, int64_t ldv, int64_t n, int64_t m, int64_t r, const void* a,
-                        void* y, double alpha, double beta, void* zpart, void* z, int64_t nslab, int64_t per) {
+                        void* y, double alpha, double beta, void* zpart, void* z, int64_t nslab, int64_t per, unsigned* ticket) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const bool aligned = (((uintptr_t)U | (uintptr_t)V | (uintptr_t)a | (uintptr_t)y) % 16 == 0) && ldu % VEC == 0 && ldv % VEC == 0 && per % VEC == 0;
-    if (aligned) lowrank_launch<T, VEC>(ctx, (const T*)U, ldu, (const T*)V, ldv, n, m, r, (const T*)a, (T*)y, (T)alpha, (T)beta, (T*)zpart, (T*)z, nslab, per);
-    else lowrank_launch<T, 1>(ctx, (const T*)U, ldu, (const T*)V, ldv, n, m, r, (const T*)a, (T*)y, (T)alpha, (T)beta, (T*)zpart, (T*)z, nslab, per);
+    if (aligned) lowrank_launch<T, VEC>(ctx, (const T*)U, ldu, (const T*)V, ldv, n, m, r, (const T*)a, (T*)y, (T)alpha, (T)beta, (T*)zpart, (T*)z, nslab, per, ticket);
+    else lowrank_launch<T, 1>(ctx, (const T*)U, ldu, (const T*)V, ldv, n, m, r, (const T*)a, (T*)y, (T)alpha, (T)beta, (T*)zpart, (T*)z, nslab, per, ticket);
 }
 
 
@@ -505,9 +539,11 @@ int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void
     CG_DEVICE(ctx);
     const bool mfma = nrhs >= 8 && (dtype == COVGRAM_F32 ? lowrank_mfma_fits<float>(r) : lowrank_mfma_fits<double>(r));
     const int pz = mfma ? nrhs : 1;                              // columns of Z held at once
-    // row slabs of V: ~4 workgroups per CU, slab length a multiple of one sweep of the block (256 threads x 16 bytes)
+    // row slabs of V: ~4 workgroups per CU (GEMV form: ~2, i.e. at least two sweeps per slab at n = 2^20 — a slab of ONE sweep spends as long in
+    // its 32-column LDS reduction as on its loads: 28.4 us at 4.7 TB/s for 134 MB), slab length a multiple of one sweep of the block (256 threads x 16 bytes)
     const int64_t sweep = 256 * (16 / (int64_t)ts);
-    int64_t per = (m + (int64_t)ctx->num_cus * 4 - 1) / ((int64_t)ctx->num_cus * 4);
+    const int64_t wg_per_cu = mfma ? 4 : 2;
+    int64_t per = (m + (int64_t)ctx->num_cus * wg_per_cu - 1) / ((int64_t)ctx->num_cus * wg_per_cu);
     per = std::max<int64_t>(sweep, ((per + sweep - 1) / sweep) * sweep);
     const int64_t nslab = (m + per - 1) / per;
     size_t need = ((size_t)nslab * r * pz + (size_t)r * pz) * ts + 512;
@@ -533,11 +569,15 @@ int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void
                                           nrhs, alpha, beta, (double*)zpart, (double*)z, nslab, per);
         if (rc) return rc;
     } else {
+        // small r: the last slab's workgroup sums the partials inside lowrank_vta_kernel (one counter, zero between launches); a long z keeps
+        // the separate one-workgroup-per-32-columns kernel
+        unsigned* ticket = nullptr;
+        if (r <= 128) { rc = tickets_reserve(ctx, 1, &ticket); if (rc) return rc; }
         for (int c = 0; c < nrhs; ++c) {                         // GEMV pair per column
             const char* ac = (const char*)ad + (size_t)c * ldad * ts;
             char* yc = (char*)yd + (size_t)c * ldyd * ts;
-            if (dtype == COVGRAM_F32) lowrank_run<float>(ctx, Ud, ldud, Vd, ldvd, n, m, r, ac, yc, alpha, beta, zpart, z, nslab, per);
-            else lowrank_run<double>(ctx, Ud, ldud, Vd, ldvd, n, m, r, ac, yc, alpha, beta, zpart, z, nslab, per);
+            if (dtype == COVGRAM_F32) lowrank_run<float>(ctx, Ud, ldud, Vd, ldvd, n, m, r, ac, yc, alpha, beta, zpart, z, nslab, per, ticket);
+            else lowrank_run<double>(ctx, Ud, ldud, Vd, ldvd, n, m, r, ac, yc, alpha, beta, zpart, z, nslab, per, ticket);
         }
     }
     CG_CHECK_HIP(hipGetLastError());

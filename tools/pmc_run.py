@@ -1,5 +1,5 @@
 """Run K launches of one hot-path config (for rocprofv3 --pmc / --kernel-trace passes).
-usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32|c1|f64sym|f64all|f64eq3|kron64|kron32 [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
+usage: pmc_run.py dense|densegen|shard8|grad|toeplitz|toeplitz4|toeplitz32|c1|f64sym|f64all|f64eq3|kron64|kron32|lowrank [K]     (dense: the library's default = symmetric kernel; densegen: all n*m entries)"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -50,6 +50,12 @@ elif which in ("kron64", "kron32"):             # README.md:205-210: 128^3 grid,
     G = cg.gramian(cg.separable("*", cg.Exp(), cg.Exp(), cg.Exp()), cg.LazyGrid(ax, 3))
     a = torch.randn(128 ** 3, dtype=dt, device="cuda"); y = torch.empty_like(a)
     for _ in range(K): G.mul_(y, a)
+elif which == "lowrank":                          # FiniteBasis (r = 32) on n = 2^20 points, fp32: U (U' a)
+    nl, r = 1 << 20, 32
+    xs = torch.randn(nl, dtype=torch.float32, device="cuda")
+    Gl = cg.gramian(cg.FiniteBasis([lambda t, i=i: torch.cos(0.37 * i * t) for i in range(r)]), xs)
+    al = torch.randn(nl, dtype=torch.float32, device="cuda"); yl = torch.empty_like(al)
+    for _ in range(K): Gl.mul_(yl, al)
 elif which == "toeplitz32":
     n = 1 << 22
     T = cg.gramian(cg.Exp(), cg.srange(-1, 1, n, dtype=torch.float32)); a = torch.randn(n, dtype=torch.float32, device="cuda"); y = torch.empty_like(a)
