@@ -37,53 +37,50 @@ __device__ __forceinline__ T vdot(typename VecOf<T, VEC>::type u, typename VecOf
 
 constexpr int LR_RC = 32;   // columns of V carried per pass over a row slab (accumulators per thread)
 
-// zpart[slab][k] = sum_{j in slab} V[j + k*ldv] a[j].  One workgroup per row slab; a thread streams VEC rows of up to 32
-// columns at a time (16-byte loads, `a` read once per 32 columns instead of once per column), then a deterministic
-// shuffle + LDS reduction per column.
+// zpart[slab][k] = sum_{j in slab} V[j + k*ldv] a[j].  One workgroup per row slab; of its four waves, wave w carries columns 8 w .. 8 w + 7 of
+// each 32-column pass: a lane streams VEC rows of its 8 columns per step (16-byte loads, 8 accumulators — round 4: 32 accumulators and
+// 32 loads per thread left two waves per SIMD and 4.7 TB/s; the short state runs at the occupancy of lowrank_uz_kernel), then a fixed-order
+// butterfly over the wave's 64 lanes per column.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ V, int64_t ldv, int64_t m, int64_t r, const T* __restrict__ a,
                                                           T* __restrict__ zpart, int64_t per, unsigned* __restrict__ ticket, T* __restrict__ z) {
     using VT = typename VecOf<T, VEC>::type;
+    constexpr int CW = LR_RC / 4;                               // columns per wave
     const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < m) ? (j0 + per) : m;
-    __shared__ T red[LR_RC][256 + 1];                           // [column][thread] (+1: the column sums read down a row)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ T red[8 * 32];                                   // the final sum's scratch (below)
     for (int64_t c0 = 0; c0 < r; c0 += LR_RC) {
-        const int nc = (int)((r - c0 < LR_RC) ? (r - c0) : LR_RC);
-        T acc[LR_RC];
+        const int64_t cb = c0 + wv * CW;                        // this wave's first column
+        const int nc = (int)((r - cb < CW) ? (r - cb < 0 ? 0 : r - cb) : CW);
+        T acc[CW];
 #pragma unroll
-        for (int c = 0; c < LR_RC; ++c) acc[c] = (T)0;
-        for (int64_t j = j0 + (int64_t)threadIdx.x * VEC; j < j1; j += 256 * VEC) {
+        for (int c = 0; c < CW; ++c) acc[c] = (T)0;
+        for (int64_t j = j0 + (int64_t)lane * VEC; j < j1; j += 64 * VEC) {
             if (j + VEC <= j1) {
                 const VT av = *reinterpret_cast<const VT*>(a + j);
 #pragma unroll
-                for (int c = 0; c < LR_RC; ++c)
-                    if (c < nc) acc[c] = vdot<T, VEC>(*reinterpret_cast<const VT*>(V + (c0 + c) * ldv + j), av, acc[c]);
+                for (int c = 0; c < CW; ++c)
+                    if (c < nc) acc[c] = vdot<T, VEC>(*reinterpret_cast<const VT*>(V + (cb + c) * ldv + j), av, acc[c]);
             } else {                                            // ragged end of the matrix
                 for (int64_t jj = j; jj < j1; ++jj)
 #pragma unroll
-                    for (int c = 0; c < LR_RC; ++c)
-                        if (c < nc) acc[c] = fma_t(V[(c0 + c) * ldv + jj], a[jj], acc[c]);
+                    for (int c = 0; c < CW; ++c)
+                        if (c < nc) acc[c] = fma_t(V[(cb + c) * ldv + jj], a[jj], acc[c]);
             }
         }
-        // block reduction through LDS: thread t sums 32 of column (t / 8)'s 256 partials, then 8 lanes combine (fixed order)
 #pragma unroll
-        for (int c = 0; c < LR_RC; ++c) red[c][threadIdx.x] = acc[c];
-        __syncthreads();
-        {
-            const int c = threadIdx.x >> 3, part = threadIdx.x & 7;
-            T s = (T)0;
-#pragma unroll
-            for (int e = 0; e < 32; ++e) s += red[c][part * 32 + e];
-            s += __shfl_down(s, 4, 8); s += __shfl_down(s, 2, 8); s += __shfl_down(s, 1, 8);
-            if (part == 0 && c < nc) slab_store(zpart + (int64_t)blockIdx.x * r + c0 + c, s, ticket != nullptr);
+        for (int c = 0; c < CW; ++c) {
+            T s = acc[c];
+            s += __shfl_xor(s, 32); s += __shfl_xor(s, 16); s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+            if (lane == 0 && c < nc) slab_store(zpart + (int64_t)blockIdx.x * r + cb + c, s, ticket != nullptr);
         }
-        __syncthreads();
     }
     // ticket != nullptr (round 4, small r): the LAST slab's workgroup to arrive sums the partials in lowrank_zsum_kernel's fixed order — no
     // separate launch (that kernel is ONE workgroup per 32 columns walking every slab: 9.7 us of latency at r = 32, n = 2^20), eight loads in flight
     if (ticket == nullptr || !last_arrival(ticket, gridDim.x)) return;
     const int64_t nslab = gridDim.x;
     const int kk = threadIdx.x & 31, part = threadIdx.x >> 5;
-    T* redz = &red[0][0];                                       // [8][32] of the LDS block above
+    T* redz = red;
     for (int64_t kb = 0; kb < r; kb += 32) {
         const int64_t k = kb + kk;
         T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
@@ -542,7 +539,7 @@ int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void
     // row slabs of V: ~4 workgroups per CU (GEMV form: ~2, i.e. at least two sweeps per slab at n = 2^20 — a slab of ONE sweep spends as long in
     // its 32-column LDS reduction as on its loads: 28.4 us at 4.7 TB/s for 134 MB), slab length a multiple of one sweep of the block (256 threads x 16 bytes)
     const int64_t sweep = 256 * (16 / (int64_t)ts);
-    const int64_t wg_per_cu = mfma ? 4 : 2;
+    const int64_t wg_per_cu = mfma ? 4 : 2;      // (1: 43.9 us, 2: 33.2, 4 or more: 36.4 — the last workgroup then adds 1024 partials per column)
     int64_t per = (m + (int64_t)ctx->num_cus * wg_per_cu - 1) / ((int64_t)ctx->num_cus * wg_per_cu);
     per = std::max<int64_t>(sweep, ((per + sweep - 1) / sweep) * sweep);
     const int64_t nslab = (m + per - 1) / per;
