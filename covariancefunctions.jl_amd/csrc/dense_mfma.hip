@@ -15,6 +15,12 @@
 // 2^-24 |x~||y~|; only x3y3 ~ 2^-32 is dropped) are exact in the fp32 accumulator, and they fill exactly the 8 K-slots a
 // lane owns in v_mfma_f32_32x32x16_bf16: one MFMA covers two coordinates (lane half h takes coordinate 2 mm + h).
 //
+// Which split (round 4).  Inside g^2 R^2 <= MFMA_F16_GATE (72) the coordinates are split into TWO fp16 pieces instead, x~ = h1 + h2, and only the
+// three products h1 h1, h1 h2, h2 h1 are formed (v_mfma_f32_32x32x16_f16; a lane's 8 K-slots hold two coordinates + the norm slots, so one MFMA
+// covers FOUR coordinates): what is dropped is ~2^-22 |x~_c y~_c| per coordinate — one fp32 rounding of the dot product, which the accumulator
+// commits anyway — and the matrix-core work per pair halves.  The d = 5 ... 8 kernels were power-bound (2.0 GHz under them), so that is fewer cycles
+// AND a higher clock: mvm_eq_mfma below ("Which split") has the measurements and the gate; everything after the MFMA is the same for both splits.
+//
 // Tile orientation: D = X~tile (32 rows i) * Y~tile^T (32 columns j).  A lane holds column j = lane & 31 and the 16 rows
 // i = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) of the result, so the column weight w_j is ONE per-lane register per tile and
 // the 16 accumulators of a lane collect "row i, columns == lane (mod 32)" over all column tiles; the sum over the 32
