@@ -310,6 +310,26 @@ def test_lowrank_finite_basis(cg, oracle):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_lowrank_gemv_pair_many_slabs(cg, oracle, dtype):
+    """The GEMV form over MANY row slabs (csrc/lowrank.hip): for r <= 128 the last slab's workgroup to arrive adds the slab partials inside the
+    first-pass kernel (round 4: ticket, fixed order — repeated calls are bit-identical and the counter is back at zero for the next column), for a
+    longer z the separate slab-sum kernel runs; one and several columns (each its own pair of passes), ragged n / m / r."""
+    rng = np.random.default_rng(71)
+    dt = npdt(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    for (n, m, r, p) in ((2000, 600011, 40, 1), (3000, 300000, 150, 2), (1537, 1200003, 7, 3), (70000, 70000, 128, 1), (5, 2049, 129, 1)):
+        U = rng.standard_normal((n, r)).astype(dt); V = U if n == m else rng.standard_normal((m, r)).astype(dt)
+        A = rng.standard_normal((m, p)).astype(dt)
+        Ud = torch.from_numpy(U).cuda(); Vd = Ud if V is U else torch.from_numpy(V).cuda()
+        L = cg.LazyMatrixProduct(Ud, Vd)
+        Ad = torch.from_numpy(A if p > 1 else A[:, 0].copy()).cuda()
+        y1 = (L @ Ad).cpu().numpy(); y2 = (L @ Ad).cpu().numpy()
+        ref = oracle.lowrank_mul(None, U, V, A if p > 1 else A[:, 0])
+        assert relerr(y1, ref) <= tol * (10 if dtype == torch.float32 else 1), (n, m, r, p, relerr(y1, ref))
+        assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_lowrank_matrix_rhs_on_the_matrix_cores(cg, oracle, dtype):
     """LazyMatrixProduct(U, V') with a matrix right-hand side (src/lazy_linear_algebra.jl:78-85): from 8 columns on both
     tall-skinny products run on the matrix cores in the data's own precision (csrc/lowrank.hip); fewer columns take the GEMV
