@@ -259,10 +259,11 @@ def other_configs(cg, dev):
             path = cg.get_info("last_dense_path")
             sym = bool(cg.get_info("last_mfma_sym") == 1 or cg.get_info("last_dense_sym") == 1)
             ref = c_oracle.mvm(o.Kernel(o.EQ, lengthscale=l), Xr, Xd, ad)
-            gm.append({"lengthscale": l, "path": names.get(path, str(path)) + (", upper triangle once" if sym else ", all entries"), "ms": ms, "mvm_per_s": 1e3 / ms,
+            split = "" if path != 2 else (", fp16 two-way split" if cg.get_info("last_mfma_f16") == 1 else ", bf16 three-way split")
+            gm.append({"lengthscale": l, "path": names.get(path, str(path)) + split + (", upper triangle once" if sym else ", all entries"), "ms": ms, "mvm_per_s": 1e3 / ms,
                        "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref)})
         out["gate_map_EQ_C2_size"] = {"what": "gramian(Lengthscale(EQ, l), x) * a, d=3 n=131072 fp32, x ~ N(0, I): the library's default path by lengthscale "
-                                              "(the matrix-core path is gated on g^2 R^2 <= 126 about the cloud's centre, csrc/dense_mfma.hip)", "rows_checked": 256, "by_lengthscale": gm}
+                                              "(the matrix-core path is gated on g^2 R^2 <= 126 about the cloud's centre, its fp16 split on <= 72; csrc/dense_mfma.hip)", "rows_checked": 256, "by_lengthscale": gm}
         kc = 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
         G = cg.gramian(kc, X)
         ms = _timed(lambda: G.mul_(y, a), warm=3, reps=8, warm_s=0.05)
