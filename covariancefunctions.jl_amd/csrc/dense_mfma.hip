@@ -993,12 +993,18 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
     if (ctx->dense_variant == 1 || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
     if (mfma_launcher(hk.tu_family) == nullptr) return false;
     if (hk.tu_family == COVGRAM_MATERNP && hk.k.p < 1) return false;          // MaternP(0) = Exp: not differentiable in s at 0
-    // MaternP at d <= 8: the lane-per-row kernels evaluate its profile in PACKED fp32 (two columns per instruction) and, on gramian(k, x),
-    // once per two entries (dense_sym32_kernel, round 4) — that beats the matrix-core kernels, whose 16 entries per lane run the square
-    // root, the exponential and the polynomial one by one: n = 131072, d = 3: 4.83 -> 2.61 ms, d = 8: 6.34 -> 3.85 ms; at d = 16 the distance
-    // on the matrix pipe evens it out (profiles/r04_mfma_vs_sym32.txt).  dense_variant = 2 still forces the matrix cores (tests).
+    // MaternP.  The lane-per-row kernels evaluate its profile in PACKED fp32 (two columns per instruction) and, on gramian(k, x), once per two
+    // entries (dense_sym32_kernel); the matrix-core kernels take the distance off the VALU but run the square root, the exponential and the
+    // polynomial entry by entry.  Early in round 4 the latter lost at d <= 8 (n = 131072, d = 3: 4.83 against 2.61 ms) — because hipcc kept the
+    // order test and the Power test as scalar branches around EVERY entry; with both decided once per tile (dense_mfma.hpp: mfma_profile_block)
+    // the symmetric matrix-core kernel is level at d = 3 (2.56 against 2.60 ms) and ahead from there (d = 8: 3.42 against 3.93 ms), the
+    // general kernel (two point sets, row shards) from d = 5 (16384 x 131072: d = 3 651 against 565 us, d = 8 888 against 974;
+    // profiles/r04_mfma_vs_sym32.txt).  dense_variant = 2 forces the matrix cores (tests).
     // (up to four right-hand sides: from five on the accumulation itself is a GEMM on the matrix cores, dense_mfma_mrhs_kernel)
-    if (hk.tu_family == COVGRAM_MATERNP && X->d <= 8 && nrhs < 5 && ctx->dense_variant != 2) return false;
+    if (hk.tu_family == COVGRAM_MATERNP && nrhs < 5 && ctx->dense_variant != 2) {
+        const bool sym_candidate = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N_HEAVY);
+        if (!sym_candidate && X->d <= 4) return false;
+    }
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
     if (hk.tu_family >= COVGRAM_NFAMILY) {
         // composite: every factor must be one of the smooth matrix-core profiles, and the relative errors of a product add up:

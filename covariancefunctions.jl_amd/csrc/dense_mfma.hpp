@@ -138,9 +138,40 @@ __device__ __forceinline__ float eq_row_fragments_fmt(const float* __restrict__ 
     else return eq_row_fragments<K2>(xr, Cn, d, g, h, a);
 }
 
+template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
+// The profile on the 16 entries a lane holds of one tile: s -> k(s), in place.  Everything that is uniform over the launch — MaternP's order, the
+// Power wrapper — is decided ONCE per tile here: inside the per-entry loop hipcc kept those tests as scalar branches around every entry (MaternP(2)
+// on the symmetric kernel: 80 branches + 32 scalar loads of the polynomial per 16 entries, 4.8 ms at C2 size where its arithmetic prices at 2).
+template <int FAM, typename KP>
+__device__ __forceinline__ void mfma_profile_block(f32x16& D, const KP& kp) {
+    if constexpr (FAM == COVGRAM_MATERNP) {
+        const float h0 = kp.h0[0], h1 = kp.h0[1], h2 = kp.h0[2], h3 = kp.h0[3];
+        const int p = kp.p;
+        if (p == 2) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(__builtin_fmaf(h2, r, h1), r, h0) * __builtin_amdgcn_exp2f(-r); }
+        } else if (p == 1) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(h1, r, h0) * __builtin_amdgcn_exp2f(-r); }
+        } else if (p == 3) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(h3, r, h2), r, h1), r, h0) * __builtin_amdgcn_exp2f(-r); }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[v] = Phi<FAM, float, mfma_folded<FAM>>::eval(fmaxf(D[v], 0.0f), kp);      // sqrt of a rounding-negative s
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = Phi<FAM, float, mfma_folded<FAM>>::eval(D[v], kp);
+    }
+    if (kp.power != 1) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = ipow(D[v], kp.power);
+    }
+}
+
 // EQ and MaternP take the dense path's FOLDED parameter block here too (log2(e) and sqrt(2p+1) in the coordinate pre-scale,
 // rescaled tables: exp2 of the MFMA result, no multiplications in front) — the host passes make_host_kernel(.., for_gradient = false)
-template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
 
 // LDS = 0: one wave per workgroup, its own fragment loads; LDS = 2: four waves on consecutive row tiles share every column tile
 // through LDS, one tile per stage, its K2 fragment slices fetched by the waves in turn (as dense_mfma_eq_kernel<.., 4, 2>)
@@ -217,15 +248,11 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
 #pragma unroll
                     for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv[v], acc[r][c][v]);
             } else {
+            mfma_profile_block<FAM>(D, kp);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float s = D[v];
-                if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);          // sqrt of a rounding-negative s
-                float kv = Phi<FAM, float, mfma_folded<FAM>>::eval(s, kp);
-                if (kp.power != 1) kv = ipow(kv, kp.power);
+            for (int v = 0; v < 16; ++v)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv, acc[r][c][v]);
-            }
+                for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], D[v], acc[r][c][v]);
             }
         }
     };
@@ -548,17 +575,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int v = 0; v < 16; ++v) D[v] = kv[v];
         } else {
+        if constexpr (FAST) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);
-            else {
-                float s = D[v];
-                if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);          // sqrt of a rounding-negative s
-                float kv = Phi<FAST ? COVGRAM_EQ : FAM, float, mfma_folded<FAST ? COVGRAM_EQ : FAM>>::eval(s, kp);
-                if (kp.power != 1) kv = ipow(kv, kp.power);
-                D[v] = kv;
-            }
-        }
+            for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]);
+        } else mfma_profile_block<FAM>(D, kp);
         }
         const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
@@ -769,16 +789,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 expr_value_block<float, ISO, 16>(sv, kp, kv);                                   \
                 _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = kv[v];                    \
             } else {                                                                            \
-            _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                    \
-                if constexpr (FAST) D[v] = __builtin_amdgcn_exp2f(D[v]);                        \
-                else {                                                                          \
-                    float s = D[v];                                                             \
-                    if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);                   \
-                    float kv = Phi<FAST ? COVGRAM_EQ : FAM, float, mfma_folded<FAST ? COVGRAM_EQ : FAM>>::eval(s, kp); \
-                    if (kp.power != 1) kv = ipow(kv, kp.power);                                 \
-                    D[v] = kv;                                                                  \
-                }                                                                               \
-            }                                                                                   \
+            if constexpr (FAST) { _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]); } \
+            else mfma_profile_block<FAM>(D, kp);                                                \
             }                                                                                   \
             const float wr = (J >= I0) ? w : 0.0f;                                              \
             float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;                                   \

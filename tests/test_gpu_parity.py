@@ -946,8 +946,11 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
     # the thresholds by profile cost (csrc/common.hpp MFMA_SYM_MIN_N_*): EQ d <= 4 from 18000, wider EQ from 15000, MaternP / RQ from 12500
     for kern, ko, nn, dd, want in ((cg.EQ(), oracle.Kernel(oracle.EQ), 17000, 3, 0), (cg.EQ(), oracle.Kernel(oracle.EQ), 19000, 3, 1),
                                    (cg.EQ(), oracle.Kernel(oracle.EQ), 16000, 8, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 12000, 12, 0),
-                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 12, 1),       # (MaternP at d <= 8 runs packed on the lane-per-row kernels: round 4)
-                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 3, 0), (cg.RQ(1.5), oracle.Kernel(oracle.RQ, param=1.5), 13000, 3, 1)):
+                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 12, 1),
+                                   # (MaternP at d <= 4: gramian(k, x) from the threshold on the symmetric matrix-core kernel — its order is decided once per tile since late
+                                   # round 4 —, below it and for two point sets packed on the lane-per-row kernels)
+                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 3, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 12000, 3, 0),
+                                   (cg.RQ(1.5), oracle.Kernel(oracle.RQ, param=1.5), 13000, 3, 1)):
         Xs = rng.standard_normal((nn, dd)).astype(np.float32); as_ = rng.standard_normal(nn).astype(np.float32)
         bb = (cg.gramian(kern, torch.from_numpy(Xs).cuda()) @ torch.from_numpy(as_).cuda()).cpu().numpy()
         assert cg.get_info("last_mfma_sym") == want, (type(kern).__name__, nn, dd)

@@ -18,7 +18,8 @@ for n in (32768, 131072):
             G = cg.gramian(k, X)
             cg.set_option("dense_variant", 0); t0 = t_us(lambda: G.mul_(y, a)); p0 = (cg.get_info("last_dense_path"), cg.get_info("last_mfma_sym"), cg.get_info("last_dense_sym")); y0 = y.clone()
             cg.set_option("dense_variant", 1); t1 = t_us(lambda: G.mul_(y, a)); p1 = (cg.get_info("last_dense_path"), cg.get_info("last_mfma_sym"), cg.get_info("last_dense_sym"))
-            print(f"n={n} d={d:2d} {name:14s}: default (path, mfma_sym, dense_sym)={p0} {t0:8.1f} us | direct differences {p1} {t1:8.1f} us  x{t0/t1:.2f}  diff {float((y-y0).norm()/y0.norm()):.1e}", flush=True)
+            cg.set_option("dense_variant", 2); t2 = t_us(lambda: G.mul_(y, a)); p2 = (cg.get_info("last_dense_path"), cg.get_info("last_mfma_sym"), cg.get_info("last_dense_sym")); d2 = float((y-y0).norm()/y0.norm())
+            print(f"n={n} d={d:2d} {name:14s}: default (path, mfma_sym, dense_sym)={p0} {t0:8.1f} us | direct differences {p1} {t1:8.1f} us | matrix cores forced {p2} {t2:8.1f} us (diff {d2:.1e})", flush=True)
 # row shard (two point sets: no symmetric form): matrix cores (dense_variant = 2) against the lane-per-row kernel
 for n in (131072,):
     for d in (3, 8):
