@@ -537,6 +537,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
     else if (!strcmp(key, "toeplitz_persist")) ctx->toeplitz_persist = value;
     else if (!strcmp(key, "mfma_f16")) ctx->mfma_f16 = value;
+    else if (!strcmp(key, "mfma_fuse_w")) ctx->mfma_fuse_w = value;
     else if (!strcmp(key, "toeplitz_real_spectrum")) ctx->toeplitz_real_spectrum = value;
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;
     else if (!strcmp(key, "jsplit")) ctx->jsplit = value;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
                                                            float* __restrict__ out, int64_t npad, int64_t tchunk, float g,
                                                            float alpha, float beta, int32_t final_store, const float* __restrict__ Cn,
                                                            unsigned long long* __restrict__ stamps, unsigned* __restrict__ tickets,
-                                                           float* __restrict__ yfinal) {
+                                                           float* __restrict__ yfinal, const float* __restrict__ EF, int64_t mcols) {
     // WPB waves per workgroup take consecutive row tiles and walk the SAME column tiles at the same pace (no barrier,
     // nothing shared explicitly): their fragment loads coalesce in the CU's vector L1 instead of each going to L2
     const int l = threadIdx.x & 63, t = l & 31, h = l >> 5;
@@ -169,9 +169,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     // Column tiles in pairs with two operand buffers (no register copies); the prefetch of a tile past the chunk is clamped
     // to the last tile (a harmless re-read) instead of branching.  Uniform base + 32-bit lane offset -> saddr loads.
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    const float* __restrict__ wbase = W + T0 * 32;                // W[j] = a_j exp2(f_j), packed per MVM (0 for padding columns)
+    // column weights w_j = a_j exp2(f_j) (0 for padding columns).  EF != nullptr (round 4, small problems): W is the caller's a itself and the product
+    // with the cached fraction factors is formed here, where a tile's weights are fetched: no weight-pack launch in front of the MVM (mvm_eq_mfma)
+    const float* __restrict__ wbase = W + T0 * 32;
     const int nt = (int)(T1 - T0);
-    auto weight = [&](int tc) { return wbase[tc * 32 + t]; };
+    auto weight = [&](int tc) {
+        if (EF == nullptr) return wbase[tc * 32 + t];
+        const int64_t j = (T0 + tc) * 32 + t;
+        return j < mcols ? W[j] * EF[j] : 0.0f;
+    };
     auto load_tile = [&](int ti, Frag (&f)[K2], float& w) {
         const int tc = ti < nt ? ti : nt - 1;
 #pragma unroll
@@ -542,24 +548,24 @@ static int mfma_blocks(int rt) {
 template <int K2, int FMT = 0>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
                         int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn,
-                        unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal) {
+                        unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal, const float* EF, int64_t mcols) {
     constexpr bool NARROW = K2 <= MFMA_NARROW_MAXK2;
     unsigned long long* const ns = nullptr;
     if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         *launched = dim3((grid.x + 7) / 8, grid.y);
-        if constexpr (K2 <= 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        if constexpr (K2 <= 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
-        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal); return; } }
-        if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols); return; } }
+        if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal);
+        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     }
 }
 
@@ -633,13 +639,20 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const float* EF;
     int rc = eq_fragments(ctx, Y, K2, g, Cn, &PB, &EF, fmt);
     if (rc) return rc;
-    // the weights a_j exp2(f_j) of THIS right-hand side (the in-kernel product — two loads and a multiply per column tile in
-    // place of this 4 us launch — measured 3 % slower on C2 in round 2, as in round 1)
-    void* Wp;
-    rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
-    if (rc) return rc;
-    float* W = (float*)Wp;
-    hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, a, EF, W, m, ntile * 32);
+    // the weights a_j exp2(f_j) of THIS right-hand side: a pack launch in front of the kernel, or — up to 16384 columns, where the launch is a
+    // tenth of the MVM — formed inside the kernel where a tile's weights are fetched (tools/fuse_w_ab.py: n = 2048 12.0 -> 10.8 us, 4096 13.2 -> 13.0,
+    // 16384 34.1 -> 33.7; beyond that the two dependent loads in front of the product hold the fetching wave behind its own LDS-DMA:
+    // 16384 x 131072 191.6 -> 195.3 us, C2-shaped 1351 -> 1408 us, as measured in rounds 1 and 2).  Option "mfma_fuse_w": 1 / 0 force it on / off.
+    const bool fuse_w = ctx->mfma_fuse_w == 1 || (ctx->mfma_fuse_w < 0 && m <= 16384);
+    const float* W = a;
+    if (!fuse_w) {
+        void* Wp;
+        rc = ws_reserve(ctx, 0, (size_t)ntile * 32 * sizeof(float), &Wp);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mfma_pack_w_kernel, dim3((unsigned)((ntile * 32 + 255) / 256)), dim3(256), 0, ctx->stream, a, EF, (float*)Wp, m, ntile * 32);
+        W = (const float*)Wp;
+    }
+    const float* EFk = fuse_w ? EF : nullptr;
     // split the column tiles so that the grid holds ~CUs * 128 waves (as the lane-per-row kernel, profiles/r01_quickbench_wg64.txt)
     // row tiles per wave: two share every B fragment while the state fits (d <= 8); option "rows_per_lane" = 1 / 2 forces it
     int rt = ctx->rows_per_lane == 1 ? 1 : (ctx->rows_per_lane == 2 ? 2 : (K2 <= MFMA_NARROW_MAXK2 ? 2 : 1));
@@ -718,7 +731,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
     ctx->last_mfma_lds = lds4 ? 1 : 0;
     dim3 launched;
-#define CG_MFMA_CASE(K) case K: if (fmt) { if constexpr (K <= 8) launch_mfma<K, 1>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); } else launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y); break;
+#define CG_MFMA_CASE(K) case K: if (fmt) { if constexpr (K <= 8) launch_mfma<K, 1>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m); } else launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;

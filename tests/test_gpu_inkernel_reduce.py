@@ -74,3 +74,27 @@ def test_lane_per_row_kernel_sums_its_own_slab(cg, oracle, dtype, n, m, d, p):
             assert np.linalg.norm(y.double().cpu().numpy() - ref) / np.linalg.norm(ref) <= (1e-5 if dtype == torch.float32 else 1e-12)
     finally:
         cg.set_option("dense_variant", 0); cg.set_option("dense_sym", -1); cg.set_option("inkernel_reduce", -1)
+
+
+def test_column_weights_formed_in_the_kernel_are_bit_identical(cg):
+    """Option mfma_fuse_w: the general matrix-core EQ kernel forms w_j = a_j exp2(f_j) where it fetches a tile's weights (default up to 16384 columns) or reads
+    them from the pack launch's buffer — the same fp32 product either way, so the results are bit-identical; ragged sizes, both splits, the in-kernel reduce on top."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    try:
+        for n, m, d in ((1000, 777, 3), (4099, 5000, 8), (300, 20001, 2), (2500, 2500, 12)):
+            X = torch.from_numpy((rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)).cuda()
+            Y = torch.from_numpy((rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)).cuda()
+            a = torch.from_numpy(rng.standard_normal(m).astype(np.float32)).cuda()
+            G = cg.gramian(cg.EQ(), X, Y)
+            outs = []
+            for f16 in (1, 0):
+                for fw in (0, 1, -1):
+                    cg.set_option("mfma_f16", f16); cg.set_option("mfma_fuse_w", fw); cg.set_option("dense_variant", 2)
+                    outs.append((f16, (G @ a).clone()))
+                    assert cg.get_info("last_dense_path") == 2
+            for f16 in (1, 0):
+                group = [o for f, o in outs if f == f16]
+                assert all(torch.equal(group[0], o) for o in group[1:]), (n, m, d, f16)
+    finally:
+        cg.set_option("mfma_f16", -1); cg.set_option("mfma_fuse_w", -1); cg.set_option("dense_variant", 0)
