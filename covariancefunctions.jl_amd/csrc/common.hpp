@@ -194,7 +194,7 @@ struct covgram_ctx {
     int64_t mfma_mrhs = -1;         // matrix right-hand sides on the fp32 matrix cores (dense_mfma_mrhs_kernel): -1 from 5 (9: cheap profiles, d <= 3) columns, 0 never, 1 from 2
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
-    int64_t mfma_fuse_w = -1;      // general matrix-core EQ kernel: the column weights a_j exp2(f_j) formed in the kernel (1; -1: up to 16384 columns) or by a pack launch in front of it (0)
+    int64_t mfma_fuse_w = -1;      // general matrix-core EQ kernel: the column weights a_j exp2(f_j) formed in the kernel (-1 / 1) or by a pack launch in front of it (0)
     int64_t mfma_f16 = -1;         // general matrix-core EQ kernel: the fp16 two-way split (half the MFMAs per tile): -1 / 1 = within MFMA_F16_GATE, 0 = never, 2 = within MFMA_GATE (measurements only)
     int64_t last_mfma_f16 = 0;
     int64_t toeplitz_persist = -1; // fused radix-16 row kernel: persistent workgroups (one per CU; a value > 1 = that many) that prefetch the next row pair into registers: -1 = fp64 only (measured), 0 = one pair per workgroup, 1 = always

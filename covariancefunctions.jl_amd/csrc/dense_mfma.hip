@@ -169,8 +169,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
     // Column tiles in pairs with two operand buffers (no register copies); the prefetch of a tile past the chunk is clamped
     // to the last tile (a harmless re-read) instead of branching.  Uniform base + 32-bit lane offset -> saddr loads.
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
-    // column weights w_j = a_j exp2(f_j) (0 for padding columns).  EF != nullptr (round 4, small problems): W is the caller's a itself and the product
-    // with the cached fraction factors is formed here, where a tile's weights are fetched: no weight-pack launch in front of the MVM (mvm_eq_mfma)
+    // column weights w_j = a_j exp2(f_j) (0 for padding columns).  EF != nullptr (round 4): W is the caller's a itself and the product with the cached
+    // fraction factors is formed here, where a tile's weights are fetched: no weight-pack launch in front of the MVM (mvm_eq_mfma)
     const float* __restrict__ wbase = W + T0 * 32;
     const int nt = (int)(T1 - T0);
     auto weight = [&](int tc) {
@@ -265,14 +265,22 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int nstage = (nt + WPB - 1) / WPB;
-        float gw;
+        // (gw, ge): the weight's two factors a_j and exp2(f_j) when the kernel forms the product itself (EF != nullptr) — loaded here, multiplied
+        // only where the weight goes to LDS at the end of the stage: a product right behind the loads would hold this wave until the LDS-DMA
+        // it has just issued lands (the same counter); ge = 1 when W holds packed weights
+        float gw, ge = 1.0f;
 #define CG_DMA(stage, SF)                                                                       \
         {                                                                                       \
             const int ti_ = (stage) * WPB + wv;                                                 \
             const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
                 __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
-            gw = ti_ < nt ? weight(tc_) : 0.0f;                    /* tiles past the chunk: weight 0 */ \
+            if (EF == nullptr) gw = ti_ < nt ? wbase[tc_ * 32 + t] : 0.0f;   /* tiles past the chunk: weight 0 */ \
+            else {                                                                              \
+                const int64_t j_ = (T0 + tc_) * 32 + t;                                         \
+                const bool in_ = ti_ < nt && j_ < mcols;                                        \
+                gw = in_ ? W[j_] : 0.0f; ge = in_ ? EF[j_] : 0.0f;                              \
+            }                                                                                   \
         }
 #define CG_STAGE(SF, SW)                                                                        \
         _Pragma("unroll 1") for (int k = 0; k < WPB; k += 2) {                                  \
@@ -285,17 +293,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
             process(f1, w1);                                                                    \
         }
         CG_DMA(0, sfA)
-        if (h == 0) swA[wv][t] = gw;
+        if (h == 0) swA[wv][t] = gw * ge;
         __syncthreads();
         for (int st = 0; st < nstage; st += 2) {
             CG_DMA(st + 1 < nstage ? st + 1 : st, sfB)              // past the last stage: a re-fetch nobody reads
             CG_STAGE(sfA, swA)
-            if (h == 0) swB[wv][t] = gw;
+            if (h == 0) swB[wv][t] = gw * ge;
             __syncthreads();
             if (st + 1 >= nstage) break;
             CG_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
             CG_STAGE(sfB, swB)
-            if (h == 0) swA[wv][t] = gw;
+            if (h == 0) swA[wv][t] = gw * ge;
             __syncthreads();
         }
 #undef CG_DMA
@@ -639,11 +647,12 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     const float* EF;
     int rc = eq_fragments(ctx, Y, K2, g, Cn, &PB, &EF, fmt);
     if (rc) return rc;
-    // the weights a_j exp2(f_j) of THIS right-hand side: a pack launch in front of the kernel, or — up to 16384 columns, where the launch is a
-    // tenth of the MVM — formed inside the kernel where a tile's weights are fetched (tools/fuse_w_ab.py: n = 2048 12.0 -> 10.8 us, 4096 13.2 -> 13.0,
-    // 16384 34.1 -> 33.7; beyond that the two dependent loads in front of the product hold the fetching wave behind its own LDS-DMA:
-    // 16384 x 131072 191.6 -> 195.3 us, C2-shaped 1351 -> 1408 us, as measured in rounds 1 and 2).  Option "mfma_fuse_w": 1 / 0 force it on / off.
-    const bool fuse_w = ctx->mfma_fuse_w == 1 || (ctx->mfma_fuse_w < 0 && m <= 16384);
+    // the weights a_j exp2(f_j) of THIS right-hand side: formed inside the kernel (round 4) — the wave that fetches a tile loads a_j and the cached
+    // exp2(f_j) with it and multiplies where the weight goes to LDS at the end of the stage.  (Rounds 1-2 had measured the in-kernel product 3 %
+    // SLOWER than the pack launch: the product stood right behind its two loads and so behind the LDS-DMA the wave had just issued — one counter.
+    // Deferred: C2-shaped 1359 -> 1340 us, a 16384-row shard 190.1 -> 186.5, n = 16384 35.1 -> 33.2, n = 2048 12.1 -> 10.8;
+    // profiles/r04_fuse_w_ab.txt.)  Option "mfma_fuse_w" = 0 restores the pack launch; results are bit-identical either way.
+    const bool fuse_w = ctx->mfma_fuse_w != 0;
     const float* W = a;
     if (!fuse_w) {
         void* Wp;

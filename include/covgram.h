@@ -166,8 +166,8 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "mfma_f16" (the general matrix-core EQ kernel's split of the coordinates: -1 / 1 = the fp16 two-way split — 3 products per coordinate, one MFMA per
  * FOUR coordinates, half the matrix-core work of the bf16 three-way split — while both clouds lie within g^2 R^2 <= 72 and the bf16 split beyond,
  * 0 = always the bf16 split, 2 = the fp16 split up to the matrix-core gate of 126: measurements only),
- * "mfma_fuse_w" (the general matrix-core EQ kernel's column weights a_j exp2(f_j): 1 = formed inside the kernel, 0 = by a pack launch in front of it,
- * -1 = inside the kernel up to 16384 columns, where the launch is a tenth of the MVM),
+ * "mfma_fuse_w" (the general matrix-core EQ kernel's column weights a_j exp2(f_j): -1 / 1 = formed inside the kernel, 0 = by a pack launch in front of
+ * it — bit-identical results),
  * "mfma_stamp" (1 = the general matrix-core EQ kernel runs its clock-stamping DIAGNOSTIC build — s_memtime / s_memrealtime
  * around every workgroup's column loop, for bench.py's sustained-clock figure; never set in production). */
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);

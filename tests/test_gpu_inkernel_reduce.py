@@ -77,7 +77,7 @@ def test_lane_per_row_kernel_sums_its_own_slab(cg, oracle, dtype, n, m, d, p):
 
 
 def test_column_weights_formed_in_the_kernel_are_bit_identical(cg):
-    """Option mfma_fuse_w: the general matrix-core EQ kernel forms w_j = a_j exp2(f_j) where it fetches a tile's weights (default up to 16384 columns) or reads
+    """Option mfma_fuse_w: the general matrix-core EQ kernel forms w_j = a_j exp2(f_j) where it fetches a tile's weights (the default) or reads
     them from the pack launch's buffer — the same fp32 product either way, so the results are bit-identical; ragged sizes, both splits, the in-kernel reduce on top."""
     import numpy as np
     rng = np.random.default_rng(5)
