@@ -21,4 +21,4 @@ for n, per, d, pp in ((524288, 65536, 8, 0), (131072, 131071, 3, 0), (524288, 65
     cg.set_option("mfma_stamp", 0); cg.set_option("rows_per_lane", 0)
     pairs = per * n
     cyc = ms * 1e-3 * khz * 1e3 * 1024 / (pairs / 64)          # SIMD cycles per 64 pairs: 1024 SIMDs
-    print(f"rows {per} x cols {n} d={d} {'pipelined stream' if pp else 'cluster order   '}: {ms * 1e3:.1f} us, clock under the stamped kernel {khz / 1e6:.3f} GHz -> {cyc:.2f} SIMD cycles per 64 pairs (at 2.4 GHz it would read {ms * 1e-3 * 2.4e9 * 1024 / (pairs / 64):.2f})")
+    print(f"rows {per} x cols {n} d={d}: {ms * 1e3:.1f} us, clock under the stamped kernel {khz / 1e6:.3f} GHz -> {cyc:.2f} SIMD cycles per 64 pairs (at 2.4 GHz it would read {ms * 1e-3 * 2.4e9 * 1024 / (pairs / 64):.2f})")
