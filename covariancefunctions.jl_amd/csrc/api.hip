@@ -555,6 +555,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "matrix_variant")) ctx->matrix_variant = value;
     else if (!strcmp(key, "mfma_mrhs")) ctx->mfma_mrhs = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
+    else if (!strcmp(key, "sum_fused")) ctx->sum_fused = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -573,6 +574,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_inkernel_reduce")) *value = ctx->last_inkernel_reduce;
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;
+    else if (!strcmp(key, "last_sum_fused")) *value = ctx->last_sum_fused;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
         // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none
@@ -825,11 +827,14 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
                 int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta, int32_t loc) {
     int rc = check_pair(ctx, X, Y);
     if (rc) return rc;
+    ctx->last_sum_fused = 0;
     {
         SumTerm terms[COVGRAM_COMPOSITE_MAX_TERMS];
         int nt = 0;
         double constant = 0.0;
-        if (composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {
+        // (a Sum the one-pass matrix-core kernels take is NOT split: every term shares the pair's distance, as in the reference's
+        //  per-pair evaluation src/algebra.jl:27-47 — dense_mfma.hip: sum_fused_applies)
+        if (!sum_fused_applies(ctx, k, X, Y, nrhs) && composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {
             HostKernel chk;
             rc = make_host_kernel(k, X->dtype, false, &chk);   // the composite's own validation (traits, limits) still applies
             if (rc) return rc;
@@ -1175,7 +1180,9 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         SumTerm terms[COVGRAM_COMPOSITE_MAX_TERMS];
         int nt = 0;
         double constant = 0.0;
-        if (composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {   // derivatives are linear in the kernel: term by term as well
+        // (a Sum the one-pass matrix-core kernels take is NOT split: every term shares the pair's distance, as in the reference's
+        //  per-pair evaluation src/algebra.jl:27-47 — dense_mfma.hip: sum_fused_applies)
+        if (!sum_fused_applies(ctx, k, X, Y, nrhs) && composite_sum_terms(ctx, k, loc, terms, &nt, &constant)) {   // derivatives are linear in the kernel: term by term as well
             HostKernel chk;
             rc = make_host_kernel(k, X->dtype, true, &chk);
             if (rc) return rc;

@@ -2,6 +2,7 @@
 // gfx950 only; no CPU compute path exists in this library (include/covgram.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -105,9 +106,30 @@ struct ExprParams {
     KParams<T> f[EXPR_MAXF];     // per factor: gamma2 = 1/l^2, power and the profile constants (scale is in coef)
 };
 
+// A Sum of two or three single-profile isotropic terms (src/algebra.jl:5-14; the reference evaluates every term on the SAME pair, :27-47) on
+// the fp32 matrix-core kernels in ONE pass (round 5): the MFMA yields s' = g^2 |x - y|^2 once, term t sees s' ratio[t] (ratio[0] = 1: g carries
+// the first term's whole argument scale, lengthscale and folded constants), and the profiles are evaluated term after term on the tile's
+// register pairs (dense_mfma.hpp: mfma_sum_block).  A matrix-core-only pseudo-family: no lane-per-row / gradient instance exists.
+constexpr int FAM_SUM_ISO = COVGRAM_NFAMILY + 2;
+constexpr int SUM_MAXT = 3;
+template <typename T>
+struct SumParams {
+    T gamma;                     // coordinate pre-scale of rows and columns: the first term's argument is the MFMA result itself
+    int32_t power;               // always 1
+    int32_t nterms;              // 2 or 3
+    int32_t fam[SUM_MAXT];       // covgram_family of each term: EQ, RQ, Cauchy, IMQ or MaternP
+    int32_t p[SUM_MAXT];         // MaternP order (1 .. 3)
+    T ratio[SUM_MAXT];           // the term's argument is s' ratio[t]
+    // the term's constants, its coefficient folded in: EQ {coef}: coef exp2(-arg); MaternP {coef h_0 .. coef h_3} (tables rescaled to
+    // sqrt(arg) = r log2 e): q(sqrt arg) exp2(-sqrt arg); RQ {coef, -alpha}: coef exp2(-alpha log2(1 + arg)); Cauchy {coef}: coef / (1 + arg);
+    // IMQ {coef, c^2}: coef rsq(arg + c^2)
+    T c[SUM_MAXT][4];
+};
+
 template <int FAM, typename T> struct ParamsOf { using type = KParams<T>; };
 template <typename T> struct ParamsOf<FAM_EXPR_ISO, T> { using type = ExprParams<T>; };
 template <typename T> struct ParamsOf<FAM_EXPR_DOT, T> { using type = ExprParams<T>; };
+template <typename T> struct ParamsOf<FAM_SUM_ISO, T> { using type = SumParams<T>; };
 template <int FAM> constexpr bool fam_is_expr = (FAM == FAM_EXPR_ISO || FAM == FAM_EXPR_DOT);
 template <int FAM> constexpr bool fam_is_iso = (FAM != COVGRAM_DOT && FAM != COVGRAM_EXPDOT && FAM != COVGRAM_ASINDOT && FAM != FAM_EXPR_DOT);
 
@@ -136,9 +158,63 @@ inline KParams<T> cast_params(const KParams<double>& s) {
     return d;
 }
 
+// Is the composite `hk` a Sum the one-pass kernels take?  2-3 terms, each ONE profile (times constants) of EQ / RQ / Cauchy / IMQ /
+// MaternP(1..3) without a Power wrapper.
+inline bool sum_fusable(const HostKernel& hk) {
+    if (hk.tu_family != FAM_EXPR_ISO || hk.nterms < 2 || hk.nterms > SUM_MAXT) return false;
+    for (int t = 0; t < hk.nterms; ++t) {
+        if (hk.nfac[t] != 1 || hk.fkp[t].power != 1) return false;
+        const int f = hk.ffam[t];
+        const bool ok = f == COVGRAM_EQ || f == COVGRAM_RQ || f == COVGRAM_CAUCHY || f == COVGRAM_IMQ ||
+                        (f == COVGRAM_MATERNP && hk.fkp[t].p >= 1 && hk.fkp[t].p <= 3);
+        if (!ok) return false;
+    }
+    return true;
+}
+// the one-pass parameter block of such a Sum (hk.fkp[t]: the factor's UNFOLDED block, gamma = 1 / l_t, natural tables)
+inline SumParams<double> make_sum_params(const HostKernel& hk) {
+    SumParams<double> sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.power = 1; sp.nterms = hk.nterms;
+    const double LOG2E = 1.4426950408889634074;
+    double a0 = 1.0;
+    for (int t = 0; t < hk.nterms && t < SUM_MAXT; ++t) {
+        const KParams<double>& q = hk.fkp[t];
+        const double coef = hk.coef[t];
+        double at = q.gamma2;                                   // the term's argument = at |x - y|^2
+        sp.fam[t] = hk.ffam[t]; sp.p[t] = q.p;
+        switch (hk.ffam[t]) {
+            case COVGRAM_EQ: at *= 0.5 * LOG2E; sp.c[t][0] = coef; break;                      // exp(-s/2) = exp2(-arg)
+            case COVGRAM_MATERNP: {                                                              // sqrt(arg) = r log2 e, r = sqrt((2p+1) s)
+                at *= q.mp_c * LOG2E * LOG2E;
+                double li = 1.0;
+                for (int i = 0; i < 4; ++i) { sp.c[t][i] = i <= q.p ? coef * q.h0[i] * li : 0.0; li /= LOG2E; }
+                break;
+            }
+            case COVGRAM_RQ: at *= q.c0; sp.c[t][0] = coef; sp.c[t][1] = -q.param; break;     // u = 1 + s / (2 alpha)
+            case COVGRAM_IMQ: sp.c[t][0] = coef; sp.c[t][1] = q.param; break;                  // param holds c^2
+            default: sp.c[t][0] = coef; break;                                                   // Cauchy
+        }
+        if (t == 0) a0 = at;
+        sp.ratio[t] = at / a0;
+    }
+    sp.gamma = sqrt(a0);
+    return sp;
+}
+
 template <int FAM, typename T>
 inline typename ParamsOf<FAM, T>::type make_params(const HostKernel& hk) {
-    if constexpr (fam_is_expr<FAM>) {
+    if constexpr (FAM == FAM_SUM_ISO) {
+        const SumParams<double> s = make_sum_params(hk);
+        SumParams<T> d;
+        memset(&d, 0, sizeof(d));
+        d.gamma = (T)s.gamma; d.power = 1; d.nterms = s.nterms;
+        for (int t = 0; t < SUM_MAXT; ++t) {
+            d.fam[t] = s.fam[t]; d.p[t] = s.p[t]; d.ratio[t] = (T)s.ratio[t];
+            for (int i = 0; i < 4; ++i) d.c[t][i] = (T)s.c[t][i];
+        }
+        return d;
+    } else if constexpr (fam_is_expr<FAM>) {
         ExprParams<T> e;
         memset(&e, 0, sizeof(e));
         e.gamma = (T)1; e.power = 1; e.nterms = hk.nterms;
@@ -175,6 +251,8 @@ struct covgram_ctx {
     int64_t grad_bcast = -1;     // fp64 expanded-form gradient MVM with the column records in VGPRs (v_fmac_f64_dpp row_newbcast): -1 auto, 0 never, 1 / 4 = always with that many waves per workgroup
     int64_t last_grad_bcast = 0;
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
+    int64_t sum_fused = -1;      // fp32 Sum of 2-3 single-profile isotropic terms: one pass of the matrix-core kernels over the shared distance (-1 / 1 where they apply, 0: one MVM per term)
+    int64_t last_sum_fused = 0;
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
     int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
     int64_t last_dense_sym = 0;
@@ -330,6 +408,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
                     int pfirst = 0, int pstride = 1, const covgram_kernel* kgen = nullptr);
 bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs = 1);
+bool sum_fused_applies(const covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, int nrhs);
 int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const float* a, int64_t lda,
                  float* y, int64_t ldy, int32_t nrhs, double alpha, double beta);
 

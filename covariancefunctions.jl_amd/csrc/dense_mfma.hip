@@ -817,6 +817,7 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
 }
 
 static int mfma_k2_for(int dims);
+static int mfma_family_of(const covgram_ctx* ctx, const HostKernel& hk, float* gamma);
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 // the generic profiles' symmetric form: same conditions on top of the generic matrix-core gate (hk: gamma = 1/l parameter block)
 bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
@@ -824,7 +825,10 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     if (!mfma_gen_eligible(ctx, hk, X, Y, nrhs)) return false;
     const int k2 = mfma_k2_for(X->d + (hk.k.trait == COVGRAM_ISOTROPIC ? 1 : 0));
     if (k2 < 0) return false;
-    const int tpp = k2 > MFMA_NARROW_MAXK2 ? 4 : 8;
+    float gam_unused;
+    const int lfam = mfma_family_of(ctx, hk, &gam_unused);
+    if (lfam == FAM_SUM_ISO && k2 > 8) return false;                              // no one-pass symmetric instance: one (symmetric) MVM per term instead
+    const int tpp = mfma_sym_tiles_per_panel(lfam, k2);
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
     const bool heavy = hk.tu_family == COVGRAM_MATERNP || hk.tu_family == COVGRAM_RQ || hk.tu_family >= COVGRAM_NFAMILY;   // profile costs several exponentials
@@ -845,6 +849,9 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     }
     const HostKernel& hku = fast ? hk : hkg;
     const bool iso = hku.k.trait == COVGRAM_ISOTROPIC;
+    float gamg = 0.0f;
+    const int lfam = fast ? COVGRAM_EQ : mfma_family_of(ctx, hku, &gamg);
+    if (!fast) ctx->last_sum_fused = lfam == FAM_SUM_ISO ? 1 : 0;
     const int64_t n = X->n;
     const int d = X->d;
     // EQ form: the fp16 two-way split inside its gate, as the general kernel (mvm_eq_mfma, "Which split"); every rank of a multi-GPU call sees the same
@@ -856,7 +863,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: d = %d has no matrix-core instance", d);
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
-    const int tpp = K2 > MFMA_NARROW_MAXK2 ? 4 : 8;                  // row tiles per panel: 8 waves x 1 tile, or 4 x 1 for long fragments
+    // row tiles per panel: 8 waves x 1 tile, 6 for the heavy profiles' 3-waves-per-SIMD form, or 4 x 1 for long fragments (dense_mfma.hpp)
+    const int tpp = fast ? (K2 > MFMA_NARROW_MAXK2 ? 4 : 8) : mfma_sym_tiles_per_panel(lfam, K2);
     const int64_t ntile = (n + 31) / 32, panels = (ntile + tpp - 1) / tpp, npad = panels * 32 * tpp + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
@@ -878,7 +886,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         float* Wg = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                           n, 1, 0, PB, Wg, K2, 1, (float)hku.kp.gamma, iso ? 1 : 0, Cn);
+                           n, 1, 0, PB, Wg, K2, 1, gamg, iso ? 1 : 0, Cn);
         PBu = PB; W = Wg;
     }
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
@@ -888,7 +896,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // chunks last, so the last round balances); >= 64 tiles — shorter chunks do not amortise a workgroup's prologue (rows, row
     // weights, first stage) —, >= 128 for a rank's share (tools/sym_tchunk_sweep.py, tools/sym_shard_probe.py: rank r of 8 at
     // C2 size 170-185 us with 128-tile chunks, 183-201 with 64)
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 8 ? 2 : 3) * (pstride > 1 ? 4 : 8);
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 4 ? 3 : 2) * (pstride > 1 ? 4 : 8);
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     tchunk = std::max<int64_t>(pstride > 1 ? 128 : 64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
@@ -965,8 +973,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         ma.nrhs = 1; ma.tchunk = tchunk; ma.alpha = 1.0f; ma.beta = 0.0f; ma.final_store = 0; ma.K2 = K2; ma.RT = 1; ma.NR = 1;
         ma.hk = &hku; ma.stream = ctx->stream; ma.grid = grid; ma.Cn = Cn;
         ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride;
-        mfma_launch_fn launch = mfma_launcher(hku.tu_family);
-        CG_REQUIRE(launch != nullptr, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: family %d has no matrix-core path", hku.tu_family);
+        mfma_launch_fn launch = mfma_launcher(lfam);
+        CG_REQUIRE(launch != nullptr, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: family %d has no matrix-core path", lfam);
         rc = launch(ma, false);
         if (rc) return rc;
     }
@@ -986,7 +994,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 // generic profiles / several right-hand sides (dense_mfma.hpp)
 // ------------------------------------------------------------------------------------------------------------------------
 #define CG_DECL(n) int launch_mfma_family_##n(const MfmaArgs&, bool query);
-CG_DECL(0) CG_DECL(2) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(11) CG_DECL(12)
+CG_DECL(0) CG_DECL(2) CG_DECL(4) CG_DECL(5) CG_DECL(6) CG_DECL(7) CG_DECL(8) CG_DECL(11) CG_DECL(12) CG_DECL(13)
 #undef CG_DECL
 
 mfma_launch_fn mfma_launcher(int family) {
@@ -1000,8 +1008,35 @@ mfma_launch_fn mfma_launcher(int family) {
         case COVGRAM_EXPDOT: return launch_mfma_family_8;
         case FAM_EXPR_ISO: return launch_mfma_family_11;          // Sum / Product / Power composites of the profiles above
         case FAM_EXPR_DOT: return launch_mfma_family_12;
+        case FAM_SUM_ISO: return launch_mfma_family_13;           // a Sum of 2-3 single-profile isotropic terms in one pass (common.hpp: SumParams)
         default: return nullptr;
     }
+}
+
+// The launcher family and coordinate pre-scale of a generic matrix-core MVM: a Sum of single-profile terms runs its one-pass form
+// (FAM_SUM_ISO: the pre-scale carries the first term's argument scale) unless option "sum_fused" = 0 keeps the composite interpreter.
+static int mfma_family_of(const covgram_ctx* ctx, const HostKernel& hk, float* gamma) {
+    if (ctx->sum_fused != 0 && sum_fusable(hk)) { *gamma = (float)make_sum_params(hk).gamma; return FAM_SUM_ISO; }
+    *gamma = (float)hk.kp.gamma;
+    return hk.tu_family;
+}
+// covgram_mvm: does this composite take the one-pass Sum kernels (instead of one MVM per term)?
+bool sum_fused_applies(const covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, int nrhs) {
+    if (ctx->sum_fused == 0 || k == nullptr || k->family != COVGRAM_COMPOSITE || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
+    HostKernel hk;
+    if (make_host_kernel(k, COVGRAM_F32, false, &hk) != COVGRAM_OK) return false;
+    if (!sum_fusable(hk) || !mfma_gen_eligible(ctx, hk, X, Y, nrhs)) return false;
+    // gramian(k, x) at d >= 16: the one-pass symmetric kernel has no instance (K2 > 8), and one symmetric MVM per term evaluates half the pairs
+    // of the one-pass general kernel
+    const bool same = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N_HEAVY);
+    if (same && mfma_k2_for(X->d + 1) > 8) return false;
+    // Measured (profiles/r05_sum_fused_ab.txt, d = 3, n = 131072): what one pass shares is the matrix-core work, the weighted sums and the slabs —
+    // every term's transcendentals remain, and they are what the kernels are bound by.  Three terms: 4.03 against 4.84 ms for one symmetric MVM
+    // per term; two terms on the symmetric form: 3.32 against 3.06 (the one-pass kernel's wave-uniform family switches and its one-tile loop cost
+    // more than the second MFMA pass and slab they save), on the general form (row shards, two point sets) 705 against 730 us.
+    // Option "sum_fused" = 1 takes the one-pass kernels wherever they exist (tests).
+    if (ctx->sum_fused == 1) return true;
+    return hk.nterms >= 3 || !same;
 }
 
 static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coordinates, from the compiled set
@@ -1015,18 +1050,10 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
     if (ctx->dense_variant == 1 || X->dtype != COVGRAM_F32 || Y->n == 0) return false;
     if (mfma_launcher(hk.tu_family) == nullptr) return false;
     if (hk.tu_family == COVGRAM_MATERNP && hk.k.p < 1) return false;          // MaternP(0) = Exp: not differentiable in s at 0
-    // MaternP.  The lane-per-row kernels evaluate its profile in PACKED fp32 (two columns per instruction) and, on gramian(k, x), once per two
-    // entries (dense_sym32_kernel); the matrix-core kernels take the distance off the VALU but run the square root, the exponential and the
-    // polynomial entry by entry.  Early in round 4 the latter lost at d <= 8 (n = 131072, d = 3: 4.83 against 2.61 ms) — because hipcc kept the
-    // order test and the Power test as scalar branches around EVERY entry; with both decided once per tile (dense_mfma.hpp: mfma_profile_block)
-    // the symmetric matrix-core kernel is level at d = 3 (2.56 against 2.60 ms) and ahead from there (d = 8: 3.42 against 3.93 ms), the
-    // general kernel (two point sets, row shards) from d = 5 (16384 x 131072: d = 3 651 against 565 us, d = 8 888 against 974;
-    // profiles/r04_mfma_vs_sym32.txt).  dense_variant = 2 forces the matrix cores (tests).
-    // (up to four right-hand sides: from five on the accumulation itself is a GEMM on the matrix cores, dense_mfma_mrhs_kernel)
-    if (hk.tu_family == COVGRAM_MATERNP && nrhs < 5 && ctx->dense_variant != 2) {
-        const bool sym_candidate = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N_HEAVY);
-        if (!sym_candidate && X->d <= 4) return false;
-    }
+    // MaternP(p >= 1): up to round 4 the lane-per-row kernels (packed fp32 profile) beat the matrix-core ones (profile entry by entry) at d <= 4.
+    // Round 5: the profile arithmetic runs on register pairs (dense_mfma.hpp: mfma_profile_pairs) and the order is a compile-time constant of the
+    // instance: the general kernel is ahead at every d (16384 x 131072, d = 3: 428 against 543 us lane-per-row; d = 8: 631 against 862;
+    // profiles/r05_sum_fused_ab.txt), the symmetric one too (n = 131072, d = 3: 2.0 against 2.6 ms) — MaternP(p >= 1) no longer has an exception here.
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
     if (hk.tu_family >= COVGRAM_NFAMILY) {
         // composite: every factor must be one of the smooth matrix-core profiles, and the relative errors of a product add up:
@@ -1086,7 +1113,10 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
     const int K2 = mfma_k2_for(d + (iso ? 1 : 0));
     const int64_t ntile = (m + 31) / 32;
-    mfma_launch_fn launch = mfma_launcher(hk.tu_family);
+    float gam;
+    const int lfam = mfma_family_of(ctx, hk, &gam);
+    ctx->last_sum_fused = lfam == FAM_SUM_ISO ? 1 : 0;
+    mfma_launch_fn launch = mfma_launcher(lfam);
     const double alpha_eff = alpha * hk.kp.scale;
     int cdone = 0;
     // many right-hand sides: blocks of up to 64 on the fp32 matrix cores (dense_mfma_mrhs_kernel).  Its time is flat up to 32 columns
@@ -1110,7 +1140,7 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         float* AP = (float*)((char*)P + fb + wb);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
-                           lda, 0, 0, PB, Wd, K2, 1, (float)hk.kp.gamma, iso ? 1 : 0, (const float*)Y->center);
+                           lda, 0, 0, PB, Wd, K2, 1, gam, iso ? 1 : 0, (const float*)Y->center);
         const int64_t ae = ntile * NB * 64 * 16;
         hipLaunchKernelGGL(mfma_pack_rhs_kernel, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, ctx->stream, a, lda, c0 + nr, c0, m, AP, NB);
         const int64_t rowtiles = (n + 31) / 32, npad = rowtiles * 32;
@@ -1149,7 +1179,7 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         float* W = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a_c,
-                           lda, nr, 0, PB, W, K2, NR, (float)hk.kp.gamma, iso ? 1 : 0, (const float*)Y->center);
+                           lda, nr, 0, PB, W, K2, NR, gam, iso ? 1 : 0, (const float*)Y->center);
         MfmaArgs ma;
         ma.K2 = K2; ma.NR = NR;
         ma.RT = (NR == 1 && K2 <= 4 && ctx->rows_per_lane != 1) ? 2 : 1;

@@ -139,43 +139,193 @@ __device__ __forceinline__ float eq_row_fragments_fmt(const float* __restrict__ 
 }
 
 template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
-// The profile on the 16 entries a lane holds of one tile: s -> k(s), in place.  Everything that is uniform over the launch — MaternP's order, the
-// Power wrapper — is decided ONCE per tile here: inside the per-entry loop hipcc kept those tests as scalar branches around every entry (MaternP(2)
-// on the symmetric kernel: 80 branches + 32 scalar loads of the polynomial per 16 entries, 4.8 ms at C2 size where its arithmetic prices at 2).
-template <int FAM, typename KP>
-__device__ __forceinline__ void mfma_profile_block(f32x16& D, const KP& kp) {
-    if constexpr (FAM == COVGRAM_MATERNP) {
-        const float h0 = kp.h0[0], h1 = kp.h0[1], h2 = kp.h0[2], h3 = kp.h0[3];
-        const int p = kp.p;
-        if (p == 2) {
+
+// ---- the profile on a tile, in register pairs (round 5) -------------------------------------------------------------------------
+// A lane holds 16 entries of a 32 x 32 tile in 16 consecutive registers = 8 aligned pairs.  Only the transcendental instructions
+// (v_sqrt / v_exp / v_log / v_rcp / v_rsq_f32: quarter rate, 8 issue cycles per wave) work entry by entry; everything around them — the
+// polynomial of MaternP, the argument scaling of RQ / Cauchy / IMQ, the Power wrapper, a Sum's per-term scaling and accumulation — is
+// v_pk_fma / v_pk_mul / v_pk_add_f32 on the pairs (two entries per instruction at ~2.2 cycles against ~2.7 each; profiles/
+// r01_microbench_valu_rates.txt).  Round 4 had done this for the EQ kernel's weighted sums only; MaternP(2) on the symmetric kernel at C2
+// size: 33 -> 22 issue cycles per 64 evaluated entries.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_splat(float x) { return (f32x2){x, x}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// sqrt of a profile argument that rounding may have left at -1e-7 P: |s| through the instruction's free source modifier instead of a
+// separate v_max_f32 (either way the result is a rounding-sized r where the exact one is 0)
+__device__ __forceinline__ f32x2 pk_sqrt_abs(f32x2 s) { return (f32x2){__builtin_amdgcn_sqrtf(__builtin_fabsf(s[0])), __builtin_amdgcn_sqrtf(__builtin_fabsf(s[1]))}; }
+__device__ __forceinline__ f32x2 pk_exp2_neg(f32x2 s) { return (f32x2){__builtin_amdgcn_exp2f(-s[0]), __builtin_amdgcn_exp2f(-s[1])}; }
+__device__ __forceinline__ f32x2 pk_exp2(f32x2 s) { return (f32x2){__builtin_amdgcn_exp2f(s[0]), __builtin_amdgcn_exp2f(s[1])}; }
+__device__ __forceinline__ f32x2 pk_log2(f32x2 s) { return (f32x2){__builtin_amdgcn_logf(s[0]), __builtin_amdgcn_logf(s[1])}; }
+__device__ __forceinline__ f32x2 pk_rcp(f32x2 s) { return (f32x2){__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])}; }
+__device__ __forceinline__ f32x2 pk_rsq(f32x2 s) { return (f32x2){__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])}; }
+
+// Register pairs are worked on NP = 4 at a time (8 entries): the symmetric kernels run 4 waves per SIMD = 128 VGPRs, and a whole tile's
+// worth of temporaries (16 roots + 16 exponentials beside the 16 arguments, the accumulators and the row weights) spilled to scratch.
+constexpr int PNP = 4;
+
+// MaternP of order P on the folded argument (sqrt(s) = r log2 e): q(sqrt s) exp2(-sqrt s), q's coefficients as splat pairs
+template <int P>
+__device__ __forceinline__ void maternp_pairs(f32x2 (&S)[PNP], f32x2 h0, f32x2 h1, f32x2 h2, f32x2 h3) {
+    f32x2 r[PNP], e[PNP];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(__builtin_fmaf(h2, r, h1), r, h0) * __builtin_amdgcn_exp2f(-r); }
-        } else if (p == 1) {
+    for (int v = 0; v < PNP; ++v) r[v] = pk_sqrt_abs(S[v]);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(h1, r, h0) * __builtin_amdgcn_exp2f(-r); }
-        } else if (p == 3) {
+    for (int v = 0; v < PNP; ++v) e[v] = pk_exp2_neg(r[v]);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { const float r = cg_sqrt(fmaxf(D[v], 0.0f)); D[v] = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(h3, r, h2), r, h1), r, h0) * __builtin_amdgcn_exp2f(-r); }
-        } else {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) D[v] = Phi<FAM, float, mfma_folded<FAM>>::eval(fmaxf(D[v], 0.0f), kp);      // sqrt of a rounding-negative s
-        }
-    } else {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) D[v] = Phi<FAM, float, mfma_folded<FAM>>::eval(D[v], kp);
-    }
-    if (kp.power != 1) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) D[v] = ipow(D[v], kp.power);
+    for (int v = 0; v < PNP; ++v) {
+        f32x2 q;
+        if constexpr (P == 1) q = pk_fma(h1, r[v], h0);
+        else if constexpr (P == 2) q = pk_fma(pk_fma(h2, r[v], h1), r[v], h0);
+        else q = pk_fma(pk_fma(pk_fma(h3, r[v], h2), r[v], h1), r[v], h0);
+        S[v] = q * e[v];
     }
 }
+
+// One single-profile family on PNP pairs, in place: s -> k(s); ORDER = MaternP's order (decided once per tile by the caller), 0 otherwise
+template <int FAM, int ORDER, typename KP>
+__device__ __forceinline__ void mfma_profile_pairs(f32x2 (&S)[PNP], const KP& kp) {
+    if constexpr (FAM == COVGRAM_MATERNP) {
+        if constexpr (ORDER >= 1 && ORDER <= 3) {
+            maternp_pairs<ORDER>(S, pk_splat(kp.h0[0]), pk_splat(kp.h0[1]), pk_splat(kp.h0[2]), pk_splat(kp.h0[3]));
+        } else {
+#pragma unroll
+            for (int v = 0; v < PNP; ++v)
+                S[v] = (f32x2){Phi<FAM, float, true>::eval(__builtin_fabsf(S[v][0]), kp), Phi<FAM, float, true>::eval(__builtin_fabsf(S[v][1]), kp)};
+        }
+    } else if constexpr (FAM == COVGRAM_EQ) {                       // folded: exp2(-s)
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_exp2_neg(S[v]);
+    } else if constexpr (FAM == COVGRAM_RQ) {                       // (1 + s / (2 alpha))^-alpha = exp2(-alpha log2 u)
+        const f32x2 c0 = pk_splat(kp.c0), one = pk_splat(1.0f), na = pk_splat(-kp.param);
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_log2(pk_fma(S[v], c0, one));
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_exp2(S[v] * na);
+    } else if constexpr (FAM == COVGRAM_CAUCHY) {
+        const f32x2 one = pk_splat(1.0f);
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_rcp(S[v] + one);
+    } else if constexpr (FAM == COVGRAM_IMQ) {
+        const f32x2 c2 = pk_splat(kp.param);
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_rsq(S[v] + c2);
+    } else if constexpr (FAM == COVGRAM_EXPDOT) {
+        const f32x2 l2e = pk_splat(1.44269504088896340736f);
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) S[v] = pk_exp2(S[v] * l2e);
+    } else if constexpr (FAM == COVGRAM_DOT) {
+    } else {
+#pragma unroll
+        for (int v = 0; v < PNP; ++v)
+            S[v] = (f32x2){Phi<FAM, float, mfma_folded<FAM>>::eval(S[v][0], kp), Phi<FAM, float, mfma_folded<FAM>>::eval(S[v][1], kp)};
+    }
+}
+
+// ---- a Sum of single-profile terms in one pass (common.hpp: SumParams) -----------------------------------------------------------
+// Term T on PNP pairs: K (+)= coef_T phi_T(S ratio_T).  T is a compile-time term index (its constants are hoisted into SGPRs), FAMILY and
+// ORDER are compile-time too: the caller takes the wave-uniform switches once per tile and term.  LAST: S may be overwritten.
+template <int T, int FAMILY, int ORDER, typename KP>
+__device__ __forceinline__ void mfma_sum_term_pairs(f32x2 (&S)[PNP], f32x2 (&K)[PNP], const KP& kp) {
+    constexpr bool FIRST = T == 0;
+    const f32x2 c0 = pk_splat(kp.c[T][0]), c1 = pk_splat(kp.c[T][1]);
+    f32x2 A[PNP];
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) A[v] = S[v];
+    } else {
+        const f32x2 ratio = pk_splat(kp.ratio[T]);
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) A[v] = S[v] * ratio;
+    }
+    if constexpr (FAMILY == COVGRAM_MATERNP) {
+        maternp_pairs<ORDER>(A, c0, c1, pk_splat(kp.c[T][2]), pk_splat(kp.c[T][3]));
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) K[v] = FIRST ? A[v] : K[v] + A[v];
+    } else {
+        if constexpr (FAMILY == COVGRAM_EQ) {
+#pragma unroll
+            for (int v = 0; v < PNP; ++v) A[v] = pk_exp2_neg(A[v]);
+        } else if constexpr (FAMILY == COVGRAM_RQ) {
+            const f32x2 one = pk_splat(1.0f);
+#pragma unroll
+            for (int v = 0; v < PNP; ++v) A[v] = pk_log2(A[v] + one);
+#pragma unroll
+            for (int v = 0; v < PNP; ++v) A[v] = pk_exp2(A[v] * c1);
+        } else if constexpr (FAMILY == COVGRAM_CAUCHY) {
+            const f32x2 one = pk_splat(1.0f);
+#pragma unroll
+            for (int v = 0; v < PNP; ++v) A[v] = pk_rcp(A[v] + one);
+        } else {                                                    // COVGRAM_IMQ
+#pragma unroll
+            for (int v = 0; v < PNP; ++v) A[v] = pk_rsq(A[v] + c1);
+        }
+#pragma unroll
+        for (int v = 0; v < PNP; ++v) K[v] = FIRST ? c0 * A[v] : pk_fma(c0, A[v], K[v]);
+    }
+}
+// term T on the whole tile (both halves behind ONE family / order switch)
+template <int T, typename KP>
+__device__ __forceinline__ void mfma_sum_term(f32x2 (&S)[2][PNP], f32x2 (&K)[2][PNP], const KP& kp) {
+    const int fam = kp.fam[T];
+#define CG_SUM_BOTH(F, O) { mfma_sum_term_pairs<T, F, O>(S[0], K[0], kp); mfma_sum_term_pairs<T, F, O>(S[1], K[1], kp); }
+    if (fam == COVGRAM_MATERNP) {
+        const int p = kp.p[T];
+        if (p == 2) CG_SUM_BOTH(COVGRAM_MATERNP, 2)
+        else if (p == 1) CG_SUM_BOTH(COVGRAM_MATERNP, 1)
+        else CG_SUM_BOTH(COVGRAM_MATERNP, 3)
+    } else if (fam == COVGRAM_EQ) CG_SUM_BOTH(COVGRAM_EQ, 0)
+    else if (fam == COVGRAM_RQ) CG_SUM_BOTH(COVGRAM_RQ, 0)
+    else if (fam == COVGRAM_CAUCHY) CG_SUM_BOTH(COVGRAM_CAUCHY, 0)
+    else CG_SUM_BOTH(COVGRAM_IMQ, 0)
+#undef CG_SUM_BOTH
+}
+
+// The profile on the 16 entries a lane holds of one tile: s -> k(s), in place.  Everything uniform over the launch (MaternP's order, the Power
+// wrapper, a Sum's families) is decided ONCE per tile: inside a per-entry loop hipcc kept those tests as scalar branches around every entry.
+// ORD: MaternP's order as a compile-time constant (1 .. 3; the host picks the instance), 0 = decided here by a wave-uniform switch
+template <int FAM, int ORD = 0, typename KP>
+__device__ __forceinline__ void mfma_profile_block(f32x16& D, const KP& kp) {
+    f32x2 S[2][PNP];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) S[v / PNP][v % PNP] = (f32x2){D[2 * v], D[2 * v + 1]};
+    if constexpr (FAM == FAM_SUM_ISO) {
+        f32x2 K[2][PNP];
+        mfma_sum_term<0>(S, K, kp);
+        mfma_sum_term<1>(S, K, kp);
+        if constexpr (ORD == 3) mfma_sum_term<2>(S, K, kp);        // (a Sum's ORD is its number of terms: 2 or 3; 0 = decided here)
+        else if constexpr (ORD == 0) { if (kp.nterms > 2) mfma_sum_term<2>(S, K, kp); }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { D[2 * v] = K[v / PNP][v % PNP][0]; D[2 * v + 1] = K[v / PNP][v % PNP][1]; }
+        return;
+    } else if constexpr (FAM == COVGRAM_MATERNP && ORD >= 1 && ORD <= 3) {
+        mfma_profile_pairs<FAM, ORD>(S[0], kp); mfma_profile_pairs<FAM, ORD>(S[1], kp);
+    } else if constexpr (FAM == COVGRAM_MATERNP) {
+        const int p = kp.p;
+        if (p == 2) { mfma_profile_pairs<FAM, 2>(S[0], kp); mfma_profile_pairs<FAM, 2>(S[1], kp); }
+        else if (p == 1) { mfma_profile_pairs<FAM, 1>(S[0], kp); mfma_profile_pairs<FAM, 1>(S[1], kp); }
+        else if (p == 3) { mfma_profile_pairs<FAM, 3>(S[0], kp); mfma_profile_pairs<FAM, 3>(S[1], kp); }
+        else { mfma_profile_pairs<FAM, 0>(S[0], kp); mfma_profile_pairs<FAM, 0>(S[1], kp); }
+    } else {
+        mfma_profile_pairs<FAM, 0>(S[0], kp); mfma_profile_pairs<FAM, 0>(S[1], kp);
+    }
+    if constexpr (ORD == 0) if (kp.power != 1) {           // (instances with a compile-time order serve power == 1 only: the host's dispatch)
+        const int pw = kp.power;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { const f32x2 b = S[v / PNP][v % PNP]; f32x2 r = b; for (int i = 1; i < pw; ++i) r = r * b; S[v / PNP][v % PNP] = r; }
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { D[2 * v] = S[v / PNP][v % PNP][0]; D[2 * v + 1] = S[v / PNP][v % PNP][1]; }
+}
+// the weighted sums behind it as v_pk_fma_f32 on register pairs: with one or two MFMAs per tile (beside a RUNNING MFMA a packed fma costs more than
+// the two it replaces, tools/pkfma_probe.hip) and for the profiles whose VALU work dwarfs the matrix pipe's at any d
+template <int FAM, int K2> constexpr bool mfma_pk_sums = K2 <= 2 || FAM == COVGRAM_MATERNP || FAM == COVGRAM_RQ || FAM == FAM_SUM_ISO;
 
 // EQ and MaternP take the dense path's FOLDED parameter block here too (log2(e) and sqrt(2p+1) in the coordinate pre-scale,
 // rescaled tables: exp2 of the MFMA result, no multiplications in front) — the host passes make_host_kernel(.., for_gradient = false)
 
 // LDS = 0: one wave per workgroup, its own fragment loads; LDS = 2: four waves on consecutive row tiles share every column tile
 // through LDS, one tile per stage, its K2 fragment slices fetched by the waves in turn (as dense_mfma_eq_kernel<.., 4, 2>)
-template <int FAM, int K2, int RT, int NR, int LDS = 0>
+template <int FAM, int K2, int RT, int NR, int LDS = 0, int ORD = 0>
 __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
@@ -214,13 +364,14 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
 
     const int64_t T0 = (int64_t)blockIdx.y * tchunk;
     const int64_t T1 = (T0 + tchunk < ntile) ? (T0 + tchunk) : ntile;
-    float acc[RT][NR][16];
+    constexpr bool PKS = mfma_pk_sums<FAM, K2>;                  // the weighted sums as v_pk_fma_f32 on register pairs
+    f32x2 acc[RT][NR][8];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < NR; ++c)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.0f;
+            for (int v = 0; v < 8; ++v) acc[r][c][v] = (f32x2){0.0f, 0.0f};
 
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
     const float* __restrict__ wbase = W + T0 * (NR * 32);
@@ -244,16 +395,17 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
                 for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v];
                 expr_value_block<float, ISO, 16>(sv, kp, kv);
 #pragma unroll
-                for (int v = 0; v < 16; ++v)
-#pragma unroll
-                    for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], kv[v], acc[r][c][v]);
+                for (int v = 0; v < 16; ++v) D[v] = kv[v];
             } else {
-            mfma_profile_block<FAM>(D, kp);
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-#pragma unroll
-                for (int c = 0; c < NR; ++c) acc[r][c][v] = __builtin_fmaf(w[c], D[v], acc[r][c][v]);
+                mfma_profile_block<FAM, ORD>(D, kp);
             }
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    if constexpr (PKS) acc[r][c][v] = pk_fma(pk_splat(w[c]), (f32x2){D[2 * v], D[2 * v + 1]}, acc[r][c][v]);
+                    else { acc[r][c][v][0] = __builtin_fmaf(w[c], D[2 * v], acc[r][c][v][0]); acc[r][c][v][1] = __builtin_fmaf(w[c], D[2 * v + 1], acc[r][c][v][1]); }
+                }
         }
     };
     if constexpr (LDS == 2) {
@@ -323,7 +475,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
             float tot = 0.0f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                float s = acc[r][c][v];
+                float s = acc[r][c][v >> 1][v & 1];
                 s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
                 tot = (vsel == v) ? s : tot;
             }
@@ -415,14 +567,9 @@ __global__ __launch_bounds__(64) void dense_mfma_mrhs_kernel(const float* __rest
             for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v];
             expr_value_block<float, ISO, 16>(sv, kp, kv);
         } else {
+            mfma_profile_block<FAM>(D, kp);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float s = D[v];
-                if constexpr (FAM == COVGRAM_MATERNP) s = fmaxf(s, 0.0f);
-                float k1 = Phi<FAM, float, mfma_folded<FAM>>::eval(s, kp);
-                if (kp.power != 1) k1 = ipow(k1, kp.power);
-                kv[v] = k1;
-            }
+            for (int v = 0; v < 16; ++v) kv[v] = D[v];
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -471,8 +618,14 @@ template <int FAM> struct SymParamsOf { using type = typename ParamsOf<FAM, floa
 template <> struct SymParamsOf<FAM_EQFAST> { using type = KParams<float>; };
 template <> struct SymParamsOf<FAM_EQFAST_H> { using type = KParams<float>; };
 
-template <int FAM, int K2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_mfma_sym_kernel(
+// NW = waves per workgroup = row tiles per panel: 8 (two workgroups per CU = 4 waves per SIMD, 128 VGPRs) or 4 (three workgroups per CU = 3 waves
+// per SIMD, 168 VGPRs: the profiles whose tile body needs them — mfma_sym_nw; the tile body itself runs fastest at 3 waves per SIMD,
+// profiles/r05_tile_body_probe.txt).  NOT 6: a workgroup's waves go round the CU's four SIMDs, so two 6-wave workgroups load them 4 / 2 / 4 / 2 and
+// the barriers pace every wave by the fullest SIMD (measured: MaternP(2) at C2 size 3.35 ms, VALU active 53 % of the time).
+// ORD: MaternP's order at compile time (mfma_profile_block)
+template <int FAM> constexpr int mfma_sym_nw = (FAM == COVGRAM_MATERNP || FAM == COVGRAM_RQ || FAM == FAM_SUM_ISO) ? 4 : 8;
+template <int FAM, int K2, int NW_ = 8, int ORD = 0>
+__global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ == 8 ? 4 : 3, NW_ == 8 ? 4 : 3))) void dense_mfma_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
     int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp,
@@ -484,11 +637,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
     constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
-    constexpr bool PK = K2 <= 2;                // packed fmas for the weighted sums (see process below)
+    constexpr bool PK = K2 <= 2 || mfma_pk_sums<FAM, K2>;   // packed fmas for the weighted sums (see process below)
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
     // keeps 4 waves per SIMD); stages of ST = 4 column tiles, fetched by waves 0..3
-    constexpr int NW = 8, ST = 4;
+    constexpr int NW = NW_, ST = 4;
     // Column chunks sit at ABSOLUTE multiples of tchunk (the panel's first one is cut at its own first tile 8 p), so the
     // workgroups in flight — consecutive panels of the same chunk index — walk the same ~1 MB of fragments, which stays in L2
     // (chunks relative to 8 p made every panel's range different: 620 MB of L2 misses per C2 launch instead of ~40).
@@ -548,9 +701,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             u[v] = wt(ri) * keep;
         }
     }
-    float acc[16];
+    // accumulators and row weights as register PAIRS from the start (round 5): as 16 scalars re-paired around every packed fma they were copied
+    // between register sets at every transition between the four copies of the stage loop (16-32 v_mov per stage)
+    f32x2 acc2[8], u2[8];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    for (int v = 0; v < 8; ++v) { acc2[v] = (f32x2){0.0f, 0.0f}; u2[v] = (f32x2){u[2 * v], u[2 * v + 1]}; }
 
     const uint4* __restrict__ pbase = PB + (T0 * K2) * 64;
     __shared__ uint4 sfA[ST][K2][64], sfB[ST][K2][64];
@@ -578,7 +733,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if constexpr (FAST) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]);
-        } else mfma_profile_block<FAM>(D, kp);
+        } else mfma_profile_block<FAM, ORD>(D, kp);
         }
         const float wr = (!MASKED || J >= I0) ? w : 0.0f;          // wave-uniform masks: only inside the diagonal block
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
@@ -586,30 +741,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // two fmas per instruction (v_pk_fma_f32 on register pairs): the same sums in the same order as below.  Beside a RUNNING MFMA a packed fma
             // costs more than the two it replaces (tools/pkfma_probe.hip: 32 of them +260 cycles next to back-to-back MFMAs), so only the
             // kernels with one or two MFMAs per tile take it (general kernel at d = 3: 1.44 -> 1.33 ms; four MFMAs per tile: +2-3 %)
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f};
 #pragma unroll
-            for (int v = 0; v < 16; v += 4) {
-                f32x2 a01 = {acc[v], acc[v + 1]}, a23 = {acc[v + 2], acc[v + 3]};
-                const f32x2 d01 = {D[v], D[v + 1]}, d23 = {D[v + 2], D[v + 3]};
-                a01 = __builtin_elementwise_fma((f32x2){wr, wr}, d01, a01);
-                a23 = __builtin_elementwise_fma((f32x2){wr, wr}, d23, a23);
-                acc[v] = a01[0]; acc[v + 1] = a01[1]; acc[v + 2] = a23[0]; acc[v + 3] = a23[1];
-                c01 = __builtin_elementwise_fma((f32x2){u[v], u[v + 1]}, d01, c01);
-                c23 = __builtin_elementwise_fma((f32x2){u[v + 2], u[v + 3]}, d23, c23);
+            for (int v = 0; v < 8; v += 2) {
+                const f32x2 d01 = {D[2 * v], D[2 * v + 1]}, d23 = {D[2 * v + 2], D[2 * v + 3]};
+                acc2[v] = pk_fma((f32x2){wr, wr}, d01, acc2[v]);
+                acc2[v + 1] = pk_fma((f32x2){wr, wr}, d23, acc2[v + 1]);
+                c01 = pk_fma(u2[v], d01, c01);
+                c23 = pk_fma(u2[v + 1], d23, c23);
             }
             c0 = c01[0]; c1 = c01[1]; c2 = c23[0]; c3 = c23[1];
         } else {
 #pragma unroll
-        for (int v = 0; v < 16; v += 4) {
-            acc[v] = __builtin_fmaf(wr, D[v], acc[v]);
-            acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);
-            acc[v + 2] = __builtin_fmaf(wr, D[v + 2], acc[v + 2]);
-            acc[v + 3] = __builtin_fmaf(wr, D[v + 3], acc[v + 3]);
-            c0 = __builtin_fmaf(u[v], D[v], c0);
-            c1 = __builtin_fmaf(u[v + 1], D[v + 1], c1);
-            c2 = __builtin_fmaf(u[v + 2], D[v + 2], c2);
-            c3 = __builtin_fmaf(u[v + 3], D[v + 3], c3);
+        for (int v = 0; v < 8; v += 2) {
+            acc2[v][0] = __builtin_fmaf(wr, D[2 * v], acc2[v][0]);
+            acc2[v][1] = __builtin_fmaf(wr, D[2 * v + 1], acc2[v][1]);
+            acc2[v + 1][0] = __builtin_fmaf(wr, D[2 * v + 2], acc2[v + 1][0]);
+            acc2[v + 1][1] = __builtin_fmaf(wr, D[2 * v + 3], acc2[v + 1][1]);
+            c0 = __builtin_fmaf(u2[v][0], D[2 * v], c0);
+            c1 = __builtin_fmaf(u2[v][1], D[2 * v + 1], c1);
+            c2 = __builtin_fmaf(u2[v + 1][0], D[2 * v + 2], c2);
+            c3 = __builtin_fmaf(u2[v + 1][1], D[2 * v + 3], c3);
         }
         }
         cpart = (!MASKED || J > I0) ? (c0 + c1) + (c2 + c3) : 0.0f;   // this half-wave's 16 rows; the halves meet in the flush
@@ -622,7 +774,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
             gw = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);   /* tiles past the chunk: weight 0 */ \
         }
+    /* the one-pass Sum takes the stage's tiles one at a time: a short loop body the register allocator handles without scratch (two at a time: 36-52 B) */ \
 #define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
+        if constexpr (FAM == FAM_SUM_ISO) {                                                     \
+            _Pragma("unroll 1") for (int k = 0; k < ST; ++k) {                                  \
+                Frag f0[K2];                                                                    \
+                _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];      \
+                const float w0 = SW[k][t];                                                      \
+                float cp0;                                                                      \
+                process(std::integral_constant<bool, M_>(), f0, w0, T0 + (int64_t)(st_) * ST + k, cp0); \
+                CS[wv][k][l] = cp0;                                                             \
+            }                                                                                   \
+        } else                                                                                  \
         _Pragma("unroll 1") for (int k = 0; k < ST; k += 2) {                                   \
             Frag f0[K2], f1[K2];                                                                \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];          \
@@ -674,7 +837,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float tot = 0.0f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        float s = acc[v];
+        float s = acc2[v >> 1][v & 1];
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
         tot = (vsel == v) ? s : tot;
     }
@@ -794,6 +957,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }                                                                                   \
             const float wr = (J >= I0) ? w : 0.0f;                                              \
             float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;                                   \
+            if constexpr (mfma_pk_sums<FAM, K2>) {                                              \
+                f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f};                                   \
+                _Pragma("unroll") for (int v = 0; v < 16; v += 4) {                             \
+                    f32x2 a01 = {acc[v], acc[v + 1]}, a23 = {acc[v + 2], acc[v + 3]};           \
+                    const f32x2 d01 = {D[v], D[v + 1]}, d23 = {D[v + 2], D[v + 3]};             \
+                    a01 = pk_fma(pk_splat(wr), d01, a01);                                       \
+                    a23 = pk_fma(pk_splat(wr), d23, a23);                                       \
+                    acc[v] = a01[0]; acc[v + 1] = a01[1]; acc[v + 2] = a23[0]; acc[v + 3] = a23[1]; \
+                    c01 = pk_fma((f32x2){u[v], u[v + 1]}, d01, c01);                            \
+                    c23 = pk_fma((f32x2){u[v + 2], u[v + 3]}, d23, c23);                        \
+                }                                                                               \
+                c0 = c01[0]; c1 = c01[1]; c2 = c23[0]; c3 = c23[1];                             \
+            } else                                                                              \
             _Pragma("unroll") for (int v = 0; v < 16; v += 4) {                                 \
                 acc[v] = __builtin_fmaf(wr, D[v], acc[v]);                                      \
                 acc[v + 1] = __builtin_fmaf(wr, D[v + 1], acc[v + 1]);                          \
@@ -867,33 +1043,72 @@ struct MfmaArgs {
 };
 
 // returns the resident blocks per CU of the instance when `query` is set (no launch), COVGRAM_OK / error otherwise
+template <int FAM, int K2, int RT, int NR, int ORD>
+static void mfma_gen_launch(const MfmaArgs& a) {
+    if (a.lds)
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2, ORD>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
+                           a.PB, a.W, a.ntile, a.out, a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn,
+                           make_params<FAM, float>(*a.hk));
+    else
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, ORD>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
+                           a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
+}
 template <int FAM, int K2, int RT, int NR>
 static int mfma_gen_one(const MfmaArgs& a, bool query) {
     if (query) {
         static int cached = 0;
         if (!cached) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_mfma_gen_kernel<FAM, K2, RT, NR>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            constexpr int QORD = (NR == 1 && (FAM == COVGRAM_MATERNP || FAM == FAM_SUM_ISO)) ? 2 : 0;   // the instance most launches take
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, QORD>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
             cached = nb;
         }
         return cached;
     }
-    if (a.lds)
-        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
-                           a.PB, a.W, a.ntile, a.out, a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn,
-                           make_params<FAM, float>(*a.hk));
-    else
-        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
-                           a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
+    // MaternP(1), MaternP(2) (Matern 3/2, 5/2) with one right-hand side: the order is a compile-time constant of the instance; a Sum: its number of terms
+    if constexpr (FAM == COVGRAM_MATERNP && NR == 1) {
+        if (a.hk->k.p == 2 && a.hk->k.power == 1) { mfma_gen_launch<FAM, K2, RT, NR, 2>(a); return COVGRAM_OK; }
+        if (a.hk->k.p == 1 && a.hk->k.power == 1) { mfma_gen_launch<FAM, K2, RT, NR, 1>(a); return COVGRAM_OK; }
+    }
+    if constexpr (FAM == FAM_SUM_ISO && NR == 1) {
+        if (a.hk->nterms == 2) mfma_gen_launch<FAM, K2, RT, NR, 2>(a); else mfma_gen_launch<FAM, K2, RT, NR, 3>(a);
+        return COVGRAM_OK;
+    }
+    mfma_gen_launch<FAM, K2, RT, NR, 0>(a);
     return COVGRAM_OK;
 }
 
+template <int FAM, int K2, int ORD>
+static void mfma_sym_narrow(const MfmaArgs& a) {
+    constexpr int NW = mfma_sym_nw<FAM>;
+    hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2, NW, ORD>), a.grid, dim3(64 * NW), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                       (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+}
+// which symmetric form serves (family, K2): the 8- or 6-wave panels with stages of four tiles (narrow), or four waves and one tile per stage
+// (wide).  The one-pass Sum takes the wide form from K2 = 3 on (its 6-wave instances spill 12-40 B at K2 = 3, 4) and has no instance beyond K2 = 8.
+template <int FAM> constexpr int mfma_sym_narrow_maxk2 = FAM == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
+inline int mfma_sym_tiles_per_panel(int launcher_family, int k2) {
+    const bool heavy = launcher_family == COVGRAM_MATERNP || launcher_family == COVGRAM_RQ || launcher_family == FAM_SUM_ISO;
+    const int narrow_max = launcher_family == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
+    return (k2 > narrow_max || heavy) ? 4 : 8;
+}
 template <int FAM, int K2>
 static int mfma_sym_one(const MfmaArgs& a) {
-    if constexpr (K2 <= MFMA_NARROW_MAXK2)
-        hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2>), a.grid, dim3(512), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
-                           (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
-    else
+    if constexpr (FAM == FAM_SUM_ISO && K2 > 8) {
+        set_error("dense_mfma_sym: the one-pass Sum has no instance at K2 = %d", K2); return COVGRAM_EUNSUPPORTED;
+    } else
+    if constexpr (K2 <= mfma_sym_narrow_maxk2<FAM>) {
+        if constexpr (FAM == COVGRAM_MATERNP) {            // the order is a compile-time constant of the instance
+            switch (a.hk->k.power == 1 ? a.hk->k.p : 0) {
+                case 1: mfma_sym_narrow<FAM, K2, 1>(a); break;
+                case 2: mfma_sym_narrow<FAM, K2, 2>(a); break;
+                case 3: mfma_sym_narrow<FAM, K2, 3>(a); break;
+                default: mfma_sym_narrow<FAM, K2, 0>(a); break;
+            }
+        } else if constexpr (FAM == FAM_SUM_ISO) {         // ... and so is a Sum's number of terms
+            if (a.hk->nterms == 2) mfma_sym_narrow<FAM, K2, 2>(a); else mfma_sym_narrow<FAM, K2, 3>(a);
+        } else mfma_sym_narrow<FAM, K2, 0>(a);
+    } else
         hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
                            a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
     return COVGRAM_OK;

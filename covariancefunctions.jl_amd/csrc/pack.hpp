@@ -55,7 +55,10 @@ __device__ __forceinline__ T slab_load(const T* p) { return __hip_atomic_load(p,
 
 __device__ __forceinline__ bool last_arrival(unsigned* __restrict__ ticket, unsigned expected) {
     __shared__ unsigned flag;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's write-through slab stores have been acknowledged
+    // EVERY wave drains its own write-through (sc1) slab stores before the barrier the ticket is taken behind.  Written as inline asm:
+    // a workgroup-scope release fence lowers to an lgkmcnt wait only on gfx950 (no vmcnt), and the compiler may drop a builtin wait it
+    // believes redundant (MI355X guide, "Compiler hazard").  tools/check_isa.py asserts the wait sits in front of the barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -17,6 +17,18 @@ elif which == "densegen":
     cg.set_option("mfma_sym", 0)
     G = cg.gramian(cg.EQ(), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
     for _ in range(K): G.mul_(y, a)
+elif which in ("matern", "materngen", "f2", "f2gen", "maternshard"):   # round 5: packed-profile matrix-core kernels and the one-pass Sum at the contract size
+    n = 131072
+    Xh = rng.standard_normal((n, 3)).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    k = cg.MaternP(2) if which.startswith("matern") else 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
+    if which.endswith("gen"): cg.set_option("mfma_sym", 0); cg.set_option("dense_variant", 2)
+    if which == "maternshard":
+        cg.set_option("dense_variant", 2)
+        G = cg.gramian(k, X[:16384].contiguous(), X); y = torch.empty(16384, dtype=torch.float32, device="cuda")
+    else:
+        G = cg.gramian(k, X); y = torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(K): G.mul_(y, a)
 elif which == "shard8":
     n, per = 524288, 65536
     X = torch.from_numpy(np.random.default_rng(0xC0F + 2).standard_normal((n, 8)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
