@@ -1085,7 +1085,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         // the lane-per-row kernel can sum its own split-J slab (last-arriving workgroup of each 64-row block, fixed order: pack.hpp) — only
         // on request: its column splits are fine (64 at C1's size), and 64 tickets on one counter plus the uncached re-read cost more than
         // the launch they save (profiles/r04_inkernel_reduce_ab.txt: C1 27.1 -> 39.0 us, n = 16384 259 -> 262)
-        const bool ikr = jsplit > 1 && !wide && ctx->inkernel_reduce == 1;
+        const bool ikr = !wide && inkernel_reduce_on(ctx, false, n, jsplit);
         ctx->last_inkernel_reduce = ikr ? 1 : 0;
         if (ikr) { rc = tickets_reserve(ctx, (size_t)rowblocks, &da.tickets); if (rc) return rc; da.yfinal = y_c; }
         auto* tm = timer_next(ctx);

@@ -258,7 +258,10 @@ struct covgram_ctx {
     int64_t last_dense_sym = 0;
     int64_t dense_bcast = -1;    // fp64 dense MVM of wide points on dense_bcast_kernel (expanded distance, v_fmac_f64_dpp): -1 = from padded d = 16 inside the radius gate, 0 never, 1 whenever compiled (d >= 8)
     int64_t last_dense_bcast = 0;
-    int64_t inkernel_reduce = -1; // split-J partials of the dense kernels summed by the last-arriving workgroup of each row block (-1 / 1: yes, 0: the separate reduce launch)
+    // split-J partials summed by the last-arriving workgroup of each row block instead of a reduce launch (pack.hpp: last_arrival).  ONE rule
+    // (inkernel_reduce_on below, used by both call sites; include/covgram.h says the same): 1 = wherever the column split is > 1 (lane-per-row
+    // and matrix-core EQ kernels), 0 = never, -1 = the matrix-core EQ kernel up to n = 4096 only (where the whole MVM is launch latency)
+    int64_t inkernel_reduce = -1;
     int64_t last_inkernel_reduce = 0;
     unsigned* tickets = nullptr;  // one arrival counter per row block, zero between launches (pack.hpp: last_arrival)
     size_t tickets_cap = 0;
@@ -326,6 +329,10 @@ struct covgram_points {
 
 namespace covgram {
 
+inline bool inkernel_reduce_on(const covgram_ctx* ctx, bool mfma_eq_kernel, int64_t n, int64_t jsplit) {
+    if (jsplit <= 1 || ctx->inkernel_reduce == 0) return false;
+    return ctx->inkernel_reduce == 1 || (mfma_eq_kernel && n <= 4096);
+}
 int ws_reserve(covgram_ctx* ctx, int slot, size_t bytes, void** out);
 // >= count zeroed arrival counters (grown stream-ordered; they return to zero by themselves after every launch that uses them)
 int tickets_reserve(covgram_ctx* ctx, size_t count, unsigned** out);

@@ -599,8 +599,10 @@ static int eq_fragments(covgram_ctx* ctx, const covgram_points* Y, int K2, float
     if (!hit) {
         CG_REQUIRE(victim != nullptr, COVGRAM_EUNSUPPORTED, "all %d fragment slots of this point set are pinned by captured graphs (one per (lengthscale, d) used "
                    "inside a capture): destroy the handle, or keep to %d lengthscales per point set in graphs", covgram_points::FRAG_SLOTS, covgram_points::FRAG_SLOTS);
-        CG_REQUIRE(!capturing || (victim->ptr && victim->bytes == total), COVGRAM_EUNSUPPORTED,
-                   "the fragments of this (point set, lengthscale) must be packed once OUTSIDE stream capture (run one eager MVM first): packing allocates");
+        // ANY miss during capture is refused: a re-pack captured into the graph would leave the slot's key naming fragments that do not exist
+        // until the first replay (an eager MVM in between would read the previous lengthscale's), and it would pin a slot per captured lengthscale
+        CG_REQUIRE(!capturing, COVGRAM_EUNSUPPORTED,
+                   "the fragments of this (point set, lengthscale) must be packed once OUTSIDE stream capture: run one eager MVM with this lengthscale first");
         if (victim->ptr && victim->bytes != total) {   // only when the handle is re-used at another K2: off the steady-state path
             CG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(victim->ptr); victim->ptr = nullptr;
         }
@@ -652,7 +654,10 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // SLOWER than the pack launch: the product stood right behind its two loads and so behind the LDS-DMA the wave had just issued — one counter.
     // Deferred: C2-shaped 1359 -> 1340 us, a 16384-row shard 190.1 -> 186.5, n = 16384 35.1 -> 33.2, n = 2048 12.1 -> 10.8;
     // profiles/r04_fuse_w_ab.txt.)  Option "mfma_fuse_w" = 0 restores the pack launch; results are bit-identical either way.
-    const bool fuse_w = ctx->mfma_fuse_w != 0;
+    // ... unless a and y overlap (an in-place MVM, y == a): the workgroups of a final-store or ticketed launch write y while others still read
+    // a — the pack launch copies the weights first, as every dense path did before round 4 (include/covgram.h: aliasing)
+    const bool overlap = (const char*)a < (const char*)(y + n) && (const char*)y < (const char*)(a + m);
+    const bool fuse_w = ctx->mfma_fuse_w != 0 && !overlap;
     const float* W = a;
     if (!fuse_w) {
         void* Wp;
@@ -733,7 +738,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // 16384 37.9 -> 37.2, rank 0 of 8's shard of C2 214.4 -> 213.5, of 16 116.3 -> 115.0: it pays where the whole MVM is launch latency
     // and is noise elsewhere, so the automatic rule takes it up to n = 4096 (option "inkernel_reduce" = 1 / 0 forces it on / off)
     unsigned* tickets = nullptr;
-    const bool ikr = js > 1 && (ctx->inkernel_reduce == 1 || (ctx->inkernel_reduce < 0 && n <= 4096));
+    const bool ikr = inkernel_reduce_on(ctx, true, n, js);
     ctx->last_inkernel_reduce = ikr ? 1 : 0;
     if (ikr) { rc = tickets_reserve(ctx, (size_t)rowtiles, &tickets); if (rc) return rc; }
     auto* tm = timer_next(ctx);

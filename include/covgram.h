@@ -151,6 +151,9 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * Cauchy / IMQ / Dot) while its column-sum slab of n^2 / 8 bytes stays within 1 GiB, 0 = never, 1 = always, up to a 2 GiB slab — the
  * slab lives in the ctx's workspace until the ctx is destroyed: 512 MiB at n = 65536, once per ctx),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
+ * "sum_fused" (fp32 Sum of two or three single-profile isotropic terms — EQ, RQ, Cauchy, IMQ, MaternP(1..3), no Power wrapper — in ONE pass of
+ * the matrix-core kernels, every term evaluated on the pair's shared distance as the reference does, src/algebra.jl:27-47: -1 = where it
+ * measured faster than one MVM per term (three terms; two terms on two point sets), 0 = never, 1 = wherever the one-pass kernels exist),
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
  * gamma^2 R^2 <= 1000 of their common centre, 0 = never, 1 = always),
@@ -173,7 +176,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_mfma_f16" (1: the last general matrix-core EQ MVM ran the fp16 two-way split), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_sum_fused" (1: the last covgram_mvm ran a Sum on the one-pass kernels), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_mfma_f16" (1: the last general matrix-core EQ MVM ran the fp16 two-way split), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);
@@ -193,7 +196,10 @@ int covgram_points_destroy(covgram_points* pts);
 int covgram_points_info(const covgram_points* pts, int64_t* n, int32_t* d, int32_t* dtype);
 
 /* y <- alpha * G(k; X, Y) * a + beta * y.   G is n×m (n = |X|, m = |Y|); a is m×nrhs (lda >= m),
- * y is n×nrhs (ldy >= n), column-major; dtype is that of the points.  loc applies to a and y. */
+ * y is n×nrhs (ldy >= n), column-major; dtype is that of the points.  loc applies to a and y.
+ * Aliasing: y may be a itself (an in-place MVM with n == m: every dense path reads the weights from its own packed copy, or — the general
+ * matrix-core EQ kernel, which reads a directly — falls back to the pack launch when the two ranges overlap); partially overlapping
+ * columns of a multi-column a / y are not supported. */
 int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y,
                 const void* a, int64_t lda, void* y, int64_t ldy, int32_t nrhs, double alpha, double beta,
                 int32_t loc);

@@ -5,6 +5,7 @@ import ctypes as C
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -338,3 +339,18 @@ def test_shard_bounds(cg):
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) == (n + world - 1) // world
+
+
+def test_post_build_isa_lint():
+    """tools/check_isa.py lint (hipcc -S, no GPU): every ticketed kernel drains vmcnt in front of its barrier, the inline-asm
+    v_fmac_f64_dpp sites are clear of the VALU-def / EXEC hazards the compiler cannot see, and the packed-profile / one-pass
+    Sum matrix-core kernels use no scratch."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py"), "lint"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok:") >= 6, r.stdout

@@ -115,6 +115,13 @@ def report(tu: str, extra: list[str], filt: str | None) -> None:
 
 def lint() -> int:
     bad = 0
+    # every translation unit the checks read, compiled side by side (hipcc is single-threaded per TU)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [("dense_mfma.hip", tuple(MFMA)), ("lowrank.hip", ()), ("grad_fam.hip", ("-DCOVGRAM_FAM=0",)), ("dense_fam.hip", ("-DCOVGRAM_FAM=0",)),
+            ("mfma_fam.hip", tuple(MFMA + ["-DCOVGRAM_FAM=6"])), ("mfma_fam.hip", tuple(MFMA + ["-DCOVGRAM_FAM=13"]))]
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        cache = dict(zip(jobs, ex.map(lambda j: compile_asm(j[0], list(j[1])), jobs)))
+    compiled = lambda tu, extra: cache[(tu, tuple(extra))]
 
     def fail(msg):
         nonlocal bad
@@ -123,7 +130,7 @@ def lint() -> int:
 
     # 1. ticketed kernels: vmcnt(0) in front of the barrier in front of the ticket's atomic add
     for tu, extra in (("dense_mfma.hip", MFMA), ("lowrank.hip", [])):
-        ks = kernels(compile_asm(tu, extra))
+        ks = kernels(compiled(tu, extra))
         dm = demangle(list(ks))
         seen = 0
         for name, k in ks.items():
@@ -158,7 +165,7 @@ def lint() -> int:
     # 2. DPP fmac hazards in the broadcast kernels
     VALU_DEF = re.compile(r"^v_\w+\s+(v\[\d+:\d+\]|v\d+)")
     for fam, tu in ((0, "grad_fam.hip"), (0, "dense_fam.hip")):
-        ks = kernels(compile_asm(tu, [f"-DCOVGRAM_FAM={fam}"]))
+        ks = kernels(compiled(tu, [f"-DCOVGRAM_FAM={fam}"]))
         dm = demangle(list(ks))
         nd = 0
         for name, k in ks.items():
@@ -200,7 +207,7 @@ def lint() -> int:
 
     # 3. zero scratch in the packed-profile / one-pass Sum matrix-core kernels
     for fam in (6, 13):
-        ks = kernels(compile_asm("mfma_fam.hip", MFMA + [f"-DCOVGRAM_FAM={fam}"]))
+        ks = kernels(compiled("mfma_fam.hip", MFMA + [f"-DCOVGRAM_FAM={fam}"]))
         dm = demangle(list(ks))
         n = 0
         for name, k in ks.items():
