@@ -450,7 +450,7 @@ def main():
     torch.cuda.synchronize()
     cg.set_option("time_kernels", 1)
     collective = world > 1 or G.force_collective
-    G.timing = collective                                    # events around the local kernel and around the one collective
+    G.timing = False                                         # the timed steps take the product route: ONE library call per MVM (kernel + collective on the ctx stream)
     step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
@@ -465,9 +465,36 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = [e0.elapsed_time(e1) for e0, e1 in step_ev]
     kernel_ms, launches = cg.kernel_time()
-    loc_ms, col_ms, nsplit = G.timing_ms() if collective else (0.0, 0.0, 0)
-    G.timing = False
     cg.set_option("time_kernels", 0)
+    # where a step's time goes — AFTER the timed region, diagnostic: events around the local kernel and around the one collective, for the
+    # route the timed steps took (C ABI: the library's own ncclAllGather on its stream) and for torch.distributed's (its own stream + two event hops)
+    loc_ms, col_ms, nsplit, col_by_route = 0.0, 0.0, 0, None
+    if collective:
+        G.timing = True
+        for _ in range(3):
+            step()
+        G.timing_ms()
+        for _ in range(10):
+            step()
+        loc_ms, col_ms, nsplit = G.timing_ms()
+        G.timing = False
+        col_by_route = {"c_abi" if getattr(G, "_abi", False) else "torch_distributed": col_ms / max(nsplit, 1)}
+        if getattr(G, "_abi", False):
+            os.environ["COVGRAM_ABI_COLLECTIVE"] = "0"
+            try:
+                Gt = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+                bt = torch.empty_like(b)
+                Gt.timing = True
+                for _ in range(3):
+                    Gt.matmul(a, out=bt)
+                Gt.timing_ms()
+                for _ in range(10):
+                    Gt.matmul(a, out=bt)
+                _, ct, nt = Gt.timing_ms()
+                col_by_route["torch_distributed"] = ct / max(nt, 1)
+                del Gt, bt
+            finally:
+                os.environ.pop("COVGRAM_ABI_COLLECTIVE", None)
     dense_path = cg.get_info("last_dense_path")
     sym_path = cg.get_info("last_mfma_sym") == 1
     f16_split = dense_path == 2 and cg.get_info("last_mfma_f16") == 1      # the matrix-core EQ kernels' fp16 two-way split of the coordinates (round 4)
@@ -767,8 +794,12 @@ def main():
             line["rehearsal"] = "COVGRAM_BENCH_REHEARSAL=1: all ranks on GPU 0, collectives over gloo through host memory — a code-path rehearsal, NOT a measurement"
         if per_rank is not None:
             line["per_rank"] = per_rank
-            line["per_rank_note"] = ("kernel_ms: the rank's dominant kernel by HIP events on the launch stream; local_ms / collective_ms: events on the same stream "
-                                     "around the shard's MVM and around the ONE collective (RCCL runs it on its own stream between two event waits of this one)")
+            line["per_rank_note"] = ("kernel_ms: the rank's dominant kernel by HIP events on the launch stream over the K timed steps; local_ms / collective_ms: 10 steps "
+                                     "AFTER the timed region with events around the shard's MVM and around the ONE collective (the timed steps make one library call per MVM)")
+        if col_by_route is not None:
+            line["collective_route"] = ("C ABI: covgram_mvm_sharded = shard kernel + ncclAllGather enqueued on the ctx stream (include/covgram.h)" if getattr(G, "_abi", False)
+                                        else "torch.distributed all_gather_into_tensor")
+            line["collective_ms_by_route"] = col_by_route
         if t1_ms is not None:
             line["single_gpu_ms"] = t1_ms
             line["ideal_ms"] = t1_ms / world

@@ -22,7 +22,8 @@ F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE, ENOMEM = 0, -1, -2, -3, -4, -5
 MATERNP_MAX_P = 8
-ABI_VERSION = 112   # COVGRAM_VERSION of the include/covgram.h these prototypes mirror
+COMM_ID_BYTES = 128
+ABI_VERSION = 113   # COVGRAM_VERSION of the include/covgram.h these prototypes mirror
 
 
 class covgram_kernel(C.Structure):
@@ -101,6 +102,14 @@ PROTOTYPES = {
     "covgram_valgrad_mvm": (C.c_int, [_P, _KP, _P, _P, _P, _I64, _P, _I64, _I32, _D, _D, _I32]),
     "covgram_mvm_sym_supported": (C.c_int, [_P, _KP, _P, _I32, C.POINTER(C.c_int32)]),
     "covgram_mvm_sym_partial": (C.c_int, [_P, _KP, _P, _P, _P, _I32, _I32]),
+    "covgram_comm_unique_id": (C.c_int, [_P, _I64]),
+    "covgram_comm_create": (C.c_int, [_P, _P, _I32, _I32]),
+    "covgram_comm_destroy": (C.c_int, [_P]),
+    "covgram_comm_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "covgram_comm_all_gather": (C.c_int, [_P, _P, _P, _I64, _I32]),
+    "covgram_comm_all_reduce_sum": (C.c_int, [_P, _P, _I64, _I32]),
+    "covgram_mvm_sharded": (C.c_int, [_P, _KP, _P, _P, _P, _P, _D, _D]),
+    "covgram_mvm_sym_allreduce": (C.c_int, [_P, _KP, _P, _P, _P, _D, _D]),
     "covgram_toeplitz_create": (C.c_int, [_P, C.POINTER(_P), _P, _P, _I64, _I64, _I32, _I32, _I32]),
     "covgram_toeplitz_mvm": (C.c_int, [_P, _P, _P, _D, _D, _I32]),
     "covgram_toeplitz_destroy": (C.c_int, [_P]),

@@ -16,6 +16,8 @@ evaluations of the row-sharded form for one n-vector all-reduce instead of the a
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -67,6 +69,45 @@ def _all_gather_into(target: torch.Tensor, shard: torch.Tensor, group) -> None:
         dist.all_gather_into_tensor(target, shard, group=group)
 
 
+# ---- the collective behind the C ABI (include/covgram.h: covgram_comm_*; round 5) -----------------------------------------------------
+# Under the "nccl" (= RCCL) backend on GPU tensors the ONE collective of the MVM runs inside libcovgram.so, on the ctx stream, right behind
+# the kernels (covgram_mvm_sharded / covgram_mvm_sym_allreduce): torch.distributed only carries the 128-byte unique id once.  torch's own
+# collective stays as the route for gloo (CPU tests, host-staged), for process groups other than the default one, and when
+# COVGRAM_ABI_COLLECTIVE=0 asks for it (bench.py times both).
+_ABI_COMM = {}          # device index -> (rank, world) of the communicator the ctx owns
+
+
+def abi_comm(device: torch.device, group=None) -> bool:
+    """Make sure the library ctx of `device` owns an RCCL communicator over the default process group; False when this route does not apply."""
+    if os.environ.get("COVGRAM_ABI_COLLECTIVE", "1") == "0" or device.type != "cuda" or not dist.is_initialized():
+        return False
+    if group is not None and group is not dist.group.WORLD:
+        return False
+    try:
+        if dist.get_backend(group) != "nccl":
+            return False
+    except Exception:
+        return False
+    from . import _ffi
+    from .gramian import get_ctx
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ctx = get_ctx(device)
+    if _ABI_COMM.get(device.index) == (rank, world):
+        return True
+    lib = _ffi.lib()
+    ident = [None]
+    if rank == 0:
+        buf = (C.c_ubyte * _ffi.COMM_ID_BYTES)()
+        _ffi.check(lib.covgram_comm_unique_id(C.cast(buf, C.c_void_p), _ffi.COMM_ID_BYTES))
+        ident[0] = bytes(buf)
+    if world > 1:
+        dist.broadcast_object_list(ident, src=0)             # the only thing torch.distributed moves for this route
+    raw = (C.c_ubyte * _ffi.COMM_ID_BYTES).from_buffer_copy(ident[0])
+    _ffi.check(lib.covgram_comm_create(ctx.handle, C.cast(raw, C.c_void_p), rank, world))
+    _ABI_COMM[device.index] = (rank, world)
+    return True
+
+
 class ShardedGramian:
     """Row shard of gramian(k, x, y) owned by this rank + the all-gather that completes b.
 
@@ -109,6 +150,10 @@ class ShardedGramian:
         # stream bracket the local kernel(s) and the one collective; read with timing_ms()
         self.timing = False
         self._ev = []
+        # the C-ABI route: the library's own kernels on GPU points, the default process group on RCCL
+        self._abi = bool(local_factory_is_default and sym_partial_factory is None and x.is_cuda and (self.world > 1 or self.force_collective)
+                         and abi_comm(x.device, group))
+        self._abi_full = None
         self.sym_partial = None
         if symmetric is not False and y is None and self.block == 1 and (self.world > 1 or self.force_collective):
             if sym_partial_factory is not None:
@@ -119,6 +164,45 @@ class ShardedGramian:
                 if hasattr(full, "sym_partial_supported") and full.sym_partial_supported(self.world):
                     self._full_op = full
                     self.sym_partial = full.sym_partial_
+        self._abi_op = None
+        if self._abi and self.block == 1:
+            from .gramian import Gramian
+            op = getattr(self, "_full_op", None) or local_factory(k, x, y)
+            self._abi_op = op if isinstance(op, Gramian) else None
+
+    # -- the C-ABI route --------------------------------------------------------------------------------------------------
+    def _abi_gramian(self, k, x, y):
+        if self._abi_full is None:
+            from .gramian import Gramian
+            self._abi_full = getattr(self, "_full_op", None) or Gramian(k, x, y)
+        return self._abi_full
+
+    def _abi_collective(self, kind: str, send: torch.Tensor, recv: Optional[torch.Tensor] = None):
+        from . import _ffi
+        from .gramian import get_ctx, _dtype_code
+        ctx = get_ctx(send.device).bind_stream()
+        lib = _ffi.lib()
+        if kind == "gather":
+            _ffi.check(lib.covgram_comm_all_gather(ctx, _ffi._P(send.data_ptr()), _ffi._P(recv.data_ptr()), send.numel(), _dtype_code(send.dtype)))
+        else:
+            _ffi.check(lib.covgram_comm_all_reduce_sum(ctx, _ffi._P(send.data_ptr()), send.numel(), _dtype_code(send.dtype)))
+
+    def _abi_mul(self, y: torch.Tensor, a: torch.Tensor, alpha: float, beta: float) -> bool:
+        """mul! in ONE library call — shard kernel + its collective enqueued on the ctx stream — for a vector on a scalar-kernel Gramian."""
+        G = self._abi_op
+        if G is None or a.dim() != 1 or self.block != 1 or not (y.is_contiguous() and y.is_cuda and y.dtype == G.dtype and y.shape == (self.n,)):
+            return False
+        from . import _ffi
+        a_c = a.to(device=G.device, dtype=G.dtype).contiguous()
+        lib = _ffi.lib()
+        ctx = G._px.ctx.bind_stream()
+        if self.sym_partial is not None:
+            _ffi.check(lib.covgram_mvm_sym_allreduce(ctx, _ffi.kref(G._spec()), G._px.handle, _ffi._P(a_c.data_ptr()), _ffi._P(y.data_ptr()),
+                                                     float(alpha), float(beta)))
+        else:
+            _ffi.check(lib.covgram_mvm_sharded(ctx, _ffi.kref(G._spec()), G._px.handle, G._py.handle, _ffi._P(a_c.data_ptr()), _ffi._P(y.data_ptr()),
+                                               float(alpha), float(beta)))
+        return True
 
     def _buffers(self, a: torch.Tensor):
         key = (tuple(a.shape[1:]), a.dtype, a.device)
@@ -166,6 +250,14 @@ class ShardedGramian:
             if self.local is not None:
                 self._local_into(out, a)
             return out
+        if self._abi and not self.timing and a.dim() == 1 and self.block == 1:
+            # the C-ABI route: kernel(s) + the one collective in ONE library call, all on the ctx stream
+            res = out if (out is not None and out.is_contiguous()) else torch.empty(self.n, dtype=a.dtype, device=a.device)
+            if self._abi_mul(res, a, 1.0, 0.0):
+                if out is not None and res is not out:
+                    out.copy_(res)
+                    return out
+                return res
         if self.sym_partial is not None and a.dim() == 1:
             # symmetric form: this rank's partial product, then ONE all-reduce (the only collective of the MVM)
             if out is None or not out.is_contiguous():
@@ -175,7 +267,10 @@ class ShardedGramian:
             e0 = self._mark(a.device)
             self.sym_partial(res, a, self.rank, self.world)
             e1 = self._mark(a.device)
-            _all_reduce_sum(res, self.group)
+            if self._abi:
+                self._abi_collective("reduce", res)
+            else:
+                _all_reduce_sum(res, self.group)
             e2 = self._mark(a.device)
             if e0 is not None:
                 self._ev.append((e0, e1, e2))
@@ -190,7 +285,10 @@ class ShardedGramian:
         e1 = self._mark(a.device)
         exact = (self.per * self.world == self.n)
         target = out if (exact and out is not None and out.is_contiguous()) else full
-        _all_gather_into(target, shard, self.group)                        # the ONLY collective of the MVM
+        if self._abi and shard.is_contiguous() and target.is_contiguous():
+            self._abi_collective("gather", shard, target)                  # the ONLY collective of the MVM, on the library's stream
+        else:
+            _all_gather_into(target, shard, self.group)
         e2 = self._mark(a.device)
         if e0 is not None:
             self._ev.append((e0, e1, e2))
@@ -207,6 +305,8 @@ class ShardedGramian:
     def mul_(self, y: torch.Tensor, a: torch.Tensor, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
         """mul!(y, G, a, α, β) with b complete on every rank: lets the Krylov callers (covgram.cg) run unchanged on a
         row-sharded Gramian — vectors are replicated, so their dot products need no further collective."""
+        if self._abi and not self.timing and (self.world > 1 or self.force_collective) and self._abi_mul(y, a, alpha, beta):
+            return y
         if alpha == 1.0 and beta == 0.0:
             return self.matmul(a, out=y)
         t = self.matmul(a)

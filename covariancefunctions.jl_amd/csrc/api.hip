@@ -506,6 +506,7 @@ int covgram_ctx_destroy(covgram_ctx* ctx) {
     ::covgram::DeviceGuard _cg_dev(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx_blas_destroy(ctx);
+    (void)comm_destroy(ctx);
     for (auto& w : ctx->ws) if (w.ptr) (void)hipFree(w.ptr);
     if (ctx->sym_map) (void)hipFree(ctx->sym_map);
     if (ctx->stamp_buf) (void)hipFree(ctx->stamp_buf);

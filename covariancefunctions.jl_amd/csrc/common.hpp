@@ -280,6 +280,8 @@ struct covgram_ctx {
     int64_t last_mfma_f16 = 0;
     int64_t toeplitz_persist = -1; // fused radix-16 row kernel: persistent workgroups (one per CU; a value > 1 = that many) that prefetch the next row pair into registers: -1 = fp64 only (measured), 0 = one pair per workgroup, 1 = always
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
+    void* comm = nullptr;        // ncclComm_t of covgram_comm_create (comm.hip): the MVM's one collective runs on `stream`
+    int32_t comm_rank = 0, comm_world = 0;
     int num_cus = 256;
     void* blas = nullptr;        // rocblas_handle of the compute-bound Kronecker mode products (kron.hip), created on first use
     int live_handles = 0;
@@ -424,6 +426,7 @@ int mvm_dot_factored(covgram_ctx* ctx, const HostKernel& hk, const covgram_point
                      int64_t ldy, int32_t nrhs, double alpha, double beta);
 
 void ctx_blas_destroy(covgram_ctx* ctx);
+int comm_destroy(covgram_ctx* ctx);      // comm.hip
 
 int pad_dim(int d);          // next compiled D >= d, or -1
 extern const int kDims[];    // compiled D list

@@ -57,7 +57,7 @@ const F_EQ, F_EXP, F_RQ, F_GAMMAEXP, F_CAUCHY, F_IMQ, F_MATERNP, F_DOT, F_EXPDOT
 const F_CONSTANT, F_COMPOSITE = Int32(100), Int32(101)
 const ISO, DOTP = Int32(1), Int32(2)
 const HOST, DEVICE = Int32(0), Int32(1)
-const ABI_VERSION = 112              # COVGRAM_VERSION of the header these ccall signatures mirror
+const ABI_VERSION = 113              # COVGRAM_VERSION of the header these ccall signatures mirror
 dtype_code(::Type{Float32}) = Int32(0); dtype_code(::Type{Float64}) = Int32(1)
 const DevFloat = Union{Float32, Float64}
 
@@ -306,6 +306,53 @@ function sym_partial!(part::Ptr{Cvoid}, G::Gramian{T}, a::Ptr{Cvoid}, rank::Inte
     check(ccall((:covgram_mvm_sym_partial, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32),
                 ctx(), kref(spec), X.handle, a, part, Int32(rank), Int32(world)))
     return true
+end
+
+# --- the collective behind the ABI (include/covgram.h, "the collective behind the ABI"): mul! on a Gramian sharded over the GPUs of a node ------
+# One Julia process per GPU.  `comm_unique_id()` on rank 0, its 128 bytes broadcast by whatever the job already has (MPI.bcast!, a shared
+# file), then `comm_create!(id, rank, world)` on every rank: the library owns the RCCL communicator from there on, and
+#     mul!(y, ShardedGramian(G), a, α, β)
+# is the reference's mul!(y, G, a, α, β) (src/gramian.jl:78-87) with its `@threads for i in 1:n` spread over the ranks: each evaluates its
+# rows (or, for gramian(k, x), its cyclic panels of the upper triangle) and ONE all-gather (all-reduce) on the library's stream completes y
+# on every rank.  x, a and y are device pointers here (replicated data stays resident between Krylov iterations).
+const COMM_ID_BYTES = 128
+function comm_unique_id()
+    id = zeros(UInt8, COMM_ID_BYTES)
+    check(ccall((:covgram_comm_unique_id, libcovgram), Cint, (Ptr{Cvoid}, Int64), id, Int64(COMM_ID_BYTES)))
+    return id
+end
+comm_create!(id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(ccall((:covgram_comm_create, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32), ctx(), id, Int32(rank), Int32(world)))
+comm_destroy!() = check(ccall((:covgram_comm_destroy, libcovgram), Cint, (Ptr{Cvoid},), ctx()))
+function comm_info()
+    r = Ref{Int32}(0); w = Ref{Int32}(0)
+    check(ccall((:covgram_comm_info, libcovgram), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), ctx(), r, w))
+    return Int(r[]), Int(w[])
+end
+all_gather!(recv::Ptr{Cvoid}, send::Ptr{Cvoid}, count::Integer, ::Type{T}) where {T <: DevFloat} =
+    check(ccall((:covgram_comm_all_gather, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32), ctx(), send, recv, Int64(count), dtype_code(T)))
+all_reduce_sum!(buf::Ptr{Cvoid}, count::Integer, ::Type{T}) where {T <: DevFloat} =
+    check(ccall((:covgram_comm_all_reduce_sum, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32), ctx(), buf, Int64(count), dtype_code(T)))
+
+struct ShardedGramian{T, GT <: Gramian{T}} <: AbstractMatrix{T}
+    G::GT
+end
+Base.size(S::ShardedGramian) = size(S.G)
+# y, a: device pointers to n resp. m replicated scalars of the Gramian's element type
+function LinearAlgebra.mul!(y::Ptr{Cvoid}, S::ShardedGramian{T}, a::Ptr{Cvoid}, α::Real = 1, β::Real = 0) where {T <: DevFloat}
+    G = S.G
+    spec = device_kernel(G.k); spec === nothing && error("ShardedGramian: the kernel has no device path (GenericInput)")
+    X = points(G.x, T)
+    if G.x === G.y                                          # gramian(k, x): the symmetric form where a symmetric kernel serves it
+        rc = ccall((:covgram_mvm_sym_allreduce, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
+                   ctx(), kref(spec), X.handle, a, y, Float64(α), Float64(β))
+        rc == 0 && return y
+        rc == -2 || check(rc)                               # COVGRAM_EUNSUPPORTED: row shards below
+    end
+    Y = G.x === G.y ? X : points(G.y, T)
+    check(ccall((:covgram_mvm_sharded, libcovgram), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
+                ctx(), kref(spec), X.handle, Y.handle, a, y, Float64(α), Float64(β)))
+    return y
 end
 
 # --- Toeplitz (src/gramian.jl:167-189): the handle caches the plans and the spectrum of the circulant embedding ----------

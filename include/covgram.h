@@ -45,9 +45,10 @@
 extern "C" {
 #endif
 
-#define COVGRAM_VERSION 112 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); 111 adds
+#define COVGRAM_VERSION 113 /* 0.1.1: covgram_kron_mvm, covgram_grad_mvm and covgram_valgrad_mvm take (lda, ldy, nrhs); 111 adds
                                covgram_cg_step_shifted; 112: covgram_mvm_sym_supported takes `world` (the symmetric partial form's
-                               column-sum slab depends on it), fp32 direct-difference symmetric partials.
+                               column-sum slab depends on it), fp32 direct-difference symmetric partials; 113: the communicator
+                               (covgram_comm_*), covgram_mvm_sharded, covgram_mvm_sym_allreduce.
                                A binding checks covgram_version() against the header it mirrors at load time */
 
 typedef enum covgram_status {
@@ -224,6 +225,35 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
 int covgram_mvm_sym_supported(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, int32_t world, int32_t* supported);
 int covgram_mvm_sym_partial(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y,
                             int32_t rank, int32_t world);
+
+/* ---- the collective behind the ABI (round 5) ------------------------------------------------------------------------------
+ * One process per GPU; a ctx can own ONE RCCL communicator, and the multi-GPU MVMs below enqueue their single collective on the
+ * ctx stream right behind the kernels (no second stream, no host synchronisation): the GPU analogue of the reference's only
+ * parallel axis, `@threads for i in 1:n` over the output rows of mul! (src/gramian.jl:78-87).
+ *   covgram_comm_unique_id   rank 0 calls it once and hands the COVGRAM_COMM_ID_BYTES bytes to the other ranks by any means of the
+ *                            caller's (MPI.jl's bcast, a torch.distributed store, a file): nothing else crosses processes outside RCCL.
+ *   covgram_comm_create      collective over all `world` ranks (ncclCommInitRank on the ctx's device).  RCCL is resolved at this first
+ *                            use (dlopen of librccl.so.1 — in a PyTorch process the copy torch has loaded): single-GPU callers never load it.
+ *   covgram_comm_destroy     also done by covgram_ctx_destroy.      covgram_comm_info: rank and world (world = 0: no communicator).
+ *   covgram_comm_all_gather / covgram_comm_all_reduce_sum   the two collectives themselves on device buffers, stream-ordered (a block
+ *                            Gramian's shards, a caller's own vectors); all_gather may run in place (send == recv + rank * count).
+ *   covgram_mvm_sharded      y <- alpha G(k; X, Y) a + beta y with y COMPLETE ON EVERY RANK.  X (all n row points), Y, a and y are
+ *                            replicated device data; rank r evaluates the rows [r per, (r + 1) per), per = ceil(n / world), with the
+ *                            single-GPU kernels — straight into its slice of y when world divides n, the all-gather then in place — and
+ *                            ONE ncclAllGather completes y, which is the replicated `a` of the next Krylov iteration.  One right-hand side.
+ *   covgram_mvm_sym_allreduce  the same product of gramian(k, x) in the symmetric form: covgram_mvm_sym_partial(rank, world) + ONE
+ *                            ncclAllReduce; COVGRAM_EUNSUPPORTED exactly when covgram_mvm_sym_supported says 0 (then: covgram_mvm_sharded). */
+#define COVGRAM_COMM_ID_BYTES 128
+int covgram_comm_unique_id(void* id, int64_t bytes);
+int covgram_comm_create(covgram_ctx* ctx, const void* unique_id, int32_t rank, int32_t world);
+int covgram_comm_destroy(covgram_ctx* ctx);
+int covgram_comm_info(const covgram_ctx* ctx, int32_t* rank, int32_t* world);
+int covgram_comm_all_gather(covgram_ctx* ctx, const void* send, void* recv, int64_t count, int32_t dtype);
+int covgram_comm_all_reduce_sum(covgram_ctx* ctx, void* buf, int64_t count, int32_t dtype);
+int covgram_mvm_sharded(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const covgram_points* Y, const void* a,
+                        void* y, double alpha, double beta);
+int covgram_mvm_sym_allreduce(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points* X, const void* a, void* y, double alpha,
+                              double beta);
 
 /* Gradient-kernel Gramian (nd × md): Y <- alpha * G A + beta * Y with flat point-major block vectors as the columns of
  * A (m*d × nrhs, lda >= m*d) and Y (n*d × nrhs, ldy >= n*d), column-major; a vector is nrhs = 1 (lda, ldy then unused beyond the check).

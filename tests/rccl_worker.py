@@ -1,6 +1,7 @@
 """One rank of the RCCL check (tests/test_gpu_dist.py): launched by `python -m torch.distributed.run`, one process per GPU, backend "nccl"
 (= RCCL on ROCm).  Row shards + ONE all-gather, symmetric partials + ONE all-reduce, an fp64 matrix right-hand side and the gradient
 blocks, each against rows of the fp64 oracle; rank 0 prints one JSON line.  Not collected by pytest (no test_ prefix)."""
+import ctypes as C
 import json
 import os
 import sys
@@ -31,12 +32,30 @@ def main():
     ref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32)
     rel = lambda b, r: float(np.linalg.norm(np.asarray(b, dtype=np.float64) - r) / np.linalg.norm(r))
     G = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+    # the route under RCCL is the C ABI's (round 5): covgram_mvm_sharded = the shard's kernels + ncclAllGather on the library's stream
+    res["abi_route"] = bool(G._abi)
+    rk, wd = C.c_int32(-1), C.c_int32(-1)
+    cg._ffi.check(cg._ffi.lib().covgram_comm_info(cg.get_ctx(dev).handle, C.byref(rk), C.byref(wd)))
+    res["comm_info"] = [rk.value, wd.value]
+    b1 = G @ a                                                   # ONE library call: kernel + collective
+    y2 = torch.from_numpy(ah[::-1].copy()).to(dev)
+    G.mul_(y2, a, -0.7, 1.3)                                     # alpha / beta through covgram_mvm_sharded
+    res["abi_mul"] = {"rel": rel(b1.cpu().numpy()[rows], ref), "rel_alpha_beta": rel(y2.cpu().numpy()[rows], -0.7 * ref + 1.3 * ah[::-1][rows].astype(np.float64))}
     G.timing = True
-    b = G @ a
+    b = G @ a                                                    # timing on: the shard's MVM, then covgram_comm_all_gather, bracketed by events
     loc, col, steps = G.timing_ms()
     res["gather"] = {"rel": rel(b.cpu().numpy()[rows], ref), "shard": [G.lo, G.hi], "local_ms": loc, "collective_ms": col, "steps": steps}
+    res["abi_same_as_split"] = bool(torch.equal(b, b1))
+    # ... and torch.distributed's own collective (COVGRAM_ABI_COLLECTIVE=0) gives the same bits
+    os.environ["COVGRAM_ABI_COLLECTIVE"] = "0"
+    Gt = cg.ShardedGramian(cg.EQ(), X, symmetric=False)
+    res["torch_route"] = {"abi": bool(Gt._abi), "same": bool(torch.equal(Gt @ a, b1))}
+    os.environ.pop("COVGRAM_ABI_COLLECTIVE")
     Gs = cg.ShardedGramian(cg.EQ(), X, symmetric=True)
-    res["reduce"] = {"rel": rel((Gs @ a).cpu().numpy()[rows], ref), "used_partials": Gs.sym_partial is not None}
+    res["reduce"] = {"rel": rel((Gs @ a).cpu().numpy()[rows], ref), "used_partials": Gs.sym_partial is not None, "abi": bool(Gs._abi)}
+    y3 = torch.from_numpy(ah[::-1].copy()).to(dev)
+    Gs.mul_(y3, a, 2.0, -0.5)                                    # covgram_mvm_sym_allreduce with alpha / beta
+    res["reduce"]["rel_alpha_beta"] = rel(y3.cpu().numpy()[rows], 2.0 * ref - 0.5 * ah[::-1][rows].astype(np.float64))
     n6 = 6001
     X6h = rng.standard_normal((n6, d)); a6h = rng.standard_normal(n6)
     G6 = cg.ShardedGramian(cg.MaternP(2), torch.from_numpy(X6h).to(dev), symmetric=True)

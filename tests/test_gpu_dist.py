@@ -190,6 +190,11 @@ def _run_rccl_worker(nproc):
 
 def _check_rccl(res, world):
     assert res["world"] == world and res["backend"] == "nccl"
+    # the C-ABI communicator carried every collective of this run (include/covgram.h: covgram_comm_*, covgram_mvm_sharded, covgram_mvm_sym_allreduce)
+    assert res["abi_route"] and res["comm_info"] == [0, world], (res["abi_route"], res["comm_info"])
+    assert res["abi_mul"]["rel"] <= 1e-5 and res["abi_mul"]["rel_alpha_beta"] <= 1e-5, res["abi_mul"]
+    assert res["abi_same_as_split"] and res["torch_route"] == {"abi": False, "same": True}, (res["abi_same_as_split"], res["torch_route"])
+    assert res["reduce"]["abi"] and res["reduce"]["rel_alpha_beta"] <= 1e-5, res["reduce"]
     assert res["gather"]["rel"] <= 1e-5 and res["gather"]["steps"] == 1 and res["gather"]["collective_ms"] > 0, res["gather"]
     assert res["reduce"]["rel"] <= 1e-5 and res["reduce"]["used_partials"], res["reduce"]
     assert res["reduce64"]["rel"] <= 1e-12 and res["reduce64"]["used_partials"], res["reduce64"]
@@ -210,3 +215,61 @@ def test_rccl_two_ranks_row_shards_and_symmetric_partials():
     res = _run_rccl_worker(2)
     _check_rccl(res, 2)
     assert res["gather"]["shard"] == [0, 20001]
+
+
+def test_c_abi_communicator_raw_calls_at_world_one(cg, oracle):
+    """include/covgram.h's communicator through ctypes alone, the way the Julia shim's ccalls use it: unique id, covgram_comm_create on a ctx of
+    its own (RCCL for real, world = 1), covgram_comm_info, the two raw collectives, covgram_mvm_sharded and covgram_mvm_sym_allreduce against the
+    oracle, the error paths (no communicator; a second create), covgram_comm_destroy."""
+    import ctypes as C
+    o = oracle
+    ffi = cg._ffi
+    lib = ffi.lib()
+    ctx = ffi._P()
+    ffi.check(lib.covgram_ctx_create(C.byref(ctx), 0, ffi._P(torch.cuda.current_stream().cuda_stream)))
+    try:
+        n, d = 5000, 3
+        rng = np.random.default_rng(11)
+        Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+        X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda(); y = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+        px = ffi._P()
+        ffi.check(lib.covgram_points_create(ctx, C.byref(px), ffi._P(X.data_ptr()), n, d, ffi.F32, ffi.DEVICE))
+        k = ffi.covgram_kernel(ffi.EQ, ffi.ISOTROPIC, 0, 1, 0.0, 1.0, 1.0)
+        rc = lib.covgram_mvm_sharded(ctx, ffi.kref(k), px, px, ffi._P(a.data_ptr()), ffi._P(y.data_ptr()), 1.0, 0.0)
+        assert rc == ffi.EINVAL and b"no communicator" in lib.covgram_last_error()
+        ident = (C.c_ubyte * ffi.COMM_ID_BYTES)()
+        assert lib.covgram_comm_unique_id(C.cast(ident, C.c_void_p), 64) == ffi.EINVAL          # buffer too small
+        ffi.check(lib.covgram_comm_unique_id(C.cast(ident, C.c_void_p), ffi.COMM_ID_BYTES))
+        ffi.check(lib.covgram_comm_create(ctx, C.cast(ident, C.c_void_p), 0, 1))
+        assert lib.covgram_comm_create(ctx, C.cast(ident, C.c_void_p), 0, 1) == ffi.EINVAL       # one communicator per ctx
+        rk, wd = C.c_int32(-1), C.c_int32(-1)
+        ffi.check(lib.covgram_comm_info(ctx, C.byref(rk), C.byref(wd)))
+        assert (rk.value, wd.value) == (0, 1)
+        ref = o.mul(None, o.Kernel(o.EQ), Xh.astype(np.float64), Xh.astype(np.float64), ah.astype(np.float64))
+        ffi.check(lib.covgram_mvm_sharded(ctx, ffi.kref(k), px, px, ffi._P(a.data_ptr()), ffi._P(y.data_ptr()), 1.0, 0.0))
+        ffi.check(lib.covgram_sync(ctx))
+        b = y.cpu().numpy().astype(np.float64)
+        assert np.isfinite(b).all() and np.linalg.norm(b - ref) / np.linalg.norm(ref) <= 1e-5
+        y2 = torch.from_numpy(ah[::-1].copy()).cuda()
+        ffi.check(lib.covgram_mvm_sharded(ctx, ffi.kref(k), px, px, ffi._P(a.data_ptr()), ffi._P(y2.data_ptr()), -0.7, 1.3))
+        ffi.check(lib.covgram_sync(ctx))
+        want = -0.7 * ref + 1.3 * ah[::-1].astype(np.float64)
+        assert np.linalg.norm(y2.cpu().numpy() - want) / np.linalg.norm(want) <= 1e-5
+        # the symmetric form: forced below its automatic size
+        ffi.check(lib.covgram_ctx_set_option(ctx, b"mfma_sym", 1))
+        y3 = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+        ffi.check(lib.covgram_mvm_sym_allreduce(ctx, ffi.kref(k), px, ffi._P(a.data_ptr()), ffi._P(y3.data_ptr()), 1.0, 0.0))
+        ffi.check(lib.covgram_sync(ctx))
+        assert np.linalg.norm(y3.cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-5
+        # raw collectives: in-place all-gather of one piece, all-reduce of a vector (world = 1: identities, but RCCL runs them)
+        v = torch.arange(1000, dtype=torch.float64, device="cuda"); v0 = v.clone()
+        ffi.check(lib.covgram_comm_all_gather(ctx, ffi._P(v.data_ptr()), ffi._P(v.data_ptr()), 1000, ffi.F64))
+        ffi.check(lib.covgram_comm_all_reduce_sum(ctx, ffi._P(v.data_ptr()), 1000, ffi.F64))
+        ffi.check(lib.covgram_sync(ctx))
+        assert torch.equal(v, v0)
+        ffi.check(lib.covgram_points_destroy(px))
+        ffi.check(lib.covgram_comm_destroy(ctx))
+        ffi.check(lib.covgram_comm_info(ctx, C.byref(rk), C.byref(wd)))
+        assert wd.value == 0
+    finally:
+        lib.covgram_ctx_destroy(ctx)

@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol(cg):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/covgram.h but not exported"
     assert declared == set(cg._ffi.PROTOTYPES), declared ^ set(cg._ffi.PROTOTYPES)
-    assert lib.covgram_version() == 112
+    assert lib.covgram_version() == 113
     # and the library links only what the image provides
     assert os.path.exists(cg._ffi.LIB_PATH)
 
