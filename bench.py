@@ -157,6 +157,13 @@ def _rel(b, ref):
     return float(np.linalg.norm(b - ref) / np.linalg.norm(ref))
 
 
+def _rowwise(b, ref, absref):
+    """max_i |b_i - ref_i| / (sum_j |G_ij| |a_j|): the row-wise (component-wise) error the norm-wise figure can hide — the matrix-core paths' risk is
+    per row (a far point's exponent), tests/ hold every fp32 path to 1e-5 on BOTH."""
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(b - ref) / absref))
+
+
 def other_configs(cg, dev):
     """BASELINE.json configs[0], [2], [3], [4] at their stated sizes on this one GPU: ms per MVM (host wall over back-to-back calls,
     inputs resident), rel-err against the oracle (checker, outside the timed loops) and the roofline SURVEY.md §8d assigns."""
@@ -212,12 +219,14 @@ def other_configs(cg, dev):
     kms, kl = cg.kernel_time(); cg.set_option("time_kernels", 0)
     rows = np.sort(np.random.default_rng(2).choice(per, 256, replace=False))
     ref = c_oracle.mvm(o.Kernel(o.EQ), Xh[rows].astype(np.float64), Xh.astype(np.float64), ah.astype(np.float64))
+    c3_abs = c_oracle.mvm(o.Kernel(o.EQ), Xh[rows].astype(np.float64), Xh.astype(np.float64), np.abs(ah).astype(np.float64))
     fl = float(per) * n * (3 * d + 3)
     kavg = kms / max(kl, 1)
     c3_k2 = (d + 3) // 4 if cg.get_info("last_mfma_f16") == 1 else (d + 1) // 2     # MFMAs per 32 x 32 tile: fp16 two-way split (round 4) / bf16 three-way split
     c3_cycles64 = 8.0 + (2.25 if c3_k2 <= 2 else 4.0) + 8.0 * c3_k2 / 16.0      # K2 <= 2: packed fmas (profiles/r04_pkfma_ab.txt)
     out["C3_shard"] = {"what": "EQ dense Gramian mul!, d=8 n=524288 fp32: one rank's row shard of the 8-GPU config (65536 rows x 524288 columns, all entries)",
                        "ms": ms, "kernel_avg_ms": kavg, "pairs_per_s": float(per) * n / (ms * 1e-3), "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
+                       "rowwise_err_vs_fp64_oracle": _rowwise(y.cpu().numpy()[rows], ref, c3_abs),
                        "checked_rows": len(rows),
                        "roofline": {"bound": "valu_issue", "achieved": fl / (kavg * 1e-3) * 1e-12, "peak": 1024 * 2.4e9 * 64 / c3_cycles64 * (3 * d + 3) * 1e-12,
                                     "unit": "TFLOP/s", "frac": (float(per) * n / (kavg * 1e-3)) / (1024 * 2.4e9 * 64 / c3_cycles64),
@@ -259,17 +268,39 @@ def other_configs(cg, dev):
             path = cg.get_info("last_dense_path")
             sym = bool(cg.get_info("last_mfma_sym") == 1 or cg.get_info("last_dense_sym") == 1)
             ref = c_oracle.mvm(o.Kernel(o.EQ, lengthscale=l), Xr, Xd, ad)
+            absr = c_oracle.mvm(o.Kernel(o.EQ, lengthscale=l), Xr, Xd, np.abs(ad))
             split = "" if path != 2 else (", fp16 two-way split" if cg.get_info("last_mfma_f16") == 1 else ", bf16 three-way split")
             gm.append({"lengthscale": l, "path": names.get(path, str(path)) + split + (", upper triangle once" if sym else ", all entries"), "ms": ms, "mvm_per_s": 1e3 / ms,
-                       "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref)})
+                       "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref), "rowwise_err_vs_fp64_oracle": _rowwise(y.cpu().numpy()[rows], ref, absr)})
         out["gate_map_EQ_C2_size"] = {"what": "gramian(Lengthscale(EQ, l), x) * a, d=3 n=131072 fp32, x ~ N(0, I): the library's default path by lengthscale "
                                               "(the matrix-core path is gated on g^2 R^2 <= 126 about the cloud's centre, its fp16 split on <= 72; csrc/dense_mfma.hip)", "rows_checked": 256, "by_lengthscale": gm}
         kc = 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
         G = cg.gramian(kc, X)
         ms = _timed(lambda: G.mul_(y, a), warm=3, reps=8, warm_s=0.05)
         ref = 1.5 * c_oracle.mvm(o.Kernel(o.MATERNP, p=2, lengthscale=0.7), Xr, Xd, ad) + 0.5 * c_oracle.mvm(o.Kernel(o.EQ, lengthscale=2.0), Xr, Xd, ad)
-        out["F2_composite"] = {"what": "1.5 MaternP(2; l=0.7) + 0.5 EQ(l=2) dense Gramian mul!, d=3 n=131072 fp32: one MVM per term, each on its own default path",
-                               "ms": ms, "mvm_per_s": 1e3 / ms, "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref), "rows_checked": 256}
+        absr = 1.5 * c_oracle.mvm(o.Kernel(o.MATERNP, p=2, lengthscale=0.7), Xr, Xd, np.abs(ad)) + 0.5 * c_oracle.mvm(o.Kernel(o.EQ, lengthscale=2.0), Xr, Xd, np.abs(ad))
+        fused = cg.get_info("last_sum_fused") == 1
+        out["F2_composite"] = {"what": "1.5 MaternP(2; l=0.7) + 0.5 EQ(l=2) dense Gramian mul!, d=3 n=131072 fp32, gramian(k, x): " +
+                                       ("ONE pass of the symmetric matrix-core Sum kernel" if fused else "one symmetric matrix-core MVM per term (the library's rule for two terms: "
+                                        "every term's transcendentals remain in a one-pass kernel, profiles/r05_sum_fused_ab.txt)"),
+                               "ms": ms, "mvm_per_s": 1e3 / ms, "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref),
+                               "rowwise_err_vs_fp64_oracle": _rowwise(y.cpu().numpy()[rows], ref, absr), "rows_checked": 256,
+                               "precision_note": "fp32 MaternP is evaluated in fp32 here; the reference stores MaternP's coefficients as Float64 and so evaluates the profile in "
+                                                 "Float64 on Float32 inputs, rounding on store (src/stationary.jl:126-128): a deviation inside the 1e-5 tolerance"}
+        # the same Sum with a third term, where the one-pass kernels pay (one MFMA pass, one slab, one reduce for three profiles)
+        k3 = cg.Lengthscale(cg.EQ(), 1.4) + 0.7 * cg.Lengthscale(cg.RQ(0.8), 0.9) + 0.2 * cg.MaternP(1)
+        G3 = cg.gramian(k3, X)
+        ms3 = _timed(lambda: G3.mul_(y, a), warm=3, reps=8, warm_s=0.05)
+        f3 = cg.get_info("last_sum_fused") == 1
+        ref3 = (c_oracle.mvm(o.Kernel(o.EQ, lengthscale=1.4), Xr, Xd, ad) + 0.7 * c_oracle.mvm(o.Kernel(o.RQ, param=0.8, lengthscale=0.9), Xr, Xd, ad)
+                + 0.2 * c_oracle.mvm(o.Kernel(o.MATERNP, p=1), Xr, Xd, ad))
+        cg.set_option("sum_fused", 0)
+        ms3t = _timed(lambda: G3.mul_(y, a), warm=3, reps=8, warm_s=0.05)
+        cg.set_option("sum_fused", -1)
+        G3.mul_(y, a)
+        out["F2_sum_of_three"] = {"what": "EQ(l=1.4) + 0.7 RQ(0.8; l=0.9) + 0.2 MaternP(1) dense Gramian mul!, d=3 n=131072 fp32, gramian(k, x)", "ms": ms3, "one_pass": bool(f3),
+                                  "ms_one_mvm_per_term": ms3t, "rel_err_vs_fp64_oracle": _rel(y.cpu().numpy()[rows], ref3), "rows_checked": 256}
+        del G3
         del G, X, a, y
     except Exception as e:
         out["gate_map_EQ_C2_size"] = {"what": "failed", "error": str(e)[:200]}
@@ -498,6 +529,7 @@ def main():
     dense_path = cg.get_info("last_dense_path")
     sym_path = cg.get_info("last_mfma_sym") == 1
     f16_split = dense_path == 2 and cg.get_info("last_mfma_f16") == 1      # the matrix-core EQ kernels' fp16 two-way split of the coordinates (round 4)
+    mfma_inst = cg.get_info("last_mfma_instance")                          # template arguments of the kernel the timed steps launched
 
     per_rank = None
     if world > 1:
@@ -653,10 +685,13 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import covgram_oracle as o
         ref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, ah, dtype=np.float32)
+        absref = o.mul(None, o.Kernel(o.EQ), Xh[rows], Xh, np.abs(ah), dtype=np.float32)      # sum_j G_ij |a_j| (G > 0): the row-wise error's scale
         rel_err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        row_err = _rowwise(got, ref, absref)
         gots = bs.cpu().numpy()[rows].astype(np.float64)
         if dd is not None and got_d is not None:
             dd["rel_err_vs_fp64_oracle"] = float(np.linalg.norm(got_d[rows].astype(np.float64) - ref) / np.linalg.norm(ref))
+            dd["rowwise_err_vs_fp64_oracle"] = _rowwise(got_d[rows].astype(np.float64), ref, absref)
         symmetric_variant = {
             "what": "the same mul!(b, gramian(EQ, x), a) on the library's default path: the upper triangle of the symmetric Gramian is "
                     "evaluated once (row and column sums of the same tiles)" + ("" if world == 1 else f"; rank r of {world} takes the cyclic "
@@ -665,6 +700,7 @@ def main():
             "value": args.steps / s_elapsed, "unit": "MVM/s", "ms_per_step": s_elapsed / args.steps * 1e3,
             "kernel_avg_ms": s_kern_avg_ms, "ms_median": s_step["ms_median"], "ms_min": s_step["ms_min"],
             "rel_err_vs_fp64_oracle": float(np.linalg.norm(gots - ref) / np.linalg.norm(ref)),
+            "rowwise_err_vs_fp64_oracle": _rowwise(gots, ref, absref),
             "evaluated_pairs_per_launch": float(N_POINTS) * (N_POINTS + 32) / 2 / world,
         }
 
@@ -677,9 +713,16 @@ def main():
         bytes_launch = 4.0 * (n_local * d + m * (d + 1) + n_local)      # compulsory: x rows, packed (y, a) stream, b
         kern_s = kern_avg_ms * 1e-3
         achieved_tflops = flops_launch / kern_s * 1e-12
-        traffic = None
+        # roofline.traffic: HBM bytes per launch from the latest recorded rocprofv3 PMC pass — ONLY when that pass profiled the very kernel
+        # instance this run launched (the library reports its template arguments; tools/pmc_json.py records the profiled kernel's name);
+        # otherwise null with the reason (the figure used to be a file read that no kernel change could invalidate)
+        traffic, traffic_note = None, None
+        ran_name = None
+        if dense_path == 2 and not sym_path and mfma_inst > 0:
+            q = mfma_inst
+            ran_name = "covgram::dense_mfma_eq_kernel<%d, %d, %d, %d, %d, %d>" % (q // 100000, q // 10000 % 10, q // 1000 % 10, q // 100 % 10, q // 10 % 10, q % 10)
         pmc = None
-        for rnd in ("r04", "r03", "r02", "r01"):                                   # the latest recorded PMC pass of the kernel that ran
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):                            # the latest recorded PMC pass of this kernel family
             cand = os.path.join(ROOT, "profiles", f"{rnd}_" + (("dense_mfma_sym_pmc.json" if sym_path else "dense_mfma_pmc.json") if dense_path == 2
                                                                else "dense_pmc.json"))
             if os.path.exists(cand):
@@ -687,9 +730,19 @@ def main():
                 break
         if pmc:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                rec = json.load(open(pmc))
+                prof_name = rec.get("kernel_name") or rec.get("kernel", "")
+                if ran_name is None:
+                    traffic_note = f"{os.path.basename(pmc)} exists, but this run's kernel is not the general matrix-core EQ kernel whose instance the library reports"
+                elif prof_name.replace(" ", "").startswith(ran_name.replace(" ", "")):
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_note = f"{os.path.basename(pmc)}: a PMC pass of {ran_name}, the instance this run launched"
+                else:
+                    traffic_note = f"{os.path.basename(pmc)} profiled {prof_name.split('(')[0].strip()}, this run launched {ran_name}: no traffic figure"
+            except Exception as e:
+                traffic, traffic_note = None, f"unreadable PMC record: {e}"
+        else:
+            traffic_note = "no PMC record under profiles/"
         # which kernel ran (the library picks the matrix-core EQ path when its norm bound holds)
         # Issue pricing (MI355X_MICROARCH.md, row 'vector-instruction ISSUE cost'): per wave-instruction and SIMD v_exp_f32 8 cycles,
         # v_fma_f32 4, and each v_mfma_f32_32x32x16_bf16 holds the SIMD's vector issue for 8 of its 32 cycles; costs add.
@@ -758,7 +811,8 @@ def main():
                            f"upper triangle by cyclic 256-row panels x{world} + 1 RCCL all-reduce of b per MVM" if sym_path
                            else f"row-shard x{world} + 1 RCCL all-gather of b per MVM")},
             "pairs_per_s": mvms * float(n) * m,
-            "rel_err_vs_fp64_oracle": rel_err,
+            "rel_err_vs_fp64_oracle": rel_err, "rowwise_err_vs_fp64_oracle": row_err,
+            "err_note": "1024 random rows against the fp64 oracle after the timed regions: rel = |b - ref|_2 / |ref|_2, rowwise = max_i |b_i - ref_i| / sum_j |G_ij a_j|",
             "symmetric_variant": symmetric_variant,
             "direct_difference_variant": dd,
             "incl_h2d_d2h": incl,
@@ -775,7 +829,8 @@ def main():
                 "reference_flops_frac": float(n_local) * m * (3 * d + 3) / kern_s * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
                 "vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_source": "recorded rocprofv3 --pmc pass of this kernel (profiles/, FETCH_SIZE doubled per the guide), not measured in this run",
+                "traffic_source": "recorded rocprofv3 --pmc pass (profiles/, FETCH_SIZE doubled per the guide), not measured in this run; taken only when that pass "
+                                  "profiled the kernel instance this run launched", "traffic_check": traffic_note, "kernel_instance": ran_name,
                 "kernel_avg_ms": kern_avg_ms, "launches": int(launches),
                 "algorithmic_flops_per_launch": flops_launch,
                 "note": note,

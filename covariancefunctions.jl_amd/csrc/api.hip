@@ -576,6 +576,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_grad_expand")) *value = ctx->last_grad_expand;
     else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;
     else if (!strcmp(key, "last_sum_fused")) *value = ctx->last_sum_fused;
+    else if (!strcmp(key, "last_mfma_instance")) *value = ctx->last_mfma_instance;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
         // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none

@@ -278,6 +278,7 @@ struct covgram_ctx {
     int64_t mfma_fuse_w = -1;      // general matrix-core EQ kernel: the column weights a_j exp2(f_j) formed in the kernel (-1 / 1) or by a pack launch in front of it (0)
     int64_t mfma_f16 = -1;         // general matrix-core EQ kernel: the fp16 two-way split (half the MFMAs per tile): -1 / 1 = within MFMA_F16_GATE, 0 = never, 2 = within MFMA_GATE (measurements only)
     int64_t last_mfma_f16 = 0;
+    int64_t last_mfma_instance = 0;   // template arguments of the last matrix-core EQ kernel launched: K2 1e5 + RT 1e4 + WPB 1e3 + LDS 100 + STAMP 10 + FMT (general), -(K2 10 + FMT) (symmetric), 0 other
     int64_t toeplitz_persist = -1; // fused radix-16 row kernel: persistent workgroups (one per CU; a value > 1 = that many) that prefetch the next row pair into registers: -1 = fp64 only (measured), 0 = one pair per workgroup, 1 = always
     int64_t toeplitz_fused = 1;  // 1: row FFT + spectral step + inverse row FFT as one kernel when M' = 4^L <= 4096; 0: rocFFT batches
     void* comm = nullptr;        // ncclComm_t of covgram_comm_create (comm.hip): the MVM's one collective runs on `stream`

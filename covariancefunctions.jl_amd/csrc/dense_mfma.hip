@@ -556,24 +556,25 @@ static int mfma_blocks(int rt) {
 template <int K2, int FMT = 0>
 static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const float* X, int64_t n, int32_t d, const uint4* PB, const float* W,
                         int64_t ntile, float* out, int64_t npad, int64_t tchunk, float g, float alpha, float beta, int final_store, const float* Cn,
-                        unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal, const float* EF, int64_t mcols) {
+                        unsigned long long* stamps, dim3* launched, unsigned* tickets, float* yfinal, const float* EF, int64_t mcols, int64_t* inst) {
     constexpr bool NARROW = K2 <= MFMA_NARROW_MAXK2;
     unsigned long long* const ns = nullptr;
+    auto enc = [](int k2, int rtt, int wpb, int lds, int stamp) { return (int64_t)k2 * 100000 + rtt * 10000 + wpb * 1000 + lds * 100 + stamp * 10 + FMT; };
     if (lds4 && K2 <= 2 && grid.x >= 1024) {   // d <= 4 and many row tiles: eight waves share each column tile (C2: 1.569 -> 1.550 ms; not for a 16384-row shard)
         *launched = dim3((grid.x + 7) / 8, grid.y);
-        if constexpr (K2 <= 2) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
+        if constexpr (K2 <= 2) { if (stamps) { *inst = enc(K2, 2, 8, 1, 1); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 8, 1, 1, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
+        *inst = enc((K2 <= 2 ? K2 : 1), 2, 8, 1, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 2 ? K2 : 1), 2, 8, 1, 0, FMT>), *launched, dim3(512), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else if (lds4) {   // 256-thread workgroups: four waves on consecutive row tiles share the column tiles through LDS
         *launched = dim3((grid.x + 3) / 4, grid.y);
-        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols); return; } }
-        if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
+        if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { *inst = enc(K2, 4, 4, 1, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols); return; } }
+        if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { *inst = enc(K2, 2, 4, 1, 1); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
+        *inst = enc(K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
+        *inst = enc((K2 <= 8 ? K2 : 1), 2, 1, 0, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else {
         *launched = grid;
-        hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
+        *inst = enc(K2, 1, 1, 0, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 1, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     }
 }
 
@@ -745,7 +746,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     if (tm) (void)hipEventRecord(tm->first, ctx->stream);
     ctx->last_mfma_lds = lds4 ? 1 : 0;
     dim3 launched;
-#define CG_MFMA_CASE(K) case K: if (fmt) { if constexpr (K <= 8) launch_mfma<K, 1>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m); } else launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m); break;
+#define CG_MFMA_CASE(K) case K: if (fmt) { if constexpr (K <= 8) launch_mfma<K, 1>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m, &ctx->last_mfma_instance); } else launch_mfma<K>(rt, lds4, grid, ctx->stream, (const float*)X->dptr, n, d, PB, W, ntile, out, npad, tchunk, g, (float)alpha_eff, (float)beta, fs, Cn, stamps, &launched, tickets, y, EFk, m, &ctx->last_mfma_instance); break;
     switch (K2) {
         CG_MFMA_CASE(1) CG_MFMA_CASE(2) CG_MFMA_CASE(3) CG_MFMA_CASE(4) CG_MFMA_CASE(6) CG_MFMA_CASE(8) CG_MFMA_CASE(12) CG_MFMA_CASE(16)
         default: set_error("dense_mfma: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
@@ -960,6 +961,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #define CG_SYMWH_CASE(K) case K: hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST_H, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                     PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
                                                     KParams<float>{}, EF); break;
+    ctx->last_mfma_instance = fast ? -(int64_t)(K2 * 10 + fmt) : 0;
     if (fast && fmt) {
         switch (K2) {
             CG_SYMH_CASE(1) CG_SYMH_CASE(2) CG_SYMH_CASE(3) CG_SYMH_CASE(4)

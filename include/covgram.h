@@ -177,7 +177,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
 int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value);
 /* read-only facts: "last_dense_path" (which kernel the last covgram_mvm ran: 0 none yet, 1 lane-per-row direct differences,
  * 2 matrix cores, 3 wide rows, 4 Gramian(Dot(), x, y) factored as X (Y' a)), "last_mfma_lds" (1: that matrix-core MVM shared its column tiles through LDS), "last_mfma_sym" (1: the last dense
- * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_sum_fused" (1: the last covgram_mvm ran a Sum on the one-pass kernels), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_mfma_f16" (1: the last general matrix-core EQ MVM ran the fp16 two-way split), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
+ * MVM ran the symmetric upper-triangle kernel), "last_dense_sym" (1: it ran a direct-difference symmetric kernel, fp64 or fp32), "last_inkernel_reduce" (1: the last dense kernel summed its own split-J slab), "last_grad_expand" (1: the last gradient MVM ran the expanded form), "last_grad_bcast" (waves per workgroup of the broadcast kernel if the last gradient MVM ran it, else 0), "last_sum_fused" (1: the last covgram_mvm ran a Sum on the one-pass kernels), "last_mfma_instance" (which instance of the matrix-core EQ kernels the last launch was: the template arguments of dense_mfma_eq_kernel as K2 1e5 + RT 1e4 + WPB 1e3 + LDS 100 + STAMP 10 + FMT, -(K2 10 + FMT) for the symmetric kernel, 0 otherwise — bench.py checks its recorded PMC pass against it), "last_dense_bcast" (1: the last fp64 dense MVM ran a register-broadcast kernel), "last_mfma_f16" (1: the last general matrix-core EQ MVM ran the fp16 two-way split), "last_jsplit" (the column split of the last lane-per-row dense launch), "last_kron_path" (which kernels the last covgram_kron_mvm ran, as bits: 1 = the fused last-two-modes pass, 2 = the single-mode kernel, 4 = the last-mode kernel, 8 = a rocBLAS GEMM (a factor side >= 1024, >= 256 with >= 2 GFLOP, or a shape the kernels refuse), 16 = two small trailing factors multiplied out first), "num_cus", "last_clock_khz" (median shader clock over the workgroups of the last
  * launch made with "mfma_stamp" = 1; synchronises the stream; 0 = no stamped launch yet). */
 int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value);
 int covgram_sync(covgram_ctx* ctx);

@@ -51,6 +51,9 @@ def test_config2_eq_d3_n131072_f32_general_and_symmetric(cg, oracle):
             cg.set_option("mfma_sym", sym)
             b = (G @ a).cpu().numpy()
             assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == (0 if sym == 0 else 1)
+            # ... and it is the INSTANCE bench.py times: the fp16 two-way split, for sym = 0 dense_mfma_eq_kernel<K2 = 1, RT = 2, WPB = 8, LDS = 1, STAMP = 0, FMT = 1>
+            assert cg.get_info("last_mfma_f16") == 1
+            assert cg.get_info("last_mfma_instance") == (128101 if sym == 0 else -11), cg.get_info("last_mfma_instance")
             assert np.isfinite(b).all()
             assert relerr(b[rows], ref) <= 1e-5 and rowwise(b[rows], ref, absref, L) <= 1e-5, (sym, relerr(b[rows], ref), rowwise(b[rows], ref, absref, L))
     finally:
@@ -72,6 +75,8 @@ def test_config3_eq_d8_n524288_f32_shard_and_symmetric_partials(cg, oracle):
     G = cg.gramian(cg.EQ(), X[lo:hi], X)
     b = (G @ a).cpu().numpy()
     assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 0 and b.shape == (per,)
+    # the kernel bench.py's C3_shard line times: fp16 split, d = 8 -> two MFMAs per tile: dense_mfma_eq_kernel<K2 = 2, RT = 2, WPB = 8, LDS = 1, 0, FMT = 1>
+    assert cg.get_info("last_mfma_f16") == 1 and cg.get_info("last_mfma_instance") == 228101, cg.get_info("last_mfma_instance")
     assert np.isfinite(b).all()
     assert relerr(b[rows - lo], ref) <= 1e-5 and rowwise(b[rows - lo], ref, absref, L) <= 1e-5, (relerr(b[rows - lo], ref), rowwise(b[rows - lo], ref, absref, L))
     # (b) symmetric partials of all 8 ranks
@@ -80,6 +85,7 @@ def test_config3_eq_d8_n524288_f32_shard_and_symmetric_partials(cg, oracle):
     tot = torch.zeros(n, dtype=torch.float32, device="cuda"); part = torch.empty_like(tot)
     for r in range(world):
         Gf.sym_partial_(part, a, r, world); tot += part
+    assert cg.get_info("last_mfma_f16") == 1 and cg.get_info("last_mfma_instance") == -21     # the symmetric kernel, K2 = 2, fp16 split
     bs = tot.cpu().numpy()
     assert np.isfinite(bs).all()
     assert relerr(bs[rows], ref) <= 1e-5 and rowwise(bs[rows], ref, absref, L) <= 1e-5, (relerr(bs[rows], ref), rowwise(bs[rows], ref, absref, L))
