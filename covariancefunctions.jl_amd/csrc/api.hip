@@ -557,6 +557,9 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "mfma_mrhs")) ctx->mfma_mrhs = value;
     else if (!strcmp(key, "composite_termwise")) ctx->composite_termwise = value;
     else if (!strcmp(key, "sum_fused")) ctx->sum_fused = value;
+    else if (!strcmp(key, "lowrank_reverse")) ctx->lowrank_reverse = value;
+    else if (!strcmp(key, "mfma_sym_rt")) ctx->mfma_sym_rt = value;
+    else if (!strcmp(key, "lowrank_wgs")) ctx->lowrank_wgs = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }
     return COVGRAM_OK;
@@ -577,6 +580,7 @@ int covgram_ctx_get_info(covgram_ctx* ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_grad_bcast")) *value = ctx->last_grad_bcast;
     else if (!strcmp(key, "last_sum_fused")) *value = ctx->last_sum_fused;
     else if (!strcmp(key, "last_mfma_instance")) *value = ctx->last_mfma_instance;
+    else if (!strcmp(key, "last_mfma_sym_rt")) *value = ctx->last_mfma_sym_rt;
     else if (!strcmp(key, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(key, "last_clock_khz")) {
         // median over the workgroups of the last stamped launch of (shader cycles) / (100 MHz ticks) x 100 MHz, in kHz; 0: none

@@ -50,6 +50,7 @@
 //   dense_mfma_sym_kernel / _sym_wide_kernel gramian(k, x), one point set: the upper triangle once, row AND column sums
 //                                            ("Symmetric Gramian" below); also rank r of P's share for the multi-GPU form.
 #include "dense_mfma.hpp"
+#include "dense_mfma_sym2.hpp"
 
 namespace covgram {
 
@@ -902,7 +903,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // chunks last, so the last round balances); >= 64 tiles — shorter chunks do not amortise a workgroup's prologue (rows, row
     // weights, first stage) —, >= 128 for a rank's share (tools/sym_tchunk_sweep.py, tools/sym_shard_probe.py: rank r of 8 at
     // C2 size 170-185 us with 128-tile chunks, 183-201 with 64)
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * (tpp == 4 ? 3 : 2) * (pstride > 1 ? 4 : 8);
+    const bool rt2_plan = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;     // 4-wave workgroups: three per CU
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * ((tpp == 4 || rt2_plan) ? 3 : 2) * (pstride > 1 ? 4 : 8);
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     tchunk = std::max<int64_t>(pstride > 1 ? 128 : 64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
@@ -962,6 +964,18 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
                                                     PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, \
                                                     KParams<float>{}, EF); break;
     ctx->last_mfma_instance = fast ? -(int64_t)(K2 * 10 + fmt) : 0;
+    // the EQ forms up to four MFMAs per tile: two row tiles per wave, 4-wave workgroups (dense_mfma_sym2.hpp) — option "mfma_sym_rt": -1 / 2 = that, 1 = the
+    // 8-wave one-row-tile kernel
+    const bool rt2 = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;
+    ctx->last_mfma_sym_rt = rt2 ? 2 : 1;
+#define CG_SYM2_CASE(F, K) case K: hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, EF); break;
+    if (rt2 && fmt) {
+        switch (K2) { CG_SYM2_CASE(FAM_EQFAST_H, 1) CG_SYM2_CASE(FAM_EQFAST_H, 2) CG_SYM2_CASE(FAM_EQFAST_H, 3) CG_SYM2_CASE(FAM_EQFAST_H, 4) default: break; }
+    } else if (rt2) {
+        switch (K2) { CG_SYM2_CASE(FAM_EQFAST, 1) CG_SYM2_CASE(FAM_EQFAST, 2) CG_SYM2_CASE(FAM_EQFAST, 3) CG_SYM2_CASE(FAM_EQFAST, 4) default: break; }
+    } else
+#undef CG_SYM2_CASE
     if (fast && fmt) {
         switch (K2) {
             CG_SYMH_CASE(1) CG_SYMH_CASE(2) CG_SYMH_CASE(3) CG_SYMH_CASE(4)

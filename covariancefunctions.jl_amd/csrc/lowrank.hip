@@ -86,6 +86,15 @@ __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ 
         T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
         if (k < r) {
             int64_t sl = part;
+            // 32 uncached loads in flight per thread (round 5; 8 before): this tail is pure memory latency — 512 slabs x 32 columns took eight
+            // dependent round trips of ~1.2 us behind the last slab (lowrank_vta_kernel 33.6 us against 24.1 for the equally long second pass)
+            for (; sl + 248 < nslab; sl += 256) {
+                T pv[32];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) pv[q] = slab_load(zpart + (sl + 8 * q) * r + k);
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { s0 += pv[q]; s1 += pv[q + 1]; s2 += pv[q + 2]; s3 += pv[q + 3]; }
+            }
             for (; sl + 56 < nslab; sl += 64) {
                 const T p0 = slab_load(zpart + sl * r + k), p1 = slab_load(zpart + (sl + 8) * r + k), p2 = slab_load(zpart + (sl + 16) * r + k),
                         p3 = slab_load(zpart + (sl + 24) * r + k), p4 = slab_load(zpart + (sl + 32) * r + k), p5 = slab_load(zpart + (sl + 40) * r + k),
@@ -137,13 +146,16 @@ __global__ __launch_bounds__(256) void lowrank_zsum_kernel(const T* __restrict__
 // y[i] = alpha * sum_k U[i + k*ldu] z[k] + beta * y[i]; VEC rows per thread, z in LDS
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void lowrank_uz_kernel(const T* __restrict__ U, int64_t ldu, int64_t n, int64_t r, const T* __restrict__ zg,
-                                                         T* __restrict__ y, T alpha, T beta) {
+                                                         T* __restrict__ y, T alpha, T beta, int32_t reverse) {
     using VT = typename VecOf<T, VEC>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* z = reinterpret_cast<T*>(smem);
     for (int64_t k = threadIdx.x; k < r; k += 256) z[k] = zg[k];
     __syncthreads();
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    // reverse (U is V, round 5): the first pass has just streamed this matrix front to back, so its LAST rows are the freshest lines of the
+    // Infinity Cache — the second pass walks it back to front
+    const int64_t blk = reverse ? (int64_t)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int64_t i = (blk * 256 + threadIdx.x) * VEC;
     if (i >= n) return;
     if (i + VEC <= n) {
         VT s = (VT)0;
@@ -170,7 +182,8 @@ static void lowrank_launch(covgram_ctx* ctx, const T* U, int64_t ldu, const T* V
     if (!ticket) hipLaunchKernelGGL(lowrank_zsum_kernel<T>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, ctx->stream, (const T*)zpart, nslab, r, z);
     const int64_t rows_per_block = 256 * VEC;
     hipLaunchKernelGGL((lowrank_uz_kernel<T, VEC>), dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(256), (size_t)r * sizeof(T),
-                       ctx->stream, U, ldu, n, r, (const T*)z, y, alpha, beta);
+                       ctx->stream, U, ldu, n, r, (const T*)z, y, alpha, beta,
+                       (ctx->lowrank_reverse == 1 || (ctx->lowrank_reverse < 0 && (const void*)U == (const void*)V && (size_t)n * r * sizeof(T) <= ((size_t)192 << 20))) ? 1 : 0);
 }
 
 template <typename T>
@@ -539,7 +552,7 @@ int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void
     // row slabs of V: ~4 workgroups per CU (GEMV form: ~2, i.e. at least two sweeps per slab at n = 2^20 — a slab of ONE sweep spends as long in
     // its 32-column LDS reduction as on its loads: 28.4 us at 4.7 TB/s for 134 MB), slab length a multiple of one sweep of the block (256 threads x 16 bytes)
     const int64_t sweep = 256 * (16 / (int64_t)ts);
-    const int64_t wg_per_cu = mfma ? 4 : 2;      // (1: 43.9 us, 2: 33.2, 4 or more: 36.4 — the last workgroup then adds 1024 partials per column)
+    const int64_t wg_per_cu = ctx->lowrank_wgs > 0 ? ctx->lowrank_wgs : (mfma ? 4 : 2);      // (1: 43.9 us, 2: 33.2, 4 or more: 36.4 — the last workgroup then adds 1024 partials per column)
     int64_t per = (m + (int64_t)ctx->num_cus * wg_per_cu - 1) / ((int64_t)ctx->num_cus * wg_per_cu);
     per = std::max<int64_t>(sweep, ((per + sweep - 1) / sweep) * sweep);
     const int64_t nslab = (m + per - 1) / per;

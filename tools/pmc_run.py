@@ -29,6 +29,13 @@ elif which in ("matern", "materngen", "f2", "f2gen", "maternshard"):   # round 5
     else:
         G = cg.gramian(k, X); y = torch.empty(n, dtype=torch.float32, device="cuda")
     for _ in range(K): G.mul_(y, a)
+elif which in ("c3sym", "c2sym"):                # the symmetric EQ kernel: rank 3 of 8's cyclic panels of C3 (d = 8, n = 524288) / all of C2's triangle
+    n, d = (524288, 8) if which == "c3sym" else (131072, 3)
+    X = torch.from_numpy(np.random.default_rng(0xC0F + 2).standard_normal((n, d)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    G = cg.gramian(cg.EQ(), X); y = torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(K):
+        if which == "c3sym": G.sym_partial_(y, a, 3, 8)
+        else: G.mul_(y, a)
 elif which == "shard8":
     n, per = 524288, 65536
     X = torch.from_numpy(np.random.default_rng(0xC0F + 2).standard_normal((n, 8)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
