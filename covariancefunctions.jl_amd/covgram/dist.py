@@ -74,7 +74,8 @@ def _all_gather_into(target: torch.Tensor, shard: torch.Tensor, group) -> None:
 # the kernels (covgram_mvm_sharded / covgram_mvm_sym_allreduce): torch.distributed only carries the 128-byte unique id once.  torch's own
 # collective stays as the route for gloo (CPU tests, host-staged), for process groups other than the default one, and when
 # COVGRAM_ABI_COLLECTIVE=0 asks for it (bench.py times both).
-_ABI_COMM = {}          # device index -> (rank, world) of the communicator the ctx owns
+_ABI_COMM = {}          # device index -> (rank, world) of the communicator the ctx owns; None: creation failed on some rank, torch's route for good
+_ABI_FAILED = []        # why (reprs), for the bench line
 
 
 def abi_comm(device: torch.device, group=None) -> bool:
@@ -92,8 +93,11 @@ def abi_comm(device: torch.device, group=None) -> bool:
     from .gramian import get_ctx
     rank, world = dist.get_rank(), dist.get_world_size()
     ctx = get_ctx(device)
-    if _ABI_COMM.get(device.index) == (rank, world):
-        return True
+    if device.index in _ABI_COMM:
+        if _ABI_COMM[device.index] is None:
+            return False
+        if _ABI_COMM[device.index] == (rank, world):
+            return True
     lib = _ffi.lib()
     ident = [None]
     if rank == 0:
@@ -103,7 +107,23 @@ def abi_comm(device: torch.device, group=None) -> bool:
     if world > 1:
         dist.broadcast_object_list(ident, src=0)             # the only thing torch.distributed moves for this route
     raw = (C.c_ubyte * _ffi.COMM_ID_BYTES).from_buffer_copy(ident[0])
-    _ffi.check(lib.covgram_comm_create(ctx.handle, C.cast(raw, C.c_void_p), rank, world))
+    ok = 1
+    try:
+        _ffi.check(lib.covgram_comm_create(ctx.handle, C.cast(raw, C.c_void_p), rank, world))
+    except Exception as e:                                   # e.g. an RCCL build the library cannot load: every rank must take the same route
+        ok = 0
+        _ABI_FAILED.append(repr(e))
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        agreed = int(flag.item())
+    else:
+        agreed = ok
+    if not agreed:
+        if ok:
+            lib.covgram_comm_destroy(ctx.handle)
+        _ABI_COMM[device.index] = None
+        return False
     _ABI_COMM[device.index] = (rank, world)
     return True
 

@@ -559,6 +559,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "sum_fused")) ctx->sum_fused = value;
     else if (!strcmp(key, "lowrank_reverse")) ctx->lowrank_reverse = value;
     else if (!strcmp(key, "mfma_sym_rt")) ctx->mfma_sym_rt = value;
+    else if (!strcmp(key, "mfma_sym_st")) ctx->mfma_sym_st = value;
     else if (!strcmp(key, "lowrank_wgs")) ctx->lowrank_wgs = value;
     else if (!strcmp(key, "time_kernels")) { ctx->time_kernels = value; ctx->timers_used = 0; }
     else { set_error("unknown option '%s'", key); return COVGRAM_EINVAL; }

@@ -253,6 +253,7 @@ struct covgram_ctx {
     int64_t lds_pad = 0;         // occupancy experiments: dynamic LDS bytes per dense workgroup
     int64_t mfma_sym_rt = -1;    // symmetric matrix-core EQ kernel: row tiles per wave (-1 / 2: two, 4-wave workgroups, dense_mfma_sym2.hpp; 1: one, 8-wave workgroups)
     int64_t last_mfma_sym_rt = 0;
+    int64_t mfma_sym_st = 0;     // symmetric matrix-core kernels with 4-wave workgroups: column tiles per stage (0 = auto: 8 where three workgroups still fit a CU's LDS, 4 = always four)
     int64_t lowrank_wgs = 0;      // low rank: row slabs of the first pass per CU (0 = auto: 2, matrix right-hand sides 4)
     int64_t lowrank_reverse = -1; // low rank U (V' a), one right-hand side: the second pass walks U back to front (-1: when U is V and fits the Infinity Cache, 0 never, 1 always)
     int64_t sum_fused = -1;      // fp32 Sum of 2-3 single-profile isotropic terms: one pass of the matrix-core kernels over the shared distance (-1 / 1 where they apply, 0: one MVM per term)

@@ -968,7 +968,9 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // 8-wave one-row-tile kernel
     const bool rt2 = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;
     ctx->last_mfma_sym_rt = rt2 ? 2 : 1;
-#define CG_SYM2_CASE(F, K) case K: hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+#define CG_SYM2_CASE(F, K) case K: if (K <= 2 && ctx->mfma_sym_st != 4) hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K, (K <= 2 ? 8 : 4)>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, EF); \
+                                   else hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K, 4>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
                                                       PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, EF); break;
     if (rt2 && fmt) {
         switch (K2) { CG_SYM2_CASE(FAM_EQFAST_H, 1) CG_SYM2_CASE(FAM_EQFAST_H, 2) CG_SYM2_CASE(FAM_EQFAST_H, 3) CG_SYM2_CASE(FAM_EQFAST_H, 4) default: break; }

@@ -17,14 +17,16 @@
 
 namespace covgram {
 
-template <int FAM, int K2>
+// ST_: column tiles per stage (one barrier, one round of LDS-DMA issues, weight reads and column-sum flushes per stage): 8 where the LDS allows
+// three workgroups per CU (K2 <= 2: 49 KB each), else 4
+template <int FAM, int K2, int ST_ = (K2 <= 2 ? 8 : 4)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym2_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
     int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const float* __restrict__ EF) {
     static_assert(FAM == FAM_EQFAST || FAM == FAM_EQFAST_H, "the two-row-tile form is the EQ kernel's");
     constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
-    constexpr int NW = 4, RT = 2, TPP = NW * RT, ST = 4;            // 8 row tiles per panel, stages of 4 column tiles (one fetched by each wave)
+    constexpr int NW = 4, RT = 2, TPP = NW * RT, ST = ST_, SPW = ST / NW;   // 8 row tiles per panel; stages of ST column tiles, SPW fetched (and later flushed) by each wave
     auto wt = [&](int64_t j) { return j < n ? W[j] * EF[j] : 0.0f; };
     const int32_t wm = wgmap[blockIdx.x];
     const int64_t lp = wm >> 12;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int nstage = (nt + ST - 1) / ST;
-    float gw = 0.0f;
+    float gw[SPW];
     // one column tile against both row tiles: E once per row tile, row sums with the column weight, column sums of both row tiles in one pair of
     // register accumulators.  MASKED (stages that touch the panel's diagonal block): row tile I takes row sums from tiles J >= I, column sums from J > I.
     auto process = [&](auto masked, const Frag (&f)[K2], float w, int64_t J, float& cpart) {
@@ -104,13 +106,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         cpart = (c01[0] + c01[1]) + (c23[0] + c23[1]);
     };
 #define CG2_DMA(stage, SF)                                                                      \
-        {                                                                                       \
-            const int ti_ = (stage) * ST + wv;                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < SPW; ++q_) {                                    \
+            const int ti_ = (stage) * ST + wv + NW * q_;                                        \
             const int tc_ = ti_ < nt ? ti_ : nt - 1;                                            \
             _Pragma("unroll") for (int mm = 0; mm < K2; ++mm)                                   \
-                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv][mm][0], 16, 0, 0); \
-            gw = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);                            \
+                __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&SF[wv + NW * q_][mm][0], 16, 0, 0); \
+            gw[q_] = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);                        \
         }
+#define CG2_PUTW(SW) if (h == 0) { _Pragma("unroll") for (int q_ = 0; q_ < SPW; ++q_) SW[wv + NW * q_][t] = gw[q_]; }
     /* one column tile per iteration: the two row tiles already give the wave two independent MFMA chains and 32 exponentials to overlap, and a second \
        column tile's fragments and results in flight spilled (48-100 B at K2 <= 2, 500 B at K2 = 4) */ \
 #define CG2_STAGE_M(M_, st_, SF, SW, CS)                                                        \
@@ -127,32 +130,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         else { CG2_STAGE_M(true, st_, SF, SW, CS) }
     // after the stage's barrier: wave w adds the 4 waves x 2 half-waves' column sums of tile w of that stage (fixed order)
 #define CG2_FLUSH(st_, CS)                                                                      \
-        {                                                                                       \
-            const int64_t J_ = T0 + (int64_t)(st_) * ST + wv;                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < SPW; ++q_) {                                    \
+            const int64_t J_ = T0 + (int64_t)(st_) * ST + wv + NW * q_;                         \
             if (h == 0 && J_ < T1) {                                                            \
                 float s_ = 0.0f;                                                                \
-                _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][wv][t] + CS[w_][wv][32 + t]; \
+                _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) s_ += CS[w_][wv + NW * q_][t] + CS[w_][wv + NW * q_][32 + t]; \
                 S[lp * npad + 32 * J_ + t] = s_;                                                \
             }                                                                                   \
         }
     CG2_DMA(0, sfA)
-    if (h == 0) swA[wv][t] = gw;
+    CG2_PUTW(swA)
     __syncthreads();
     for (int st = 0; st < nstage; st += 2) {
         CG2_DMA(st + 1 < nstage ? st + 1 : st, sfB)
         if (st > 0) CG2_FLUSH(st - 1, csB)
         CG2_STAGE(st, sfA, swA, csA)
-        if (h == 0) swB[wv][t] = gw;
+        CG2_PUTW(swB)
         __syncthreads();
         if (st + 1 >= nstage) { CG2_FLUSH(st, csA) break; }
         CG2_DMA(st + 2 < nstage ? st + 2 : st + 1, sfA)
         CG2_FLUSH(st, csA)
         CG2_STAGE(st + 1, sfB, swB, csB)
-        if (h == 0) swA[wv][t] = gw;
+        CG2_PUTW(swA)
         __syncthreads();
         if (st + 2 >= nstage) { CG2_FLUSH(st + 1, csB) }
     }
 #undef CG2_DMA
+#undef CG2_PUTW
 #undef CG2_STAGE
 #undef CG2_STAGE_M
 #undef CG2_FLUSH
