@@ -1249,21 +1249,28 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
     // two right-hand sides per pass where the lane-per-row kernel is compiled for it (grad_mvm.hpp: r, s, phi', phi'' once per pair)
     const bool two_ok = !wide && m > 0 && hk.k.power == 1 && grad_two_rhs_ok(ts, D, hk.tu_family);
     // expanded form (grad_mvm.hpp): fp64 isotropic simple profiles whose pre-scaled clouds lie within the radius gate
-    const bool expd_ok = !wide && m > 0 && iso && dtype == COVGRAM_F64 && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 &&
+    // fp32 (round 5): the same form inside GRAD_EXPAND_GATE_F32 — there the absolute error of s is a few fp32 roundings of R^2, what the fp32
+    // matrix-core dense kernels carry inside their gate of the same size (dense_mfma.hip), measured at the gate in tests/test_gpu_grad_expand32.py
+    const double expand_gate = dtype == COVGRAM_F64 ? GRAD_EXPAND_GATE : GRAD_EXPAND_GATE_F32;
+    const bool expd_ok = !wide && m > 0 && iso && hk.tu_family < COVGRAM_NFAMILY && ctx->grad_keep_r != 1 && !(dtype == COVGRAM_F32 && hk.k.power != 1) &&
                           (ctx->grad_expand == 1 ||
                            // measured (tools/c4_expand_ab.py, profiles/r02_c4_expand_ab.txt): pays from d = 8 (C4 0.86x, d = 8 0.95x,
                            // d = 3 +4 %); MaternP(p >= 1) 0.89x since its exp(-r) is the library's own (it was +3 % with the
                            // 34-instruction one).  Never by default for the profiles that are singular at s = 0 (exponential,
                            // gamma-exponential, MaternP(0)): their diagonal blocks are NaN in the reference (inf * 0), which the
                            // exact zero of a direct difference reproduces and the rounded zero of the expanded form would not
-                           (ctx->grad_expand < 0 && D >= 8 && hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
+                           // fp32 (tools/grad32_expand_ab.py, profiles/r05_grad32_expand_ab.txt, n = 16384): EQ d = 32 994 -> 828 us, d = 48 (n = 8192) 523 -> 391,
+                           // d = 16 552 -> 457; RQ 0.85-0.94x; MaternP only from d = 32 (d = 8, 16: 1.12-1.19x — its jet's square root and the
+                           // expanded form's clamp sit in front of a shorter dimension loop)
+                           (ctx->grad_expand < 0 && D >= 8 && !(dtype == COVGRAM_F32 && hk.tu_family == COVGRAM_MATERNP && D < 32) &&
+                            hk.tu_family != COVGRAM_MATERN && hk.tu_family != COVGRAM_EXP &&
                             hk.tu_family != COVGRAM_GAMMAEXP && !(hk.tu_family == COVGRAM_MATERNP && hk.k.p == 0) &&
-                            hk.kp.gamma2 * gate_radius2(X, Y) <= GRAD_EXPAND_GATE));
+                            hk.kp.gamma2 * gate_radius2(X, Y) <= expand_gate));
     // round 4: the expanded form with the column records in VGPRs (grad_bcast.hpp; option "grad_bcast": -1 auto, 0 never, 1 / 4 = with
     // that many waves per workgroup).  One right-hand side per pass: where it applies, matrix right-hand sides run column by column on it
     // (C4 shape: 2 x 1.36 ms against 3.30 ms for the scalar-stream kernel's two-column pass)
     int bcast_sel = 0;
-    if (expd_ok && hk.k.power == 1 && grad_bcast_ok(D) && hk.tu_family != COVGRAM_MATERN && ctx->grad_bcast != 0)
+    if (expd_ok && dtype == COVGRAM_F64 && hk.k.power == 1 && grad_bcast_ok(D) && hk.tu_family != COVGRAM_MATERN && ctx->grad_bcast != 0)
         bcast_sel = ctx->grad_bcast == 1 ? 1 : (ctx->grad_bcast == 4 ? 4 : GRAD_BCAST_AUTO(D));
     for (int c0 = 0; c0 < nrhs;) {
     const int nr = (two_ok && !bcast_sel && c0 + 1 < nrhs) ? 2 : 1;
@@ -1346,9 +1353,12 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn, nr, lda_d);
-        if (expd)
+        if (expd && dtype == COVGRAM_F64)
             hipLaunchKernelGGL(grad_pack_extra_kernel<double>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, d,
                                (const double*)a_dev, hk.kp.gamma, vg, (const double*)Cn, (double*)Ex, nr, lda_d);
+        else if (expd)
+            hipLaunchKernelGGL(grad_pack_extra_kernel<float>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d,
+                               (const float*)a_dev, (float)hk.kp.gamma, vg, (const float*)Cn, (float*)Ex, nr, lda_d);
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)

@@ -411,6 +411,7 @@ constexpr double MFMA_GATE = 126.0;
 // on the gate's sphere and aligned (tests: "wide aligned") — measured 1.09e-5 row-wise at g^2 R^2 = 96 against the bf16 split's 7.2e-6, growing
 // linearly with the bound: 8.2e-6 at 72, what the bf16 split shows at 110 of its 126 (tools/f16_split_ab.py: typical clouds differ by < 10 %)
 constexpr double MFMA_F16_GATE = 72.0;
+constexpr double GRAD_EXPAND_GATE_F32 = 128.0;   // the same form in fp32 (round 5): abs. error of s a few fp32 roundings of R^2 — the size of the fp32 matrix-core gate
 constexpr double GRAD_EXPAND_GATE = 1000.0;   // gamma^2 R^2 up to which the fp64 gradient kernel expands |x - y|^2 (abs. error ~1e-16 R^2; grad_mvm.hpp)
 double gate_radius2(const covgram_points* X, const covgram_points* Y);
 int points_max_norm2(covgram_points* p);

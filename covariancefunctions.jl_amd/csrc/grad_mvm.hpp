@@ -20,7 +20,9 @@
 // 4 fma per dimension and pair, a third fewer instructions on a kernel that is fp64-VALU bound.  s and c2 (x' - y') are then
 // differences of O(|x'|^2) terms instead of direct differences (src/util.jl:40-47): the absolute error is ~1e-16 R^2 (R = the
 // radius of the pre-scaled cloud about the common centre), so the form is used while R^2 <= GRAD_EXPAND_GATE = 1000 — C4:
-// R^2 ~ 90, measured rel-err 3e-15 — and never in fp32.  Option "grad_expand": -1 this rule, 0 never, 1 always (tests).
+// R^2 ~ 90, measured rel-err 3e-15.  fp32 (round 5): the same form while R^2 <= GRAD_EXPAND_GATE_F32 = 128 — s then carries a few fp32 roundings of R^2, as the fp32
+// matrix-core dense kernels do inside their gate; a third fewer VALU instructions on a kernel that is 87 % VALU-busy (profiles/r05_grad32_pmc.txt).
+// Option "grad_expand": -1 these rules, 0 never, 1 always (tests).
 //
 // Software pipeline of the scalar stream.  The state (x_i, b_i [, r]) costs 2-3 d-vectors of VGPRs, so wide fp64 rows
 // run at 2 waves per SIMD and cannot hide scalar-load latency by occupancy: rocprofv3 showed 61 % of the wave cycles of
@@ -486,7 +488,7 @@ static int launch_grad_one(const GradArgs& a) {
     if constexpr (grad_two_rhs_ok(sizeof(T), D, FAM)) {
         if (a.nr == 2) {
             bool x2 = false;
-            if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
+            if constexpr (fam_is_iso<FAM> && !fam_is_expr<FAM>) {
                 if (a.expd) { if (a.vg) CG_GRAD_LAUNCH_N(false, false, true, true, 2); else CG_GRAD_LAUNCH_N(false, false, false, true, 2); x2 = true; }
             }
             if (!x2) { if (a.vg) CG_GRAD_LAUNCH_N(false, false, true, false, 2); else CG_GRAD_LAUNCH_N(false, false, false, false, 2); }
@@ -494,10 +496,14 @@ static int launch_grad_one(const GradArgs& a) {
         }
     }
     if (!done && a.nr != 1) { set_error("grad_mvm: %d right-hand sides per launch are not compiled for this shape", a.nr); return COVGRAM_EUNSUPPORTED; }
-    if constexpr (sizeof(T) == 8 && fam_is_iso<FAM> && !fam_is_expr<FAM>) {
-        if (!done && a.expd) {   // expanded form: 4 fma per dimension and pair (header)
-            if (a.vg) { if (pow) CG_GRAD_LAUNCH_N(false, POWT, true, true, 1); else CG_GRAD_LAUNCH_N(false, false, true, true, 1); }
-            else { if (pow) CG_GRAD_LAUNCH_N(false, POWT, false, true, 1); else CG_GRAD_LAUNCH_N(false, false, false, true, 1); }
+    if constexpr (fam_is_iso<FAM> && !fam_is_expr<FAM>) {
+        if (!done && a.expd) {   // expanded form: 4 fma per dimension and pair (header); fp32: without a Power wrapper (the host's rule)
+            if constexpr (sizeof(T) == 8) {
+                if (a.vg) { if (pow) CG_GRAD_LAUNCH_N(false, POWT, true, true, 1); else CG_GRAD_LAUNCH_N(false, false, true, true, 1); }
+                else { if (pow) CG_GRAD_LAUNCH_N(false, POWT, false, true, 1); else CG_GRAD_LAUNCH_N(false, false, false, true, 1); }
+            } else {
+                if (a.vg) CG_GRAD_LAUNCH_N(false, false, true, true, 1); else CG_GRAD_LAUNCH_N(false, false, false, true, 1);
+            }
             done = true;
         }
     }

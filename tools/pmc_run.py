@@ -46,6 +46,11 @@ elif which == "grad":
     X = torch.from_numpy(rng.standard_normal((n, d))).cuda(); a = torch.from_numpy(rng.standard_normal(n * d)).cuda()
     G = cg.gramian(cg.GradientKernel(cg.EQ()), X); y = torch.empty(n * d, dtype=torch.float64, device="cuda")
     for _ in range(K): G.mul_(y, a)
+elif which == "grad32":                          # the C4 shape in fp32: GradientKernel(EQ), d = 32, n = 16384 (the scalar-stream lane-per-row kernel)
+    n, d = 16384, 32
+    X = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n * d).astype(np.float32)).cuda()
+    G = cg.gramian(cg.GradientKernel(cg.EQ()), X); y = torch.empty(n * d, dtype=torch.float32, device="cuda")
+    for _ in range(K): G.mul_(y, a)
 elif which == "c1":
     n = 4096
     X = torch.from_numpy(rng.standard_normal((n, 3))).cuda(); a = torch.from_numpy(rng.standard_normal(n)).cuda()
