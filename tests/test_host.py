@@ -354,3 +354,59 @@ def test_post_build_isa_lint():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py"), "lint"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("ok:") >= 6, r.stdout
+
+
+def test_docs_quote_the_recorded_numbers():
+    """VERDICT r3 and r4 both found the READMEs quoting headline numbers that the recorded files do not hold.  The marked statements — README.md's
+    headline block, and every profiles/README.md row tagged <!-- check:rNN --> — must agree within 2 % with profiles/rNN_bench_n1.json and the
+    rocprofv3 stats CSV of the same round."""
+    import csv
+    import glob
+    import json
+
+    def close(a, b, what):
+        assert abs(a - b) <= 0.02 * abs(b), f"{what}: the text says {a}, the recorded file says {b}"
+
+    def recorded(rnd):
+        line = json.loads([x for x in open(os.path.join(ROOT, "profiles", f"{rnd}_bench_n1.json")) if x.startswith("{")][0])
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_kernel_stats.csv"))))
+        inst = line["roofline"].get("kernel_instance") or "dense_mfma_eq_kernel<1, 2, 8, 1, 0, 1>"
+        k = [r for r in rows if inst.replace("covgram::", "") in r["Name"]]
+        assert k, f"{rnd}: the stats CSV has no row for {inst}"
+        return line, k[0]
+
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_n1.json")))[-1]
+    rnd = os.path.basename(latest)[:3]
+    line, krow = recorded(rnd)
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    assert f"profiles/{rnd}_bench_n1.json" in readme, f"README.md does not cite the latest record {rnd}_bench_n1.json"
+    block = re.search(r"<!-- headline:begin -->(.*?)<!-- headline:end -->", readme, re.S).group(1)
+    m = re.search(r"\*\*([\d.]+) MVM/s\*\*, ([\d.]+) ms per step, kernel ([\d.]+) ms,\s*`roofline.frac` ([\d.]+), `issue_roofline_frac` ([\d.]+); rocprofv3 average of the same "
+                  r"kernel under the profiler ([\d.]+) ms over (\d+) dispatches", block)
+    assert m, "README.md: the headline sentence does not have the checked form"
+    close(float(m.group(1)), line["value"], "README value")
+    close(float(m.group(2)), line["ms_per_step"], "README ms_per_step")
+    close(float(m.group(3)), line["roofline"]["kernel_avg_ms"], "README kernel_avg_ms")
+    close(float(m.group(4)), line["roofline"]["frac"], "README roofline.frac")
+    close(float(m.group(5)), line["roofline"]["issue_roofline_frac"], "README issue_roofline_frac")
+    close(float(m.group(6)), float(krow["AverageNs"]) * 1e-6, "README profiled average")
+    assert int(m.group(7)) == int(krow["Calls"])
+    m = re.search(r"`symmetric_variant`\): ([\d.]+) MVM/s, ([\d.]+) ms per step", block)
+    close(float(m.group(1)), line["symmetric_variant"]["value"], "README symmetric value")
+    m = re.search(r"`direct_difference_variant`\): ([\d.]+) MVM/s", block)
+    close(float(m.group(1)), line["direct_difference_variant"]["value"], "README direct-difference value")
+    m = re.search(r"`cpu_baseline`\): ([\d.]+) MVM/s", block)
+    close(float(m.group(1)), line["cpu_baseline"]["value"], "README cpu_baseline")
+    # profiles/README.md: every tagged row against its own round's files
+    pr = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    tags = re.findall(r"<!-- check:(r\d\d) -->([^\n]*)", pr)
+    assert rnd in [t for t, _ in tags], f"profiles/README.md has no checked row for {rnd}"
+    for tag, row in tags:
+        l2, k2 = recorded(tag)
+        m = re.search(r"contract run ([\d.]+) MVM/s, live `kernel_avg_ms` ([\d.]+), profiled average ([\d.]+) ms over (\d+) dispatches.*?`roofline.frac` ([\d.]+)", row)
+        assert m, f"profiles/README.md row {tag}: not in the checked form"
+        close(float(m.group(1)), l2["value"], f"{tag} value")
+        close(float(m.group(2)), l2["roofline"]["kernel_avg_ms"], f"{tag} kernel_avg_ms")
+        close(float(m.group(3)), float(k2["AverageNs"]) * 1e-6, f"{tag} profiled average")
+        assert int(m.group(4)) == int(k2["Calls"])
+        close(float(m.group(5)), l2["roofline"]["frac"], f"{tag} roofline.frac")

@@ -8,7 +8,7 @@ n = 1 << 22
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 variants = [(0, 0), (1, 0), (512, 0), (128, 0)]
 try:
-    cg.set_option("toeplitz_colpersist", 0)
+    cg.set_option("toeplitz_persist", 0)
     variants += [(0, 1), (1, 1), (1, 2)]
 except Exception:
     pass
@@ -19,7 +19,7 @@ for dt in (torch.float64, torch.float32):
     for rep in range(5):
         for v in variants:
             cg.set_option("toeplitz_persist", v[0])
-            if len(variants) > 4: cg.set_option("toeplitz_colpersist", v[1])
+            # (the column kernel's persistent variant of round 4 — option toeplitz_colpersist — did not pay and was removed with its option)
             for _ in range(5): T.mul_(y, a)
             torch.cuda.synchronize(); e0.record()
             for _ in range(50): T.mul_(y, a)
