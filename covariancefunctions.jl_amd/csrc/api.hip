@@ -538,6 +538,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
     else if (!strcmp(key, "toeplitz_persist")) ctx->toeplitz_persist = value;
     else if (!strcmp(key, "mfma_f16")) ctx->mfma_f16 = value;
+    else if (!strcmp(key, "mfma_gate_pct")) { CG_REQUIRE(value >= 1 && value <= 100, COVGRAM_EINVAL, "mfma_gate_pct = %lld: 1..100", (long long)value); ctx->mfma_gate_pct = value; }
     else if (!strcmp(key, "mfma_fuse_w")) ctx->mfma_fuse_w = value;
     else if (!strcmp(key, "toeplitz_real_spectrum")) ctx->toeplitz_real_spectrum = value;
     else if (!strcmp(key, "rows_per_lane")) ctx->rows_per_lane = value;

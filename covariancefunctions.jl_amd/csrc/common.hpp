@@ -281,6 +281,7 @@ struct covgram_ctx {
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
     int64_t mfma_fuse_w = -1;      // general matrix-core EQ kernel: the column weights a_j exp2(f_j) formed in the kernel (-1 / 1) or by a pack launch in front of it (0)
+    int64_t mfma_gate_pct = 100;   // both radius gates of the fp32 matrix-core kernels, in percent of MFMA_GATE / MFMA_F16_GATE (1..100): the worst-case ROW-wise error scales with the gate (profiles/r05_gate_scan.txt)
     int64_t mfma_f16 = -1;         // general matrix-core EQ kernel: the fp16 two-way split (half the MFMAs per tile): -1 / 1 = within MFMA_F16_GATE, 0 = never, 2 = within MFMA_GATE (measurements only)
     int64_t last_mfma_f16 = 0;
     int64_t last_mfma_instance = 0;   // template arguments of the last matrix-core EQ kernel launched: K2 1e5 + RT 1e4 + WPB 1e3 + LDS 100 + STAMP 10 + FMT (general), -(K2 10 + FMT) (symmetric), 0 other
@@ -411,6 +412,8 @@ constexpr double MFMA_GATE = 126.0;
 // on the gate's sphere and aligned (tests: "wide aligned") — measured 1.09e-5 row-wise at g^2 R^2 = 96 against the bf16 split's 7.2e-6, growing
 // linearly with the bound: 8.2e-6 at 72, what the bf16 split shows at 110 of its 126 (tools/f16_split_ab.py: typical clouds differ by < 10 %)
 constexpr double MFMA_F16_GATE = 72.0;
+inline double mfma_gate_of(const covgram_ctx* ctx) { return MFMA_GATE * 0.01 * (double)ctx->mfma_gate_pct; }
+inline double mfma_f16_gate_of(const covgram_ctx* ctx) { return MFMA_F16_GATE * 0.01 * (double)ctx->mfma_gate_pct; }
 constexpr double GRAD_EXPAND_GATE_F32 = 128.0;   // the same form in fp32 (round 5): abs. error of s a few fp32 roundings of R^2 — the size of the fp32 matrix-core gate
 constexpr double GRAD_EXPAND_GATE = 1000.0;   // gamma^2 R^2 up to which the fp64 gradient kernel expands |x - y|^2 (abs. error ~1e-16 R^2; grad_mvm.hpp)
 double gate_radius2(const covgram_points* X, const covgram_points* Y);

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
 __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restrict__ Y, int64_t m, int32_t d, const float* __restrict__ A,
                                                             int64_t lda, int32_t nrhs, int32_t c0, uint4* __restrict__ PB,
                                                             float* __restrict__ W, int32_t K2, int32_t NR, float g, int32_t iso,
-                                                            const float* __restrict__ Cn) {
+                                                            const float* __restrict__ Cn, int32_t fmt) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, mm, lane)
     const int64_t ntile = (m + 31) / 32;
     if (e >= ntile * K2 * 64) return;
@@ -383,6 +383,22 @@ __global__ __launch_bounds__(256) void mfma_pack_gen_kernel(const float* __restr
     const int64_t j = 32 * T + (l & 31);
     const int c = 2 * mm + (l >> 5);
     uint4 frag = make_uint4(0, 0, 0, 0);
+    if (fmt == 1) {
+        // fp16 two-way split (dense_mfma.hpp: gen_row_fragments, GFMT = 1): positions q0 = 4 mm + 2 h and q0 + 1, three slots each — a coordinate
+        // [y1, y2, y1] of -2 g (y - c), the row norm's position d as [1, 1, 1], the column norm at d + 1 as [k, f1, f2]
+        if (j < m) {
+            float ny = 0.0f;
+            for (int cc = 0; cc < d; ++cc) { const float yc = g * (Y[j * (int64_t)d + cc] - Cn[cc]); ny = __builtin_fmaf(yc, yc, ny); }
+            unsigned sl[6] = {0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < 2; ++w) {
+                const int qq = 4 * mm + 2 * (l >> 5) + w;
+                if (qq < d) { unsigned y1, y2; split2h(-2.0f * (g * (Y[j * (int64_t)d + qq] - Cn[qq])), y1, y2); sl[3 * w] = y1; sl[3 * w + 1] = y2; sl[3 * w + 2] = y1; }
+                else if (qq == d) { sl[3 * w] = sl[3 * w + 1] = sl[3 * w + 2] = F16_ONE; }
+                else if (qq == d + 1) { const Norm16 nn = norm16(ny); sl[3 * w] = nn.k; sl[3 * w + 1] = nn.f1; sl[3 * w + 2] = nn.f2; }
+            }
+            frag = make_uint4(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), sl[4] | (sl[5] << 16), 0u);
+        }
+    } else
     if (j < m) {
         if (c < d) {
             const float yt = iso ? -2.0f * (g * (Y[j * (int64_t)d + c] - Cn[c])) : g * Y[j * (int64_t)d + c];
@@ -534,7 +550,7 @@ bool mfma_eq_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgra
     if (X->d > 32 || Y->n == 0) return false;                   // beyond d = 32 the fragments leave one wave per SIMD
     if (ctx->dense_variant == 2) return true;
     const double g2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale);   // |x~|^2 = g2 |x|^2
-    return g2 * gate_radius2(X, Y) <= MFMA_GATE;                 // BOTH sides: a far X cluster must not ride on a compact Y
+    return g2 * gate_radius2(X, Y) <= mfma_gate_of(ctx);                 // BOTH sides: a far X cluster must not ride on a compact Y
 }
 
 // resident single-wave workgroups per CU of the kernel instance (register-limited), for the grid sizing below
@@ -640,7 +656,7 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
     // accumulator's own: common.hpp); beyond it, up to MFMA_GATE, the bf16 split serves as before.  Option "mfma_f16": -1 / 1 = this rule,
     // 0 = never, 2 = wherever the matrix-core gate admits the cloud (measurements: tools/f16_split_ab.py).
     const double g2r2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale) * gate_radius2(X, Y);
-    const int fmt = (ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? MFMA_GATE : MFMA_F16_GATE)) ? 1 : 0;
+    const int fmt = (ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? mfma_gate_of(ctx) : mfma_f16_gate_of(ctx))) ? 1 : 0;
     ctx->last_mfma_f16 = fmt;
     const int K2 = fmt ? eq_k2_for(2 * ((d + 3) / 4)) : eq_k2_for(d);      // fp16: one MFMA per four coordinates
     CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma: d = %d has no matrix-core instance", d);
@@ -824,6 +840,7 @@ bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const co
 }
 
 static int mfma_k2_for(int dims);
+static int mfma_gen_fmt(const covgram_ctx* ctx, const HostKernel& hk, int lfam, const covgram_points* X, const covgram_points* Y, int maxk2, int* K2);
 static int mfma_family_of(const covgram_ctx* ctx, const HostKernel& hk, float* gamma);
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs);
 // the generic profiles' symmetric form: same conditions on top of the generic matrix-core gate (hk: gamma = 1/l parameter block)
@@ -864,9 +881,17 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // EQ form: the fp16 two-way split inside its gate, as the general kernel (mvm_eq_mfma, "Which split"); every rank of a multi-GPU call sees the same
     // cloud and lengthscale, hence the same split and the same panel size
     const double g2r2 = 1.4426950408889634074 / (hk.k.lengthscale * hk.k.lengthscale) * gate_radius2(X, X);
-    const int fmt = (fast && ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? MFMA_GATE : MFMA_F16_GATE)) ? 1 : 0;
+    const int fmt = (fast && ctx->mfma_f16 != 0 && g2r2 <= (ctx->mfma_f16 == 2 ? mfma_gate_of(ctx) : mfma_f16_gate_of(ctx))) ? 1 : 0;
     if (fast) ctx->last_mfma_f16 = fmt;
-    const int K2 = fast ? (fmt ? eq_k2_for(2 * ((d + 3) / 4)) : eq_k2_for(d)) : mfma_k2_for(d + (iso ? 1 : 0));
+    int K2 = fast ? (fmt ? eq_k2_for(2 * ((d + 3) / 4)) : eq_k2_for(d)) : mfma_k2_for(d + (iso ? 1 : 0));
+    // generic form: the fp16 split where the staged (narrow) symmetric kernel of the family has the instance (dense_mfma.hpp: mfma_sym_narrow_maxk2)
+    int gfmt = 0;
+    if (!fast) {
+        int k2h = 0;
+        gfmt = mfma_gen_fmt(ctx, hku, lfam, X, X, lfam == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2, &k2h);
+        if (gfmt) K2 = k2h;
+        ctx->last_mfma_f16 = gfmt;
+    }
     CG_REQUIRE(K2 > 0, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: d = %d has no matrix-core instance", d);
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
@@ -893,7 +918,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         float* Wg = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, a,
-                           n, 1, 0, PB, Wg, K2, 1, gamg, iso ? 1 : 0, Cn);
+                           n, 1, 0, PB, Wg, K2, 1, gamg, iso ? 1 : 0, Cn, gfmt);
         PBu = PB; W = Wg;
     }
     // column chunk: a multiple of the 4-tile stage; ~8 rounds of the resident workgroups (2 per CU) over the triangle
@@ -995,7 +1020,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PBu; ma.W = W; ma.ntile = ntile; ma.out = nullptr; ma.npad = npad; ma.ldy = n;
         ma.nrhs = 1; ma.tchunk = tchunk; ma.alpha = 1.0f; ma.beta = 0.0f; ma.final_store = 0; ma.K2 = K2; ma.RT = 1; ma.NR = 1;
         ma.hk = &hku; ma.stream = ctx->stream; ma.grid = grid; ma.Cn = Cn;
-        ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride;
+        ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride; ma.fmt = gfmt;
         mfma_launch_fn launch = mfma_launcher(lfam);
         CG_REQUIRE(launch != nullptr, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: family %d has no matrix-core path", lfam);
         rc = launch(ma, false);
@@ -1036,6 +1061,24 @@ mfma_launch_fn mfma_launcher(int family) {
     }
 }
 
+// The generic kernels' split of the coordinates (round 5): the fp16 two-way split (dense_mfma.hpp: gen_row_fragments) for the isotropic single
+// profiles and one-pass Sums while (a) its instance exists — d + 2 positions in at most `maxk2` MFMAs of four —, and (b) the cloud lies inside
+// MFMA_F16_GATE / MFMA_GATE of the generic radius gate (gate_frac: the quantity mfma_gen_eligible admits up to 1), the EQ kernel's rule
+// (option "mfma_f16": 0 never, 2 wherever the matrix-core gate admits the cloud).  Returns the format and sets the MFMAs per tile.
+static double mfma_gen_gate_frac(const HostKernel& hk, const covgram_points* X, const covgram_points* Y);
+static int mfma_gen_fmt(const covgram_ctx* ctx, const HostKernel& hk, int lfam, const covgram_points* X, const covgram_points* Y, int maxk2, int* K2) {
+    const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
+    const int d = X->d;
+    *K2 = mfma_k2_for(d + (iso ? 1 : 0));
+    if (ctx->mfma_f16 == 0 || !iso || lfam == FAM_EXPR_ISO || lfam == FAM_EXPR_DOT) return 0;
+    const int k2h = (d + 2 + 3) / 4;
+    if (k2h > maxk2 || k2h > 4) return 0;
+    const double frac = mfma_gen_gate_frac(hk, X, Y);
+    if (!(frac <= 0.01 * (double)ctx->mfma_gate_pct * (ctx->mfma_f16 == 2 ? 1.0 : MFMA_F16_GATE / MFMA_GATE))) return 0;
+    *K2 = k2h;
+    return 1;
+}
+
 // The launcher family and coordinate pre-scale of a generic matrix-core MVM: a Sum of single-profile terms runs its one-pass form
 // (FAM_SUM_ISO: the pre-scale carries the first term's argument scale) unless option "sum_fused" = 0 keeps the composite interpreter.
 static int mfma_family_of(const covgram_ctx* ctx, const HostKernel& hk, float* gamma) {
@@ -1053,13 +1096,14 @@ bool sum_fused_applies(const covgram_ctx* ctx, const covgram_kernel* k, const co
     // of the one-pass general kernel
     const bool same = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N_HEAVY);
     if (same && mfma_k2_for(X->d + 1) > 8) return false;
-    // Measured (profiles/r05_sum_fused_ab.txt, d = 3, n = 131072): what one pass shares is the matrix-core work, the weighted sums and the slabs —
-    // every term's transcendentals remain, and they are what the kernels are bound by.  Three terms: 4.03 against 4.84 ms for one symmetric MVM
-    // per term; two terms on the symmetric form: 3.32 against 3.06 (the one-pass kernel's wave-uniform family switches and its one-tile loop cost
-    // more than the second MFMA pass and slab they save), on the general form (row shards, two point sets) 705 against 730 us.
+    // Measured (d = 3, n = 131072; profiles/r05_sum_fused_ab.txt, r05_sum_general_ab.txt): what one pass shares is the matrix-core work, the weighted
+    // sums and the slabs — every term's transcendentals remain, and they are what the kernels are bound by.  Three terms: 4.07 against 4.83 ms for one
+    // symmetric MVM per term, 0.95 / 1.01 against 0.98 / 1.09 on a 16384-row shard.  Two terms: one MVM per term wins or ties on both forms (symmetric
+    // 3.05 against 3.32; shard, MaternP(2) + EQ: 0.62 against 0.71 — the EQ term costs 0.15 on its own kernel —, MaternP + MaternP 0.83 against 0.87,
+    // RQ + MaternP 0.79 against 0.78): the one-pass kernel's wave-uniform family switches and its one-tile loop cost more than the second pass saves.
     // Option "sum_fused" = 1 takes the one-pass kernels wherever they exist (tests).
     if (ctx->sum_fused == 1) return true;
-    return hk.nterms >= 3 || !same;
+    return hk.nterms >= 3;
 }
 
 static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coordinates, from the compiled set
@@ -1067,6 +1111,34 @@ static int mfma_k2_for(int dims) {   // MFMAs per tile for `dims` (pseudo-)coord
     const int need = (dims + 1) / 2;
     for (int k : ks) if (k >= need) return k;
     return -1;
+}
+
+// (radius-gate quantity of an ISOTROPIC generic matrix-core MVM) / (what mfma_gen_eligible admits): sensitivity x Power x g^2 R^2 over
+// 0.5 MFMA_GATE / log2(e), single profiles and composites alike; infinity where a profile has no matrix-core form
+static double mfma_gen_gate_frac(const HostKernel& hk, const covgram_points* X, const covgram_points* Y) {
+    const double limit = 0.5 * MFMA_GATE / 1.4426950408889634074;
+    auto sens_of = [](int fam, const KParams<double>& q) -> double {
+        switch (fam) {
+            case COVGRAM_EQ: case COVGRAM_RQ: return 0.5;
+            case COVGRAM_CAUCHY: return 1.0;
+            case COVGRAM_IMQ: return 0.5 / q.param;                      // param holds c^2
+            case COVGRAM_MATERNP: return q.p < 1 ? INFINITY : (fabs(q.mp_d1) > 0.5 ? fabs(q.mp_d1) : 0.5);
+            default: return INFINITY;
+        }
+    };
+    const double Pn = gate_radius2(X, Y);
+    if (!(Pn < 1e30)) return INFINITY;
+    if (hk.tu_family >= COVGRAM_NFAMILY) {
+        double worst = 0.0;
+        int fi = 0;
+        for (int t = 0; t < hk.nterms; ++t) {
+            double sum = 0.0;
+            for (int f = 0; f < hk.nfac[t]; ++f, ++fi) sum += sens_of(hk.ffam[fi], hk.fkp[fi]) * hk.fkp[fi].power * hk.fkp[fi].gamma2;
+            worst = std::max(worst, sum);
+        }
+        return worst * Pn / limit;
+    }
+    return sens_of(hk.tu_family, hk.kp) * hk.k.power * Pn / (hk.k.lengthscale * hk.k.lengthscale) / limit;
 }
 
 bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
@@ -1104,7 +1176,7 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
         if (ctx->dense_variant == 2) return true;
         if (!iso) return sqrt(X->max_norm2) * sqrt(Y->max_norm2) < 1e30;
         const double Pn = gate_radius2(X, Y);                                  // natural units: every factor has its own 1 / l^2
-        return worst * Pn <= 0.5 * MFMA_GATE / 1.4426950408889634074;
+        return worst * Pn <= 0.5 * mfma_gate_of(ctx) / 1.4426950408889634074;
     }
     if (mfma_k2_for(X->d + (iso ? 1 : 0)) < 0) return false;
     if (ctx->dense_variant == 2) return true;
@@ -1121,7 +1193,7 @@ bool mfma_gen_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgr
         case COVGRAM_MATERNP: sens = fabs(hk.kp.mp_d1) > 0.5 ? fabs(hk.kp.mp_d1) : 0.5; break;
         default: break;
     }
-    return sens * hk.k.power * P <= 0.5 * MFMA_GATE / 1.4426950408889634074;   // the EQ gate in natural units
+    return sens * hk.k.power * P <= 0.5 * mfma_gate_of(ctx) / 1.4426950408889634074;   // the EQ gate in natural units
 }
 
 // y[:, 0..nrhs) <- alpha * scale * G a + beta * y (device pointers, column-major with lda / ldy)
@@ -1134,10 +1206,13 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
     const bool iso = hk.k.trait == COVGRAM_ISOTROPIC;
-    const int K2 = mfma_k2_for(d + (iso ? 1 : 0));
     const int64_t ntile = (m + 31) / 32;
     float gam;
     const int lfam = mfma_family_of(ctx, hk, &gam);
+    int K2bf = 0;
+    const int gfmt_all = mfma_gen_fmt(ctx, hk, lfam, X, Y, 4, &K2bf);   // the VALU forms (up to four right-hand sides); the many-column GEMM form keeps bf16
+    const int K2m = mfma_k2_for(d + (iso ? 1 : 0));                      // ... with this many MFMAs per tile
+    int K2 = K2m;
     ctx->last_sum_fused = lfam == FAM_SUM_ISO ? 1 : 0;
     mfma_launch_fn launch = mfma_launcher(lfam);
     const double alpha_eff = alpha * hk.kp.scale;
@@ -1163,7 +1238,7 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         float* AP = (float*)((char*)P + fb + wb);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a,
-                           lda, 0, 0, PB, Wd, K2, 1, gam, iso ? 1 : 0, (const float*)Y->center);
+                           lda, 0, 0, PB, Wd, K2, 1, gam, iso ? 1 : 0, (const float*)Y->center, 0);
         const int64_t ae = ntile * NB * 64 * 16;
         hipLaunchKernelGGL(mfma_pack_rhs_kernel, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, ctx->stream, a, lda, c0 + nr, c0, m, AP, NB);
         const int64_t rowtiles = (n + 31) / 32, npad = rowtiles * 32;
@@ -1190,6 +1265,9 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
                                32 * NB, (int)js, y_c, n, ldy, nr, (float)alpha_eff, (float)beta);
         cdone += nr;
     }
+    const int gfmt = gfmt_all;
+    if (gfmt) K2 = K2bf;                                                  // (mfma_gen_fmt returned the fp16 split's MFMAs per tile)
+    ctx->last_mfma_f16 = gfmt;
     for (int c0 = cdone; c0 < nrhs; c0 += 4) {
         const int nr = std::min(4, nrhs - c0);
         const int NR = nr == 1 ? 1 : 4;
@@ -1202,9 +1280,9 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
         float* W = (float*)(PB + ntile * K2 * 64);
         const int64_t pe = ntile * K2 * 64;
         hipLaunchKernelGGL(mfma_pack_gen_kernel, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d, a_c,
-                           lda, nr, 0, PB, W, K2, NR, gam, iso ? 1 : 0, (const float*)Y->center);
+                           lda, nr, 0, PB, W, K2, NR, gam, iso ? 1 : 0, (const float*)Y->center, gfmt);
         MfmaArgs ma;
-        ma.K2 = K2; ma.NR = NR;
+        ma.K2 = K2; ma.NR = NR; ma.fmt = gfmt;
         ma.RT = (NR == 1 && K2 <= 4 && ctx->rows_per_lane != 1) ? 2 : 1;
         ma.hk = &hk; ma.stream = ctx->stream; ma.Cn = (const float*)Y->center;
         const int nb = launch(ma, true);

@@ -138,6 +138,65 @@ __device__ __forceinline__ float eq_row_fragments_fmt(const float* __restrict__ 
     else return eq_row_fragments<K2>(xr, Cn, d, g, h, a);
 }
 
+// ---- fragments of the GENERIC kernels (the MFMA yields the profile argument s = |x~|^2 + |y~|^2 - 2 x~.y~, or x.y) ------------------------
+// GFMT 0: bf16 three-way split — a lane half of MFMA mm holds ONE coordinate c = 2 mm + h in its 8 K-slots, the two norms ride in the
+//         pseudo-coordinate c = d (header of this file).
+// GFMT 1 (round 5): fp16 two-way split, as the EQ kernel's (dense_mfma.hip, "Which split") — a lane half holds TWO positions q = 4 mm + 2 h + {0, 1}
+//         of three slots each: a coordinate as [x1, x1, x2] against [y1, y2, y1] (y carries the -2), the ROW norm at position d as [k, f1, f2]
+//         against [1, 1, 1], the COLUMN norm at position d + 1 as [1, 1, 1] against [k', f1', f2'] — a norm n = k + f with k = floor(n) exact in
+//         fp16 (the gate keeps n < 2048) and f in [0, 1) as two fp16 pieces (2^-22 absolute).  Half the MFMAs per tile of the bf16 split from d = 5
+//         (d = 8: 3 against 6, which also moves it from the one-tile-per-stage kernels to the staged ones); what it drops is ~2^-22 |x~_c y~_c| per
+//         coordinate, so it is taken inside a tighter radius gate (dense_mfma.hip: mfma_gen_fmt).  Isotropic profiles only.
+struct Norm16 { unsigned k, f1, f2; };
+__device__ __forceinline__ Norm16 norm16(float n) {
+    const float k = __builtin_floorf(n), f = n - k;
+    const _Float16 a = (_Float16)f;
+    Norm16 r;
+    r.k = f16_bits(k); r.f1 = (unsigned)__builtin_bit_cast(unsigned short, a); r.f2 = f16_bits(f - (float)a);
+    return r;
+}
+// the three slots of position q on the ROW side (lane of row `xr`)
+__device__ __forceinline__ void gen16_row_triple(const float* __restrict__ xr, const float* __restrict__ Cn, int d, float g, float nx, int q,
+                                                 unsigned& s0, unsigned& s1, unsigned& s2) {
+    s0 = s1 = s2 = 0u;
+    if (q < d) { unsigned x1, x2; split2h(g * (xr[q] - Cn[q]), x1, x2); s0 = x1; s1 = x1; s2 = x2; }
+    else if (q == d) { const Norm16 nn = norm16(nx); s0 = nn.k; s1 = nn.f1; s2 = nn.f2; }
+    else if (q == d + 1) { s0 = s1 = s2 = F16_ONE; }
+}
+template <int K2, int GFMT, bool ISO>
+__device__ __forceinline__ void gen_row_fragments(const float* __restrict__ xr, const float* __restrict__ Cn, int d, float g, int h, Frag (&a)[K2]) {
+    float nx = 0.0f;
+    if constexpr (ISO)
+        for (int cc = 0; cc < d; ++cc) { const float xc = g * (xr[cc] - Cn[cc]); nx = __builtin_fmaf(xc, xc, nx); }
+    if constexpr (GFMT == 1) {
+        static_assert(ISO || GFMT == 0, "the fp16 split serves the isotropic profiles");
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) {
+            const int q0 = 4 * mm + 2 * h;
+            unsigned p0, p1, p2, r0, r1, r2;
+            gen16_row_triple(xr, Cn, d, g, nx, q0, p0, p1, p2);
+            gen16_row_triple(xr, Cn, d, g, nx, q0 + 1, r0, r1, r2);
+            a[mm].u = make_uint4(p0 | (p1 << 16), p2 | (r0 << 16), r1 | (r2 << 16), 0u);
+        }
+    } else {
+#pragma unroll
+        for (int mm = 0; mm < K2; ++mm) {
+            const int c = 2 * mm + h;
+            uint4 f = make_uint4(0, 0, 0, 0);
+            if (c < d) {
+                unsigned x1, x2, x3;
+                split3(ISO ? g * (xr[c] - Cn[c]) : g * xr[c], x1, x2, x3);
+                f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
+            } else if (ISO && c == d) {
+                unsigned n1, n2, n3;
+                split3(nx, n1, n2, n3);
+                f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
+            }
+            a[mm].u = f;
+        }
+    }
+}
+
 template <int FAM> constexpr bool mfma_folded = (FAM == COVGRAM_EQ || FAM == COVGRAM_MATERNP);
 
 // ---- the profile on a tile, in register pairs (round 5) -------------------------------------------------------------------------
@@ -325,7 +384,7 @@ template <int FAM, int K2> constexpr bool mfma_pk_sums = K2 <= 2 || FAM == COVGR
 
 // LDS = 0: one wave per workgroup, its own fragment loads; LDS = 2: four waves on consecutive row tiles share every column tile
 // through LDS, one tile per stage, its K2 fragment slices fetched by the waves in turn (as dense_mfma_eq_kernel<.., 4, 2>)
-template <int FAM, int K2, int RT, int NR, int LDS = 0, int ORD = 0>
+template <int FAM, int K2, int RT, int NR, int LDS = 0, int ORD = 0, int GFMT = 0>
 __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const float* __restrict__ X, int64_t n, int32_t d,
                                                             const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
                                                             float* __restrict__ out, int64_t npad, int64_t ldy, int32_t nrhs,
@@ -341,25 +400,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
     for (int r = 0; r < RT; ++r) {
         int64_t row = i0 + 32 * r + t;
         if (row >= n) row = n - 1;                               // clamp: computed, never stored
-        const float* __restrict__ xr = X + row * (int64_t)d;
-        float nx = 0.0f;
-        if constexpr (ISO)
-            for (int cc = 0; cc < d; ++cc) { const float xc = g * (xr[cc] - Cn[cc]); nx = __builtin_fmaf(xc, xc, nx); }
-#pragma unroll
-        for (int mm = 0; mm < K2; ++mm) {
-            const int c = 2 * mm + h;
-            uint4 f = make_uint4(0, 0, 0, 0);
-            if (c < d) {
-                unsigned x1, x2, x3;
-                split3(ISO ? g * (xr[c] - Cn[c]) : g * xr[c], x1, x2, x3);
-                f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-            } else if (ISO && c == d) {
-                unsigned n1, n2, n3;
-                split3(nx, n1, n2, n3);
-                f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
-            }
-            a[r][mm].u = f;
-        }
+        gen_row_fragments<K2, GFMT, ISO>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
     }
 
     const int64_t T0 = (int64_t)blockIdx.y * tchunk;
@@ -388,7 +429,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) void dense_mfma_gen_kernel(const fl
         for (int r = 0; r < RT; ++r) {
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int mm = 0; mm < K2; ++mm) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][mm].v, f[mm].v, D, 0, 0, 0);
+            for (int mm = 0; mm < K2; ++mm) D = eq_mma<GFMT>(a[r][mm], f[mm], D);
             if constexpr (fam_is_expr<FAM>) {                                       // composite: all 16 entries factor by factor
                 float sv[16], kv[16];
 #pragma unroll
@@ -624,7 +665,7 @@ template <> struct SymParamsOf<FAM_EQFAST_H> { using type = KParams<float>; };
 // the barriers pace every wave by the fullest SIMD (measured: MaternP(2) at C2 size 3.35 ms, VALU active 53 % of the time).
 // ORD: MaternP's order at compile time (mfma_profile_block)
 template <int FAM> constexpr int mfma_sym_nw = (FAM == COVGRAM_MATERNP || FAM == COVGRAM_RQ || FAM == FAM_SUM_ISO) ? 4 : 8;
-template <int FAM, int K2, int NW_ = 8, int ORD = 0>
+template <int FAM, int K2, int NW_ = 8, int ORD = 0, int GFMT = 0>
 __global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ == 8 ? 4 : 3, NW_ == 8 ? 4 : 3))) void dense_mfma_sym_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
@@ -636,7 +677,7 @@ __global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ ==
     // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
-    constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
+    constexpr int FMT = (FAM == FAM_EQFAST_H || (!FAST && GFMT == 1)) ? 1 : 0;   // fp16 operands: the EQ form's two-way split / the generic form's (gen_row_fragments)
     constexpr bool PK = K2 <= 2 || mfma_pk_sums<FAM, K2>;   // packed fmas for the weighted sums (see process below)
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     // 8 waves x ONE row tile each (the 16 row weights u cost as many registers as the accumulators: one row tile per wave
@@ -674,24 +715,7 @@ __global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ ==
         if constexpr (FAST) {
             er = eq_row_fragments_fmt<K2, FMT>(xr, Cn, d, g, h, a);
         } else {
-            const float gg = kp.gamma;
-            if constexpr (ISO)
-                for (int cc = 0; cc < d; ++cc) { const float xc = gg * (xr[cc] - Cn[cc]); part = __builtin_fmaf(xc, xc, part); }
-#pragma unroll
-            for (int mm = 0; mm < K2; ++mm) {
-                const int c = 2 * mm + h;
-                uint4 f = make_uint4(0, 0, 0, 0);
-                if (c < d) {
-                    unsigned x1, x2, x3;
-                    split3(ISO ? gg * (xr[c] - Cn[c]) : gg * xr[c], x1, x2, x3);
-                    f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-                } else if (ISO && c == d) {                         // the norm pseudo-coordinate of dense_mfma_gen_kernel
-                    unsigned n1, n2, n3;
-                    split3(part, n1, n2, n3);
-                    f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
-                }
-                a[mm].u = f;
-            }
+            gen_row_fragments<K2, GFMT, ISO>(xr, Cn, d, kp.gamma, h, a);
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {                             // MFMA 32x32 output: register v of half h is row 8 (v / 4) + 4 h + v % 4
@@ -1034,6 +1058,7 @@ struct MfmaArgs {
     dim3 grid;
     const float* Cn = nullptr;   // common centre of isotropic kernels (dense_mvm.hpp)
     // symmetric form (dense_mfma_sym_kernel): row-sum slab R, column-sum slab S, the explicit workgroup list
+    int32_t fmt = 0;             // 1: the generic kernels' fp16 two-way split (gen_row_fragments: GFMT = 1; isotropic profiles, K2 <= 4)
     int32_t lds = 0;             // 1: dense_mfma_gen_kernel<.., LDS = 2> (grid.x counts workgroups of 4 waves)
     int32_t mrhs = 0;            // 1 / 2: dense_mfma_mrhs_kernel with that many blocks of 32 right-hand sides (W = the packed A operands)
     int32_t sym = 0;
@@ -1043,15 +1068,22 @@ struct MfmaArgs {
 };
 
 // returns the resident blocks per CU of the instance when `query` is set (no launch), COVGRAM_OK / error otherwise
-template <int FAM, int K2, int RT, int NR, int ORD>
-static void mfma_gen_launch(const MfmaArgs& a) {
+template <int FAM, int K2, int RT, int NR, int ORD, int GFMT>
+static void mfma_gen_launch_f(const MfmaArgs& a) {
     if (a.lds)
-        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2, ORD>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 2, ORD, GFMT>), dim3((a.grid.x + 3) / 4, a.grid.y), dim3(256), 0, a.stream, a.X, a.n, a.d,
                            a.PB, a.W, a.ntile, a.out, a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn,
                            make_params<FAM, float>(*a.hk));
     else
-        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, ORD>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
+        hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, ORD, GFMT>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
                            a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
+}
+// the fp16 split's instances exist for the isotropic families up to four MFMAs per tile (d <= 14) — the host asks for nothing else
+template <int FAM, int K2> constexpr bool mfma_gen_has_f16 = fam_is_iso<FAM> && !fam_is_expr<FAM> && K2 <= 4;
+template <int FAM, int K2, int RT, int NR, int ORD>
+static void mfma_gen_launch(const MfmaArgs& a) {
+    if constexpr (mfma_gen_has_f16<FAM, K2>) { if (a.fmt == 1) { mfma_gen_launch_f<FAM, K2, RT, NR, ORD, 1>(a); return; } }
+    mfma_gen_launch_f<FAM, K2, RT, NR, ORD, 0>(a);
 }
 template <int FAM, int K2, int RT, int NR>
 static int mfma_gen_one(const MfmaArgs& a, bool query) {
@@ -1060,7 +1092,7 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
         if (!cached) {
             int nb = 0;
             constexpr int QORD = (NR == 1 && (FAM == COVGRAM_MATERNP || FAM == FAM_SUM_ISO)) ? 2 : 0;   // the instance most launches take
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, QORD>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, QORD, 0>, 64, 0) != hipSuccess || nb <= 0) nb = 16;
             cached = nb;
         }
         return cached;
@@ -1081,7 +1113,14 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
 template <int FAM, int K2, int ORD>
 static void mfma_sym_narrow(const MfmaArgs& a) {
     constexpr int NW = mfma_sym_nw<FAM>;
-    hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2, NW, ORD>), a.grid, dim3(64 * NW), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+    if constexpr (mfma_gen_has_f16<FAM, K2>) {
+        if (a.fmt == 1) {
+            hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2, NW, ORD, 1>), a.grid, dim3(64 * NW), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                               (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2, NW, ORD, 0>), a.grid, dim3(64 * NW), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
                        (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
 }
 // which symmetric form serves (family, K2): the 8- or 6-wave panels with stages of four tiles (narrow), or four waves and one tile per stage

@@ -167,9 +167,13 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "dense_bcast" (the same register-broadcast scheme for the fp64 dense value MVM of the isotropic kernels, one right-hand side:
  * |x - y|^2 expanded around cached norms, one v_fmac_f64_dpp per dimension and pair, all-entries and upper-triangle-once kernels:
  * -1 = from padded d = 16 up to d = 64 inside the gamma^2 R^2 <= 1000 gate of "grad_expand", 0 = never, 1 = wherever it applies, d >= 8),
- * "mfma_f16" (the general matrix-core EQ kernel's split of the coordinates: -1 / 1 = the fp16 two-way split — 3 products per coordinate, one MFMA per
+ * "mfma_f16" (the fp32 matrix-core kernels' split of the coordinates: -1 / 1 = the fp16 two-way split — 3 products per coordinate, one MFMA per
  * FOUR coordinates, half the matrix-core work of the bf16 three-way split — while both clouds lie within g^2 R^2 <= 72 and the bf16 split beyond,
- * 0 = always the bf16 split, 2 = the fp16 split up to the matrix-core gate of 126: measurements only),
+ * 0 = always the bf16 split, 2 = the fp16 split up to the matrix-core gate of 126: measurements only.  EQ kernels (general and symmetric) and,
+ * since round 5, the generic ones — MaternP(p >= 1), RQ, Cauchy, IMQ, EQ^p, one-pass Sums; isotropic, d <= 14 — inside the same 72 / 126 of their gate),
+ * "mfma_gate_pct" (1..100, default 100: both radius gates in percent.  BASELINE's 1e-5 is held NORM-wise at the full gates (<= 7.3e-6 measured);
+ * the ROW-wise error |err_i| / (|K| |a|)_i of an adversarial cloud — points ON the gate's sphere, isolated rows, d >= 5 — reaches 1.5e-5 (bf16) /
+ * 2.5e-5 (fp16) at the edge and scales with the gate: 40 holds 1e-5 row-wise on it.  Clouds outside run the direct-difference kernels),
  * "mfma_fuse_w" (the general matrix-core EQ kernel's column weights a_j exp2(f_j): -1 / 1 = formed inside the kernel, 0 = by a pack launch in front of
  * it — bit-identical results),
  * "mfma_stamp" (1 = the general matrix-core EQ kernel runs its clock-stamping DIAGNOSTIC build — s_memtime / s_memrealtime

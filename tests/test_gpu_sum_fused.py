@@ -88,7 +88,11 @@ def test_one_pass_sum_two_point_sets_matches_termwise_and_oracle(cg, oracle, n, 
         cg.set_option("dense_variant", 2)                    # matrix cores whatever the routing rule says at this size
         for name, k, terms in _sums(cg, o):
             G = cg.gramian(k, X, Y)
-            cg.set_option("sum_fused", -1)
+            cg.set_option("sum_fused", -1)                   # the automatic rule: three terms in one pass, two terms one MVM per term (tools/sum_general_ab.py)
+            y = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+            G.mul_(y, a)
+            assert cg.get_info("last_sum_fused") == (1 if len(terms) >= 3 else 0), name
+            cg.set_option("sum_fused", 1)
             y = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
             G.mul_(y, a)
             assert cg.get_info("last_sum_fused") == 1 and cg.get_info("last_dense_path") == 2, name
@@ -101,7 +105,7 @@ def test_one_pass_sum_two_point_sets_matches_termwise_and_oracle(cg, oracle, n, 
             assert relerr(b, ref) <= 1e-5 and rowwise(b, ref, absref) <= 1e-5, (name, relerr(b, ref), rowwise(b, ref, absref))
             assert rowwise(b, y0.cpu().numpy().astype(np.float64), absref) <= 2e-6, name
             # three right-hand sides through the 4-column instance
-            cg.set_option("sum_fused", -1)
+            cg.set_option("sum_fused", 1)
             A3 = torch.from_numpy(rng.standard_normal((3, m)).astype(np.float32)).cuda()
             B3 = (G @ A3.T).cpu().numpy()
             for c in range(3):
