@@ -852,7 +852,7 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     float gam_unused;
     const int lfam = mfma_family_of(ctx, hk, &gam_unused);
     if (lfam == FAM_SUM_ISO && k2 > 8) return false;                              // no one-pass symmetric instance: one (symmetric) MVM per term instead
-    const int tpp = mfma_sym_tiles_per_panel(lfam, k2);
+    const int tpp = mfma_sym_tiles_per_panel(lfam, k2);                           // (an upper bound of the slab whichever form runs: fewer tiles per panel = more panels)
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
     const bool heavy = hk.tu_family == COVGRAM_MATERNP || hk.tu_family == COVGRAM_RQ || hk.tu_family >= COVGRAM_NFAMILY;   // profile costs several exponentials
@@ -896,7 +896,9 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // slab row stride: rows of R / S one panel apart must not sit a power of two apart (n = 49152: 192 KB stride, every panel's
     // stores to the same columns hit the same memory channel: 1.46 ms instead of 0.25); + 4.25 KB staggers them
     // row tiles per panel: 8 waves x 1 tile, 6 for the heavy profiles' 3-waves-per-SIMD form, or 4 x 1 for long fragments (dense_mfma.hpp)
-    const int tpp = fast ? (K2 > MFMA_NARROW_MAXK2 ? 4 : 8) : mfma_sym_tiles_per_panel(lfam, K2);
+    // generic form at one or two MFMAs per tile: two row tiles per wave as the EQ form (dense_mfma_sym2.hpp; option "mfma_sym_rt" = 1: the one-row-tile panels)
+    const int gen_rt = (!fast && ctx->mfma_sym_rt != 1 && K2 <= 2 && mfma_sym2_family(lfam)) ? 2 : 1;
+    const int tpp = fast ? (K2 > MFMA_NARROW_MAXK2 ? 4 : 8) : mfma_sym_tiles_per_panel(lfam, K2, gen_rt);
     const int64_t ntile = (n + 31) / 32, panels = (ntile + tpp - 1) / tpp, npad = panels * 32 * tpp + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
@@ -994,9 +996,9 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     const bool rt2 = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;
     ctx->last_mfma_sym_rt = rt2 ? 2 : 1;
 #define CG_SYM2_CASE(F, K) case K: if (K <= 2 && ctx->mfma_sym_st != 4) hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K, (K <= 2 ? 8 : 4)>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
-                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, EF); \
+                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, KParams<float>{}, EF); \
                                    else hipLaunchKernelGGL((dense_mfma_sym2_kernel<F, K, 4>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
-                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, EF); break;
+                                                      PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, KParams<float>{}, EF); break;
     if (rt2 && fmt) {
         switch (K2) { CG_SYM2_CASE(FAM_EQFAST_H, 1) CG_SYM2_CASE(FAM_EQFAST_H, 2) CG_SYM2_CASE(FAM_EQFAST_H, 3) CG_SYM2_CASE(FAM_EQFAST_H, 4) default: break; }
     } else if (rt2) {
@@ -1020,7 +1022,8 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
         ma.X = (const float*)X->dptr; ma.n = n; ma.d = d; ma.PB = PBu; ma.W = W; ma.ntile = ntile; ma.out = nullptr; ma.npad = npad; ma.ldy = n;
         ma.nrhs = 1; ma.tchunk = tchunk; ma.alpha = 1.0f; ma.beta = 0.0f; ma.final_store = 0; ma.K2 = K2; ma.RT = 1; ma.NR = 1;
         ma.hk = &hku; ma.stream = ctx->stream; ma.grid = grid; ma.Cn = Cn;
-        ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride; ma.fmt = gfmt;
+        ma.sym = 1; ma.R = (float*)Rp; ma.S = (float*)Sp; ma.wgmap = ctx->sym_map; ma.pfirst = pfirst; ma.pstride = pstride; ma.fmt = gfmt; ma.sym_rt = gen_rt;
+        ctx->last_mfma_sym_rt = gen_rt;
         mfma_launch_fn launch = mfma_launcher(lfam);
         CG_REQUIRE(launch != nullptr, COVGRAM_EUNSUPPORTED, "dense_mfma_sym: family %d has no matrix-core path", lfam);
         rc = launch(ma, false);

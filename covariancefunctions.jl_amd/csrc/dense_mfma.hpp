@@ -1047,6 +1047,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     R[cabs * npad + i] = FAST ? er * tot : tot;
 }
 
+}  // namespace covgram
+#include "dense_mfma_sym2.hpp"
+namespace covgram {
+
 struct MfmaArgs {
     const float* X; int64_t n; int32_t d;
     const uint4* PB; const float* W; int64_t ntile;
@@ -1062,6 +1066,7 @@ struct MfmaArgs {
     int32_t lds = 0;             // 1: dense_mfma_gen_kernel<.., LDS = 2> (grid.x counts workgroups of 4 waves)
     int32_t mrhs = 0;            // 1 / 2: dense_mfma_mrhs_kernel with that many blocks of 32 right-hand sides (W = the packed A operands)
     int32_t sym = 0;
+    int32_t sym_rt = 1;          // 2: dense_mfma_sym2_kernel (two row tiles per wave, 8-tile panels) where the family has the instance (mfma_sym2_has)
     float* R = nullptr; float* S = nullptr;
     const int32_t* wgmap = nullptr;
     int32_t pfirst = 0, pstride = 1;
@@ -1110,9 +1115,26 @@ static int mfma_gen_one(const MfmaArgs& a, bool query) {
     return COVGRAM_OK;
 }
 
+// the two-row-tile symmetric kernel's generic instances: isotropic single profiles at one or two MFMAs per tile (d <= 3 bf16, d <= 6 fp16).  NOT the
+// one-pass Sum: two row tiles of its term-by-term body spill into the tile loop (measured 6.3 against 4.0 ms for three terms, tools/gen_sym_rt_ab.py)
+template <int FAM, int K2> constexpr bool mfma_sym2_has = fam_is_iso<FAM> && !fam_is_expr<FAM> && FAM != FAM_SUM_ISO && K2 <= 2;
+inline bool mfma_sym2_family(int launcher_family) {
+    switch (launcher_family) { case COVGRAM_EQ: case COVGRAM_RQ: case COVGRAM_CAUCHY: case COVGRAM_IMQ: case COVGRAM_MATERNP: return true; default: return false; }
+}
 template <int FAM, int K2, int ORD>
 static void mfma_sym_narrow(const MfmaArgs& a) {
     constexpr int NW = mfma_sym_nw<FAM>;
+    if constexpr (mfma_sym2_has<FAM, K2>) {
+        if (a.sym_rt == 2) {
+            if (a.fmt == 1)
+                hipLaunchKernelGGL((dense_mfma_sym2_kernel<FAM, K2, 8, ORD, 1>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                                   (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+            else
+                hipLaunchKernelGGL((dense_mfma_sym2_kernel<FAM, K2, 8, ORD, 0>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
+                                   (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+            return;
+        }
+    }
     if constexpr (mfma_gen_has_f16<FAM, K2>) {
         if (a.fmt == 1) {
             hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM, K2, NW, ORD, 1>), a.grid, dim3(64 * NW), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S, a.npad,
@@ -1126,7 +1148,8 @@ static void mfma_sym_narrow(const MfmaArgs& a) {
 // which symmetric form serves (family, K2): the 8- or 6-wave panels with stages of four tiles (narrow), or four waves and one tile per stage
 // (wide).  The one-pass Sum takes the wide form from K2 = 3 on (its 6-wave instances spill 12-40 B at K2 = 3, 4) and has no instance beyond K2 = 8.
 template <int FAM> constexpr int mfma_sym_narrow_maxk2 = FAM == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
-inline int mfma_sym_tiles_per_panel(int launcher_family, int k2) {
+inline int mfma_sym_tiles_per_panel(int launcher_family, int k2, int sym_rt = 1) {
+    if (sym_rt == 2 && k2 <= 2 && mfma_sym2_family(launcher_family)) return 8;   // dense_mfma_sym2_kernel: 4 waves x 2 row tiles
     const bool heavy = launcher_family == COVGRAM_MATERNP || launcher_family == COVGRAM_RQ || launcher_family == FAM_SUM_ISO;
     const int narrow_max = launcher_family == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
     return (k2 > narrow_max || heavy) ? 4 : 8;

@@ -12,22 +12,28 @@
 // reduce kernel as dense_mfma_sym_kernel: the two are interchangeable per launch (option "mfma_sym_rt"), and every sum is formed in the same order
 // within a row tile; across the two row tiles of a wave the column sums are added in registers (row tile 2 w, then 2 w + 1) where the 8-wave kernel
 // adds them in LDS in wave order — the same order.
+//
+// Generic form (round 5, second half): the same kernel for the isotropic single profiles (FAM = the launcher family, ORD / GFMT
+// as in dense_mfma_sym_kernel) — row fragments by gen_row_fragments, the profile by mfma_profile_block on both row tiles' 16 entries, W = the per-MVM
+// packed weights, no fraction factors.  These kernels are bound by their transcendentals; what two row tiles per wave halve is the per-(row tile,
+// column tile) bookkeeping, which the 4-wave one-row-tile panels of MaternP / RQ paid in full.
+// (included from the middle of dense_mfma.hpp, after the helpers it uses and before the launchers that name it)
 #pragma once
-#include "dense_mfma.hpp"
 
 namespace covgram {
 
 // ST_: column tiles per stage (one barrier, one round of LDS-DMA issues, weight reads and column-sum flushes per stage): 8 where the LDS allows
 // three workgroups per CU (K2 <= 2: 49 KB each), else 4
-template <int FAM, int K2, int ST_ = (K2 <= 2 ? 8 : 4)>
+template <int FAM, int K2, int ST_ = (K2 <= 2 ? 8 : 4), int ORD = 0, int GFMT = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym2_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
-    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const float* __restrict__ EF) {
-    static_assert(FAM == FAM_EQFAST || FAM == FAM_EQFAST_H, "the two-row-tile form is the EQ kernel's");
-    constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
+    int32_t pfirst, int32_t pstride, const int32_t* __restrict__ wgmap, const typename SymParamsOf<FAM>::type kp, const float* __restrict__ EF) {
+    constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
+    static_assert(FAST || (fam_is_iso<FAM> && !fam_is_expr<FAM>), "the two-row-tile form: the EQ kernels and the isotropic single profiles");
+    constexpr int FMT = (FAM == FAM_EQFAST_H || (!FAST && GFMT == 1)) ? 1 : 0;
     constexpr int NW = 4, RT = 2, TPP = NW * RT, ST = ST_, SPW = ST / NW;   // 8 row tiles per panel; stages of ST column tiles, SPW fetched (and later flushed) by each wave
-    auto wt = [&](int64_t j) { return j < n ? W[j] * EF[j] : 0.0f; };
+    auto wt = [&](int64_t j) { if constexpr (FAST) return j < n ? W[j] * EF[j] : 0.0f; else return W[j]; };
     const int32_t wm = wgmap[blockIdx.x];
     const int64_t lp = wm >> 12;
     const int64_t cabs = wm & 4095;
@@ -48,7 +54,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int64_t i0 = (I0 + r) * 32;
         int64_t row = i0 + t;
         if (row >= n) row = n - 1;
-        er[r] = eq_row_fragments_fmt<K2, FMT>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
+        if constexpr (FAST) er[r] = eq_row_fragments_fmt<K2, FMT>(X + row * (int64_t)d, Cn, d, g, h, a[r]);
+        else { gen_row_fragments<K2, GFMT, true>(X + row * (int64_t)d, Cn, d, kp.gamma, h, a[r]); er[r] = 1.0f; }
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             float uv[2];
@@ -85,9 +92,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int mm = 0; mm < K2; ++mm) D[r] = eq_mma<FMT>(a[r][mm], f[mm], D[r]);
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RT; ++r) {
+            if constexpr (FAST) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) D[r][v] = __builtin_amdgcn_exp2f(D[r][v]);
+                for (int v = 0; v < 16; ++v) D[r][v] = __builtin_amdgcn_exp2f(D[r][v]);
+            } else mfma_profile_block<FAM, ORD>(D[r], kp);
+        }
         f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         const int64_t i = (I0 + r) * 32 + t;
         if (((t >> 2) & 1) != h || i >= n) continue;
-        R[cabs * npad + i] = er[r] * tot;
+        R[cabs * npad + i] = FAST ? er[r] * tot : tot;
     }
 }
 

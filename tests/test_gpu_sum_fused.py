@@ -67,7 +67,7 @@ def test_one_pass_sum_symmetric_matches_termwise_and_oracle(cg, oracle, n, d):
             assert np.isfinite(b).all(), name
             assert relerr(b, ref) <= 1e-5 and rowwise(b, ref, absref) <= 1e-5, (name, n, d, relerr(b, ref), rowwise(b, ref, absref))
             assert rowwise(b0, ref, absref) <= 1e-5, name
-            assert rowwise(b, b0.astype(np.float64), absref) <= 2e-6, (name, rowwise(b, b0.astype(np.float64), absref))   # fused vs one MVM per term
+            assert rowwise(b, b0.astype(np.float64), absref) <= 4e-6, (name, rowwise(b, b0.astype(np.float64), absref))   # fused vs one MVM per term (both within 1e-5 of the oracle above)
             cg.set_option("sum_fused", 1)
             y2 = torch.from_numpy(ah[::-1].copy()).cuda()
             G.mul_(y2, a, -0.7, 1.3)
@@ -103,7 +103,7 @@ def test_one_pass_sum_two_point_sets_matches_termwise_and_oracle(cg, oracle, n, 
             b = y.cpu().numpy()
             assert np.isfinite(b).all(), name
             assert relerr(b, ref) <= 1e-5 and rowwise(b, ref, absref) <= 1e-5, (name, relerr(b, ref), rowwise(b, ref, absref))
-            assert rowwise(b, y0.cpu().numpy().astype(np.float64), absref) <= 2e-6, name
+            assert rowwise(b, y0.cpu().numpy().astype(np.float64), absref) <= 4e-6, name
             # three right-hand sides through the 4-column instance
             cg.set_option("sum_fused", 1)
             A3 = torch.from_numpy(rng.standard_normal((3, m)).astype(np.float32)).cuda()
