@@ -919,7 +919,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     }
     if (m > 0 && !dotfac) ctx->last_dense_path = mfma ? 2 : (wide ? 3 : 1);
     // fp64 gramian(k, x) * a on the direct-difference path: the upper triangle once (dense_sym_kernel, dense_mvm.hpp).  The same point
-    // set on both sides, one right-hand side, a single (non-composite) profile without a Power wrapper, d <= 64; from n = 8192 (16384 for
+    // set on both sides, one right-hand side, a single (non-composite) profile without a Power wrapper, d <= 64; from n = 6144 (16384 for
     // the profiles that cost a reciprocal or less: below that the launch is latency and the triangle's imbalance, not arithmetic —
     // tools/fp64_sym_sweep.py: break-even at n ~ 6000, x1.1-1.25 at 8192, x1.3-1.5 at 16384, x1.5-1.75 from 32768) while the column-sum
     // slab n^2 / 8 bytes — held in workspace slot 4 for the life of the ctx — stays within 1 GiB (n <= 92681) when the choice is automatic,
@@ -932,7 +932,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     const bool sym_forced = ctx->dense_sym == 1 || sp_world > 0;
     DenseSymShape symsh{};
     // fp32 break-even measured at n ~ 22000 (profiles/r04_sym32_sweep.txt: x0.85-0.9 at 16384, x1.2-1.5 at 32768, x1.5-1.85 from 65536)
-    const int64_t sym_min_n = dtype == COVGRAM_F64 ? (cheap_profile ? 16384 : 8192) : (cheap_profile ? 32768 : 24576);
+    const int64_t sym_min_n = dtype == COVGRAM_F64 ? (cheap_profile ? 16384 : 6144) : (cheap_profile ? 32768 : 24576);   // fp64, d = 3 (tools/c1_sym_ab.py): n = 4096 31 against 29 us, 6144 42 against 48, 8192 62 against 77
     const bool dsym = !mfma && !wide && m > 0 && nrhs == 1 && (ctx->dense_sym != 0 || sp_world > 0) && X->dptr == Y->dptr && n == m &&
                       (sym_forced || n >= sym_min_n) && R == 1 &&
                       dense_sym_shape(hk, X, sp_world > 0 ? sp_world : 1, sym_forced ? 2 : 1, &symsh);
@@ -941,7 +941,7 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
     // fp64, wide points (round 4, dense_bcast.hpp): |x - y|^2 expanded around cached norms — one v_fmac_f64 per dimension and pair instead of
     // a subtraction and an fma, the column records in VGPRs (DPP broadcast) instead of the scalar stream — for the profiles that are smooth
     // in s at 0, one right-hand side, no Power wrapper, inside the expanded form's radius gate (as the gradient kernel's: grad_mvm.hpp).
-    // Where the symmetric form applies too (gramian(k, x), n from 8192 / 16384, or covgram_mvm_sym_partial's cyclic row blocks) the two
+    // Where the symmetric form applies too (gramian(k, x), n from 6144 / 16384, or covgram_mvm_sym_partial's cyclic row blocks) the two
     // combine: dense_bcast_sym_kernel evaluates the upper triangle once WITH the one-fmac distance (profiles/r04_fp64_dense_d_sweep.txt).
     const bool bc_family = hk.tu_family == COVGRAM_EQ || hk.tu_family == COVGRAM_RQ || hk.tu_family == COVGRAM_CAUCHY || hk.tu_family == COVGRAM_IMQ ||
                            (hk.tu_family == COVGRAM_MATERNP && hk.k.p >= 1);

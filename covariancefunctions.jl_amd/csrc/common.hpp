@@ -259,7 +259,7 @@ struct covgram_ctx {
     int64_t sum_fused = -1;      // fp32 Sum of 2-3 single-profile isotropic terms: one pass of the matrix-core kernels over the shared distance (-1 / 1 where they apply, 0: one MVM per term)
     int64_t last_sum_fused = 0;
     int64_t composite_termwise = 1;   // Sum of single-profile terms: one MVM per term on its own path (0: the composite interpreter)
-    int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 8192 / 16384, 0 never, 1 always)
+    int64_t dense_sym = -1;      // fp64 direct-difference path on gramian(k, x): upper triangle once (-1 auto: n >= 6144 / 16384, 0 never, 1 always)
     int64_t last_dense_sym = 0;
     int64_t dense_bcast = -1;    // fp64 dense MVM of wide points on dense_bcast_kernel (expanded distance, v_fmac_f64_dpp): -1 = from padded d = 16 inside the radius gate, 0 never, 1 whenever compiled (d >= 8)
     int64_t last_dense_bcast = 0;

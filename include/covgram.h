@@ -148,7 +148,7 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "mfma_sym" (matrix-core EQ path on gramian(k, x), both sides the SAME device points: evaluate the upper triangle once;
  * -1 = from n = 12500 ... 18000 by the profile's cost, 0 = never, 1 = always),
  * "dense_sym" (the same for fp64 on the direct-difference path — the reference's default element type: gramian(k, x) with one
- * right-hand side evaluates every entry on or above the diagonal blocks once, dense_sym_kernel; -1 = from n = 8192 (16384 for
+ * right-hand side evaluates every entry on or above the diagonal blocks once, dense_sym_kernel; -1 = from n = 6144 (16384 for
  * Cauchy / IMQ / Dot) while its column-sum slab of n^2 / 8 bytes stays within 1 GiB, 0 = never, 1 = always, up to a 2 GiB slab — the
  * slab lives in the ctx's workspace until the ctx is destroyed: 512 MiB at n = 65536, once per ctx),
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
