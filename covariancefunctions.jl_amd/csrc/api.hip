@@ -537,6 +537,7 @@ int covgram_ctx_set_option(covgram_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "toeplitz_fused")) ctx->toeplitz_fused = value;
     else if (!strcmp(key, "toeplitz_colfft")) ctx->toeplitz_colfft = value;
     else if (!strcmp(key, "toeplitz_persist")) ctx->toeplitz_persist = value;
+    else if (!strcmp(key, "kron_fill")) ctx->kron_fill = value;
     else if (!strcmp(key, "mfma_f16")) ctx->mfma_f16 = value;
     else if (!strcmp(key, "mfma_gate_pct")) { CG_REQUIRE(value >= 1 && value <= 100, COVGRAM_EINVAL, "mfma_gate_pct = %lld: 1..100", (long long)value); ctx->mfma_gate_pct = value; }
     else if (!strcmp(key, "mfma_fuse_w")) ctx->mfma_fuse_w = value;

@@ -281,6 +281,7 @@ struct covgram_ctx {
     int64_t toeplitz_real_spectrum = 1; // handles of symmetric Toeplitz matrices created while this is 1 keep the row kernel's spectrum copy as reals
     int64_t toeplitz_colfft = 16; // column FFT of the Toeplitz fast path: 16 = radix-16 register butterflies (colfft16_kernel), 4 = the radix-4 LDS kernel
     int64_t mfma_fuse_w = -1;      // general matrix-core EQ kernel: the column weights a_j exp2(f_j) formed in the kernel (-1 / 1) or by a pack launch in front of it (0)
+    int64_t kron_fill = 1;         // Kronecker mode kernel: workgroups per CU its column tiling aims at (1, 2)
     int64_t mfma_gate_pct = 100;   // both radius gates of the fp32 matrix-core kernels, in percent of MFMA_GATE / MFMA_F16_GATE (1..100): the worst-case ROW-wise error scales with the gate (profiles/r05_gate_scan.txt)
     int64_t mfma_f16 = -1;         // general matrix-core EQ kernel: the fp16 two-way split (half the MFMAs per tile): -1 / 1 = within MFMA_F16_GATE, 0 = never, 2 = within MFMA_GATE (measurements only)
     int64_t last_mfma_f16 = 0;

@@ -648,7 +648,8 @@ int run_mode(covgram_ctx* ctx, const T* in, T* out, const T* F, int64_t ld, int6
     // column tiles: 128 wide when that still gives every CU a workgroup, else 64 / 32 (more, smaller workgroups for short K measured
     // slower: 32^4 fp64 42.5 -> 49.6 us)
     int nbp = 8;
-    while (nbp > 2 && (16 * nbp / 2 >= post || pre * ((post + 16 * nbp - 1) / (16 * nbp)) < (int64_t)ctx->num_cus)) nbp /= 2;
+    const int64_t want_wgs = (int64_t)ctx->num_cus * (ctx->kron_fill > 1 ? ctx->kron_fill : 1);   // option "kron_fill": workgroups per CU the column tiling aims at
+    while (nbp > 2 && (16 * nbp / 2 >= post || pre * ((post + 16 * nbp - 1) / (16 * nbp)) < want_wgs)) nbp /= 2;
     const int64_t ntiles = (post + 16 * nbp - 1) / (16 * nbp);
     const int nw = pick_nw(strips, pre * ntiles, ctx->num_cus, 4, 8);
     a.groups = (strips + nw - 1) / nw;
