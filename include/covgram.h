@@ -154,7 +154,9 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * "composite_termwise" (1 = a Sum runs one MVM per term on the term's own path, 0 = one pass of the composite kernels),
  * "sum_fused" (fp32 Sum of two or three single-profile isotropic terms — EQ, RQ, Cauchy, IMQ, MaternP(1..3), no Power wrapper — in ONE pass of
  * the matrix-core kernels, every term evaluated on the pair's shared distance as the reference does, src/algebra.jl:27-47: -1 = where it
- * measured faster than one MVM per term (three terms; two terms on two point sets), 0 = never, 1 = wherever the one-pass kernels exist),
+ * measured faster than one MVM per term (three terms), 0 = never, 1 = wherever the one-pass kernels exist),
+ * "mfma_sym_rt" (the symmetric fp32 matrix-core kernels at one or two MFMAs per tile — EQ, MaternP, RQ, Cauchy, IMQ: -1 / 2 = two row tiles per
+ * wave in 4-wave workgroups, dense_mfma_sym2.hpp; 1 = one row tile per wave),
  * "grad_expand" (fp64 isotropic gradient / value-gradient Gramians in the expanded form — |x - y|^2 = |x|^2 + |y|^2 - 2 x.y with
  * cached norms, 4 instead of 6 fp64 instructions per dimension and pair: -1 = while the pre-scaled clouds lie within
  * gamma^2 R^2 <= 1000 of their common centre, 0 = never, 1 = always),
