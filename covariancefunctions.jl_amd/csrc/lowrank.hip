@@ -55,7 +55,28 @@ __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ 
         T acc[CW];
 #pragma unroll
         for (int c = 0; c < CW; ++c) acc[c] = (T)0;
-        for (int64_t j = j0 + (int64_t)lane * VEC; j < j1; j += 64 * VEC) {
+        int64_t j = j0 + (int64_t)lane * VEC;
+        // Four row groups per trip, every load issued before the first fma (round 5): a slab is 8-16 groups per wave, and one group per trip made
+        // the pass as many dependent memory round trips long at one or two waves per SIMD (32 us at r = 32, n = 2^20 against 24 for the equally
+        // long second pass; profiles/r05_lowrank_trace.txt).  Same sums, in the order group 0, 1, 2, 3 per accumulator.  (Giving the waves that
+        // have no columns at r <= 16 a share of the rows instead was measured too: no change, not kept.)
+        constexpr int UN = 4;
+        for (; j + (int64_t)(UN - 1) * 64 * VEC + VEC <= j1; j += (int64_t)UN * 64 * VEC) {
+            VT av[UN], vv[UN][CW];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                av[u] = *reinterpret_cast<const VT*>(a + j + (int64_t)u * 64 * VEC);
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < nc) vv[u][c] = *reinterpret_cast<const VT*>(V + (cb + c) * ldv + j + (int64_t)u * 64 * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < nc) acc[c] = vdot<T, VEC>(vv[u][c], av[u], acc[c]);
+        }
+        for (; j < j1; j += 64 * VEC) {
             if (j + VEC <= j1) {
                 const VT av = *reinterpret_cast<const VT*>(a + j);
 #pragma unroll
@@ -552,7 +573,7 @@ int covgram_lowrank_mvm(covgram_ctx* ctx, const void* U, int64_t ldu, const void
     // row slabs of V: ~4 workgroups per CU (GEMV form: ~2, i.e. at least two sweeps per slab at n = 2^20 — a slab of ONE sweep spends as long in
     // its 32-column LDS reduction as on its loads: 28.4 us at 4.7 TB/s for 134 MB), slab length a multiple of one sweep of the block (256 threads x 16 bytes)
     const int64_t sweep = 256 * (16 / (int64_t)ts);
-    const int64_t wg_per_cu = ctx->lowrank_wgs > 0 ? ctx->lowrank_wgs : (mfma ? 4 : 2);      // (1: 43.9 us, 2: 33.2, 4 or more: 36.4 — the last workgroup then adds 1024 partials per column)
+    const int64_t wg_per_cu = ctx->lowrank_wgs > 0 ? ctx->lowrank_wgs : (mfma ? 4 : 1);      // GEMV form, round 5 (four row groups in flight per wave; tools/lowrank_wg_ab.py, r = 32 fp32): 1: 48.9 us, 2: 52.1, 4: 60.1 — the last workgroup adds one partial per slab and column
     int64_t per = (m + (int64_t)ctx->num_cus * wg_per_cu - 1) / ((int64_t)ctx->num_cus * wg_per_cu);
     per = std::max<int64_t>(sweep, ((per + sweep - 1) / sweep) * sweep);
     const int64_t nslab = (m + per - 1) / per;
