@@ -37,6 +37,50 @@ __device__ __forceinline__ T vdot(typename VecOf<T, VEC>::type u, typename VecOf
 
 constexpr int LR_RC = 32;   // columns of V carried per pass over a row slab (accumulators per thread)
 
+// the LAST workgroup to arrive sums the slabs' partials in lowrank_zsum_kernel's fixed order: z[k] = sum_slab zpart[slab][k], k < r (red: 8 x 32 scratch)
+template <typename T>
+__device__ __forceinline__ void slab_tail_sum(const T* __restrict__ zpart, T* __restrict__ z, int64_t r, T* __restrict__ red) {
+    const int64_t nslab = gridDim.x;
+    const int kk = threadIdx.x & 31, part = threadIdx.x >> 5;
+    T* redz = red;
+    for (int64_t kb = 0; kb < r; kb += 32) {
+        const int64_t k = kb + kk;
+        T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+        if (k < r) {
+            int64_t sl = part;
+            // 32 uncached loads in flight per thread (round 5; 8 before): this tail is pure memory latency — 512 slabs x 32 columns took eight
+            // dependent round trips of ~1.2 us behind the last slab (lowrank_vta_kernel 33.6 us against 24.1 for the equally long second pass)
+            for (; sl + 248 < nslab; sl += 256) {
+                T pv[32];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) pv[q] = slab_load(zpart + (sl + 8 * q) * r + k);
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) { s0 += pv[q]; s1 += pv[q + 1]; s2 += pv[q + 2]; s3 += pv[q + 3]; }
+            }
+            for (; sl + 56 < nslab; sl += 64) {
+                const T p0 = slab_load(zpart + sl * r + k), p1 = slab_load(zpart + (sl + 8) * r + k), p2 = slab_load(zpart + (sl + 16) * r + k),
+                        p3 = slab_load(zpart + (sl + 24) * r + k), p4 = slab_load(zpart + (sl + 32) * r + k), p5 = slab_load(zpart + (sl + 40) * r + k),
+                        p6 = slab_load(zpart + (sl + 48) * r + k), p7 = slab_load(zpart + (sl + 56) * r + k);
+                s0 += p0; s1 += p1; s2 += p2; s3 += p3; s0 += p4; s1 += p5; s2 += p6; s3 += p7;
+            }
+            for (; sl + 24 < nslab; sl += 32) {
+                s0 += slab_load(zpart + sl * r + k); s1 += slab_load(zpart + (sl + 8) * r + k); s2 += slab_load(zpart + (sl + 16) * r + k);
+                s3 += slab_load(zpart + (sl + 24) * r + k);
+            }
+            for (; sl < nslab; sl += 8) s0 += slab_load(zpart + sl * r + k);
+        }
+        __syncthreads();
+        redz[part * 32 + kk] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (part == 0 && k < r) {
+            T s = (T)0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) s += redz[p * 32 + kk];
+            z[k] = s;
+        }
+    }
+}
+
 // zpart[slab][k] = sum_{j in slab} V[j + k*ldv] a[j].  One workgroup per row slab; of its four waves, wave w carries columns 8 w .. 8 w + 7 of
 // each 32-column pass: a lane streams VEC rows of its 8 columns per step (16-byte loads, 8 accumulators — round 4: 32 accumulators and
 // 32 loads per thread left two waves per SIMD and 4.7 TB/s; the short state runs at the occupancy of lowrank_uz_kernel), then a fixed-order
@@ -99,45 +143,7 @@ __global__ __launch_bounds__(256) void lowrank_vta_kernel(const T* __restrict__ 
     // ticket != nullptr (round 4, small r): the LAST slab's workgroup to arrive sums the partials in lowrank_zsum_kernel's fixed order — no
     // separate launch (that kernel is ONE workgroup per 32 columns walking every slab: 9.7 us of latency at r = 32, n = 2^20), eight loads in flight
     if (ticket == nullptr || !last_arrival(ticket, gridDim.x)) return;
-    const int64_t nslab = gridDim.x;
-    const int kk = threadIdx.x & 31, part = threadIdx.x >> 5;
-    T* redz = red;
-    for (int64_t kb = 0; kb < r; kb += 32) {
-        const int64_t k = kb + kk;
-        T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
-        if (k < r) {
-            int64_t sl = part;
-            // 32 uncached loads in flight per thread (round 5; 8 before): this tail is pure memory latency — 512 slabs x 32 columns took eight
-            // dependent round trips of ~1.2 us behind the last slab (lowrank_vta_kernel 33.6 us against 24.1 for the equally long second pass)
-            for (; sl + 248 < nslab; sl += 256) {
-                T pv[32];
-#pragma unroll
-                for (int q = 0; q < 32; ++q) pv[q] = slab_load(zpart + (sl + 8 * q) * r + k);
-#pragma unroll
-                for (int q = 0; q < 32; q += 4) { s0 += pv[q]; s1 += pv[q + 1]; s2 += pv[q + 2]; s3 += pv[q + 3]; }
-            }
-            for (; sl + 56 < nslab; sl += 64) {
-                const T p0 = slab_load(zpart + sl * r + k), p1 = slab_load(zpart + (sl + 8) * r + k), p2 = slab_load(zpart + (sl + 16) * r + k),
-                        p3 = slab_load(zpart + (sl + 24) * r + k), p4 = slab_load(zpart + (sl + 32) * r + k), p5 = slab_load(zpart + (sl + 40) * r + k),
-                        p6 = slab_load(zpart + (sl + 48) * r + k), p7 = slab_load(zpart + (sl + 56) * r + k);
-                s0 += p0; s1 += p1; s2 += p2; s3 += p3; s0 += p4; s1 += p5; s2 += p6; s3 += p7;
-            }
-            for (; sl + 24 < nslab; sl += 32) {
-                s0 += slab_load(zpart + sl * r + k); s1 += slab_load(zpart + (sl + 8) * r + k); s2 += slab_load(zpart + (sl + 16) * r + k);
-                s3 += slab_load(zpart + (sl + 24) * r + k);
-            }
-            for (; sl < nslab; sl += 8) s0 += slab_load(zpart + sl * r + k);
-        }
-        __syncthreads();
-        redz[part * 32 + kk] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        if (part == 0 && k < r) {
-            T s = (T)0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) s += redz[p * 32 + kk];
-            z[k] = s;
-        }
-    }
+    slab_tail_sum<T>(zpart, z, r, red);
 }
 
 // z[k] = sum_slab zpart[slab][k] (fixed order): one workgroup per 32 columns, 8 slab subsets in parallel, 4 loads in flight each
@@ -487,6 +493,156 @@ __global__ __launch_bounds__(256) void dot_vta_kernel(const T* __restrict__ Y, i
         }
 }
 
+// One right-hand side (round 5): zpart[slab][c] = sum_{j in slab} Y[j][c] a[j] with DC >= min(d, 16) coordinates per pass chosen by the host (4, 8, 16:
+// the generic kernel above carries 16 x 4 sums whatever d and nrhs are — 16 loads and 64 fmas per row where d = 3 needs 3 and 3, 51 us for n = 2^20,
+// d = 8), four rows per thread in flight with every load issued before the first fma, and the last slab's workgroup sums the partials (no
+// separate zsum launch: 9.6 us of one-workgroup latency).
+template <typename T, int DC, bool VEC>
+__global__ __launch_bounds__(256) void dot_vta1_kernel(const T* __restrict__ Y, int64_t m, int32_t d, const T* __restrict__ a, T* __restrict__ zpart,
+                                                       int64_t per, unsigned* __restrict__ ticket, T* __restrict__ z) {
+    // VEC: rows are whole 16-byte vectors (d a multiple of 4 fp32 / 2 fp64, aligned base) — a quarter / half of the load instructions
+    constexpr int VW = 16 / (int)sizeof(T), NV = DC / VW;
+    using VT = typename VecOf<T, VW>::type;
+    constexpr int UN = (DC * (int)sizeof(T) > 64) ? 2 : 4;      // rows in flight per thread: at most 64 registers of operands
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < m) ? (j0 + per) : m;
+    __shared__ T red[8 * 32];
+    T* __restrict__ zp = zpart + (int64_t)blockIdx.x * d;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < d; c0 += DC) {
+        T acc[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) acc[c] = (T)0;
+        int64_t j = j0 + threadIdx.x;
+        if constexpr (VEC) {
+            const int nv = (d - c0 < DC ? d - c0 : DC) / VW;    // whole vectors of this pass that exist (d is a multiple of VW)
+            for (; j + (UN - 1) * 256 < j1; j += UN * 256) {
+                T av[UN]; VT yv[UN][NV];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    av[u] = a[j + u * 256];
+                    const VT* __restrict__ yr = reinterpret_cast<const VT*>(Y + (j + u * 256) * (int64_t)d + c0);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) yv[u][v] = yr[v < nv ? v : nv - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) acc[v * VW + e] = fma_t(yv[u][v][e], av[u], acc[v * VW + e]);
+            }
+        } else {
+            for (; j + (UN - 1) * 256 < j1; j += UN * 256) {
+                T av[UN], yv[UN][DC];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    av[u] = a[j + u * 256];
+                    const T* __restrict__ yr = Y + (j + u * 256) * (int64_t)d;
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) yv[u][c] = yr[c0 + c < d ? c0 + c : d - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) acc[c] = fma_t(yv[u][c], av[u], acc[c]);
+            }
+        }
+        for (; j < j1; j += 256) {
+            const T av = a[j];
+            const T* __restrict__ yr = Y + j * (int64_t)d;
+#pragma unroll
+            for (int c = 0; c < DC; ++c) acc[c] = fma_t(yr[c0 + c < d ? c0 + c : d - 1], av, acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            T s = acc[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red[wv * DC + c] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < DC && c0 + (int)threadIdx.x < d)
+            slab_store(zp + c0 + threadIdx.x, (red[threadIdx.x] + red[DC + threadIdx.x]) + (red[2 * DC + threadIdx.x] + red[3 * DC + threadIdx.x]), ticket != nullptr);
+        __syncthreads();
+    }
+    if (ticket == nullptr || !last_arrival(ticket, gridDim.x)) return;
+    slab_tail_sum<T>(zpart, z, (int64_t)d, red);
+}
+
+// Rows longer than 64 bytes (round 5): G = d / VW lanes share a row, one 16-byte vector each — a wave's load is 1 KB of consecutive memory.  With a
+// thread per row such rows put every lane of a load on its own cache line, 16 lines per lane and pass: d = 32 fp64 ran at 0.4 TB/s.
+// d = G VW <= 64, G a power of two; one right-hand side.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void dot_vtag_kernel(const T* __restrict__ Y, int64_t m, const T* __restrict__ a, T* __restrict__ zpart, int64_t per,
+                                                       unsigned* __restrict__ ticket, T* __restrict__ z) {
+    constexpr int VW = 16 / (int)sizeof(T), RPW = 64 / G, D = G * VW, UN = 8;
+    using VT = typename VecOf<T, VW>::type;
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < m) ? (j0 + per) : m;
+    __shared__ T red[8 * 32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane % G, rr = lane / G;
+    T acc[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) acc[e] = (T)0;
+    int64_t j = j0 + wv * RPW + rr;
+    for (; j + (int64_t)(UN - 1) * 4 * RPW < j1; j += (int64_t)UN * 4 * RPW) {
+        T av[UN]; VT yv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { av[u] = a[j + u * 4 * RPW]; yv[u] = *reinterpret_cast<const VT*>(Y + (j + u * 4 * RPW) * (int64_t)D + g * VW); }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[e] = fma_t(yv[u][e], av[u], acc[e]);
+    }
+    for (; j < j1; j += 4 * RPW) {
+        const T av = a[j]; const VT yv = *reinterpret_cast<const VT*>(Y + j * (int64_t)D + g * VW);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[e] = fma_t(yv[e], av, acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+        T s = acc[e];
+#pragma unroll
+        for (int o = 32; o >= G; o >>= 1) s += __shfl_xor(s, o);          // the lanes that hold the same vector of other rows
+        if (lane < G) red[wv * D + g * VW + e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < D)
+        slab_store(zpart + (int64_t)blockIdx.x * D + threadIdx.x, (red[threadIdx.x] + red[D + threadIdx.x]) + (red[2 * D + threadIdx.x] + red[3 * D + threadIdx.x]), ticket != nullptr);
+    __syncthreads();
+    if (ticket == nullptr || !last_arrival(ticket, gridDim.x)) return;
+    slab_tail_sum<T>(zpart, z, (int64_t)D, red);
+}
+
+// y[i] = alpha sum_c X[i][c] z[c] + beta y[i] in the same lane-group layout: a lane keeps its vector of z, KR rows per lane group and block
+template <typename T, int G>
+__global__ __launch_bounds__(256) void dot_xzg_kernel(const T* __restrict__ X, int64_t n, const T* __restrict__ zg, T* __restrict__ y, T alpha, T beta) {
+    constexpr int VW = 16 / (int)sizeof(T), RPB = 256 / G, D = G * VW, KR = 8;
+    using VT = typename VecOf<T, VW>::type;
+    const int g = threadIdx.x % G, rr = threadIdx.x / G;
+    const VT zv = *reinterpret_cast<const VT*>(zg + g * VW);
+    const int64_t i0 = (int64_t)blockIdx.x * RPB * KR + rr;
+    VT xv[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int64_t i = i0 + (int64_t)k * RPB;
+        xv[k] = *reinterpret_cast<const VT*>(X + (i < n ? i : n - 1) * (int64_t)D + g * VW);
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        T s = (T)0;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s = fma_t(xv[k][e], zv[e], s);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const int64_t i = i0 + (int64_t)k * RPB;
+        if (g == 0 && i < n) {
+            T v = alpha * s;
+            if (beta != (T)0) v = fma_t(beta, y[i], v);
+            y[i] = v;
+        }
+    }
+}
+
 // y[i + q ldy] = alpha sum_c X[i][c] z[c + q d] + beta y[i + q ldy]: a thread per row, z (d x nrhs) in LDS
 template <typename T>
 __global__ __launch_bounds__(256) void dot_xz_kernel(const T* __restrict__ X, int64_t n, int32_t d, const T* __restrict__ zg, int32_t nrhs,
@@ -523,8 +679,9 @@ static int dot_factored_run(covgram_ctx* ctx, const covgram_points* X, const cov
                             T alpha, T beta) {
     const int64_t n = X->n, m = Y->n;
     const int d = X->d;
-    int64_t per = (m + (int64_t)ctx->num_cus * 4 - 1) / ((int64_t)ctx->num_cus * 4);
-    per = std::max<int64_t>(256, ((per + 255) / 256) * 256);
+    const int64_t slabs_per_cu = nrhs == 1 ? 2 : 4;            // one rhs: few long slabs (four rows per thread in flight; the last workgroup adds one partial per slab)
+    int64_t per = (m + (int64_t)ctx->num_cus * slabs_per_cu - 1) / ((int64_t)ctx->num_cus * slabs_per_cu);
+    per = std::max<int64_t>(1024, ((per + 1023) / 1024) * 1024);
     const int64_t nslab = (m + per - 1) / per;
     const int64_t dq = (int64_t)d * nrhs;
     const size_t zoff = ((size_t)nslab * dq + 63) & ~(size_t)63;
@@ -534,8 +691,31 @@ static int dot_factored_run(covgram_ctx* ctx, const covgram_points* X, const cov
     T* zpart = (T*)w;
     T* z = zpart + zoff;
     CG_REQUIRE((size_t)dq * sizeof(T) <= 65536, COVGRAM_EUNSUPPORTED, "factored dot product: d * nrhs = %lld exceeds the 64 KB of LDS", (long long)dq);
-    hipLaunchKernelGGL(dot_vta_kernel<T>, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, (const T*)Y->dptr, m, d, a, lda, nrhs, zpart, per);
-    hipLaunchKernelGGL(lowrank_zsum_kernel<T>, dim3((unsigned)((dq + 31) / 32)), dim3(256), 0, ctx->stream, (const T*)zpart, nslab, dq, z);
+    constexpr int VW = 16 / (int)sizeof(T);
+    const bool vecY = d % VW == 0 && ((uintptr_t)Y->dptr % 16) == 0, vecX = d % VW == 0 && ((uintptr_t)X->dptr % 16) == 0;
+    const int G = d / VW;                                         // lanes per row of the lane-group kernels: rows of more than 64 bytes, d <= 64
+    const bool grp = nrhs == 1 && d % VW == 0 && (G & (G - 1)) == 0 && G >= 2 && d <= 64;
+    bool xdone = false;
+    if (nrhs == 1 && d <= 128) {
+        unsigned* ticket = nullptr;
+        rc = tickets_reserve(ctx, 1, &ticket);
+        if (rc) return rc;
+#define CG_DOTG(GV) do { if (grp && vecY && G == GV) { hipLaunchKernelGGL((dot_vtag_kernel<T, GV>), dim3((unsigned)nslab), dim3(256), 0, ctx->stream, (const T*)Y->dptr, m, a, zpart, per, ticket, z); ydone = true; } } while (0)
+#define CG_DOT1(DCV) do { if (vecY) hipLaunchKernelGGL((dot_vta1_kernel<T, DCV, true>), dim3((unsigned)nslab), dim3(256), 0, ctx->stream, (const T*)Y->dptr, m, d, a, zpart, per, ticket, z); \
+                          else hipLaunchKernelGGL((dot_vta1_kernel<T, DCV, false>), dim3((unsigned)nslab), dim3(256), 0, ctx->stream, (const T*)Y->dptr, m, d, a, zpart, per, ticket, z); } while (0)
+        bool ydone = false;
+        CG_DOTG(2); CG_DOTG(4); CG_DOTG(8); CG_DOTG(16); CG_DOTG(32);
+        if (!ydone) { if (d <= 4) CG_DOT1(4); else if (d <= 8) CG_DOT1(8); else CG_DOT1(16); }
+#undef CG_DOT1
+#undef CG_DOTG
+#define CG_XZG(GV) do { if (grp && vecX && G == GV) { hipLaunchKernelGGL((dot_xzg_kernel<T, GV>), dim3((unsigned)((n + (256 / GV) * 8 - 1) / ((256 / GV) * 8))), dim3(256), 0, ctx->stream, (const T*)X->dptr, n, (const T*)z, y, alpha, beta); xdone = true; } } while (0)
+        CG_XZG(2); CG_XZG(4); CG_XZG(8); CG_XZG(16); CG_XZG(32);
+#undef CG_XZG
+    } else {
+        hipLaunchKernelGGL(dot_vta_kernel<T>, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, (const T*)Y->dptr, m, d, a, lda, nrhs, zpart, per);
+        hipLaunchKernelGGL(lowrank_zsum_kernel<T>, dim3((unsigned)((dq + 31) / 32)), dim3(256), 0, ctx->stream, (const T*)zpart, nslab, dq, z);
+    }
+    if (!xdone)
     hipLaunchKernelGGL(dot_xz_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)dq * sizeof(T), ctx->stream, (const T*)X->dptr, n, d,
                        (const T*)z, nrhs, y, ldy, alpha, beta);
     hipError_t e = hipGetLastError();

@@ -371,11 +371,13 @@ def test_lowrank_matrix_rhs_on_the_matrix_cores(cg, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("d", [1, 3, 17, 70])
+@pytest.mark.parametrize("d", [1, 3, 4, 8, 12, 16, 17, 32, 64, 70])
 def test_dot_gramian_is_applied_as_x_yt_a(cg, oracle, dtype, d):
     """Gramian(Dot(), x, y) (src/gramian.jl:23,150-151; src/mercer.jl:6-9) is X Y': the library applies it as X (Y' a) — two
     streaming passes instead of the reference's O(n m d) entry loop — for vectors and matrices, alpha / beta, a scaled kernel;
-    dense_variant = 1 keeps the entry-by-entry kernel and both agree with the oracle.  Dot()^2 is not a product of thin factors."""
+    dense_variant = 1 keeps the entry-by-entry kernel and both agree with the oracle.  Dot()^2 is not a product of thin factors.
+    The d list covers the one-right-hand-side kernels of round 5: scalar rows (1, 3, 17, 70), whole-vector rows (4, 8, 12), and the lane-group
+    kernels for rows of more than 64 bytes (16 fp64, 32, 64; 16 fp32 stays on the vector rows)."""
     rng = np.random.default_rng(70 + d)
     dt = npdt(dtype)
     tol = TOL[dtype]
@@ -1795,3 +1797,22 @@ def test_fp64_symmetric_direct_kernel(cg, oracle):
         assert cg.get_info("last_dense_sym") == 0 and float(res.norm() / b.norm()) <= 1e-8
     finally:
         cg.set_option("dense_sym", -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n,m,d", [(70001, 50003, 3), (33333, 66667, 8), (40000, 40001, 32), (9, 5000, 16), (5000, 7, 64), (20011, 30011, 5)])
+def test_dot_gramian_long_ragged_point_sets(cg, oracle, dtype, n, m, d):
+    """The same product on point sets long enough for several row slabs, trips of four (eight) rows in flight and the last workgroup's slab sum,
+    with ragged ends; against numpy in fp64."""
+    rng = np.random.default_rng(n + m + d)
+    dt = npdt(dtype)
+    X = rng.standard_normal((n, d)).astype(dt); Y = rng.standard_normal((m, d)).astype(dt); a = rng.standard_normal(m).astype(dt); y0 = rng.standard_normal(n).astype(dt)
+    G = cg.gramian(cg.Dot(), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+    ref = X.astype(np.float64) @ (Y.astype(np.float64).T @ a.astype(np.float64))
+    yd = torch.full((n,), float("nan"), dtype=dtype, device="cuda")
+    cg.mul_(yd, G, torch.from_numpy(a).cuda())
+    assert cg.get_info("last_dense_path") == 4
+    assert relerr(yd.cpu().numpy(), ref) <= (2e-6 if dtype == torch.float32 else 1e-13)
+    yd = torch.from_numpy(y0.copy()).cuda()
+    cg.mul_(yd, G, torch.from_numpy(a).cuda(), -0.7, 1.3)
+    assert relerr(yd.cpu().numpy(), -0.7 * ref + 1.3 * y0.astype(np.float64)) <= (2e-6 if dtype == torch.float32 else 1e-13)
