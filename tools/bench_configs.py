@@ -166,7 +166,7 @@ def main():
     # ---- composite kernels and ValueGradientKernel ------------------------------------------------
     kc = 1.5 * cg.Lengthscale(cg.MaternP(2), 0.7) + 0.5 * cg.Lengthscale(cg.EQ(), 2.0)
     kco = o.Composite(((o.Kernel(o.MATERNP, p=2, lengthscale=0.7, scale=1.5),), (o.Kernel(o.EQ, lengthscale=2.0, scale=0.5),)), o.ISOTROPIC, 1.0)
-    dense("F2-composite", kc, kco, 131072, 3, torch.float32, note="; composite 1.5*MaternP(2; l=0.7) + 0.5*EQ(l=2) one MVM per term (MaternP lane-per-row + EQ matrix cores)")
+    dense("F2-composite", kc, kco, 131072, 3, torch.float32, note="; composite 1.5*MaternP(2; l=0.7) + 0.5*EQ(l=2) one symmetric matrix-core MVM per term (the library's rule for two terms)")
     for tag, kern, ko, mul_o, blk in (("F2-valgrad", cg.ValueGradientKernel(cg.EQ()), o.Kernel(o.EQ), o.valgrad_mul, d4 + 1),
                                       ("F2-composite-grad", cg.GradientKernel(cg.EQ() * cg.RQ(1.0)), o.Composite(((o.Kernel(o.EQ), o.Kernel(o.RQ, param=1.0)),)), o.grad_mul, d4)):
         rng = np.random.default_rng(0xC0F + 7)
