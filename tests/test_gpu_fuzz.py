@@ -1,163 +1,107 @@
-"""GPU tier: seeded random sweep over shapes / kernels / right-hand sides / alpha-beta for the dense, gradient and value-gradient
-entry points — ragged sizes around every tile edge (32-row MFMA tiles, 64-row waves, 512-column chunks, 4-RHS passes), both dense
-paths (matrix cores and direct differences), against the fp64 oracle."""
+"""Seeded random sweep over the dense MVM's routing space: kernel family x precision x d x (n, m) x one / two point sets x alpha, beta x the options that
+pick among the round-5 kernels (symmetric forms forced on below their automatic size, row tiles per wave, fp16 / bf16 split, one-pass Sum).  Every
+case is checked against the fp64 oracle of src/gramian.jl:78-87 norm-wise and row-wise; sizes are small (the oracle is O(n m)) and deliberately
+ragged around the 32-row tiles and 256-row panels of the matrix-core kernels."""
 import numpy as np
 import pytest
 import torch
 
-import kernel_cases
-
 pytestmark = pytest.mark.gpu
 
-
-def relerr(b, ref):
-    b = np.asarray(b, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
-    den = np.linalg.norm(ref)
-    return np.linalg.norm(b - ref) / (den if den > 0 else 1.0)
+SIZES = [1, 2, 31, 32, 33, 63, 65, 255, 256, 257, 300, 511, 513, 777, 1025, 1300]
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_random_dense_cases(cg, oracle, seed):
-    rng = np.random.default_rng(1000 + seed)
-    cases = kernel_cases.cases(cg) + kernel_cases.composite_cases(cg)
+def _kernels(cg, o, rng):
+    L = cg.Lengthscale
+    l = float(rng.uniform(0.7, 2.5)); al = float(rng.uniform(0.6, 2.5))
+    fams = [
+        ("EQ", L(cg.EQ(), l), [(1.0, o.Kernel(o.EQ, lengthscale=l))]),
+        ("MaternP1", L(cg.MaternP(1), l), [(1.0, o.Kernel(o.MATERNP, p=1, lengthscale=l))]),
+        ("MaternP2", L(cg.MaternP(2), l), [(1.0, o.Kernel(o.MATERNP, p=2, lengthscale=l))]),
+        ("MaternP3", L(cg.MaternP(3), l), [(1.0, o.Kernel(o.MATERNP, p=3, lengthscale=l))]),
+        ("RQ", L(cg.RQ(al), l), [(1.0, o.Kernel(o.RQ, param=al, lengthscale=l))]),
+        ("Cauchy", L(cg.Cauchy(), l), [(1.0, o.Kernel(o.CAUCHY, lengthscale=l))]),
+        ("IMQ", cg.InverseMultiQuadratic(al), [(1.0, o.Kernel(o.IMQ, param=al))]),
+        ("Exp", L(cg.Exp(), l), [(1.0, o.Kernel(o.EXP, lengthscale=l))]),
+        ("Dot", cg.Dot(), [(1.0, o.Kernel(o.DOT))]),
+        ("M2+EQ", 1.5 * L(cg.MaternP(2), l) + 0.5 * cg.EQ(), [(1.5, o.Kernel(o.MATERNP, p=2, lengthscale=l)), (0.5, o.Kernel(o.EQ))]),
+        ("EQ+RQ+M1", L(cg.EQ(), l) + 0.7 * cg.RQ(al) + 0.2 * cg.MaternP(1), [(1.0, o.Kernel(o.EQ, lengthscale=l)), (0.7, o.Kernel(o.RQ, param=al)), (0.2, o.Kernel(o.MATERNP, p=1))]),
+    ]
+    return fams[int(rng.integers(len(fams)))]
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_routing_cases_match_the_oracle(cg, oracle, seed):
+    o = oracle
+    rng = np.random.default_rng(90000 + seed)
+    opts = {"mfma_sym": int(rng.choice([-1, 1, 1, 0])), "mfma_sym_rt": int(rng.choice([-1, 1, 2])), "mfma_f16": int(rng.choice([-1, 0, -1])),
+            "sum_fused": int(rng.choice([-1, 0, 1])), "dense_variant": int(rng.choice([0, 0, 0, 2, 1])), "dense_sym": int(rng.choice([-1, 1]))}
     try:
-        for _ in range(14):
-            name, k, ko = cases[rng.integers(len(cases))]
-            dt = [np.float32, np.float64][rng.integers(2)]
-            d = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 70]))
-            n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257, 300]))
-            m = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 513, 1025]))
-            p = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 9]))
-            alpha, beta = [(1.0, 0.0), (-0.7, 1.3), (2.0, 0.0), (0.0, 0.5)][rng.integers(4)]
-            variant = int(rng.choice([0, 1, 2]))
-            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(dt)
-            A = rng.standard_normal((m, p)).astype(dt); Y0 = rng.standard_normal((n, p)).astype(dt)
-            if p == 1: A, Y0 = A[:, 0], Y0[:, 0]
-            cg.set_option("dense_variant", variant)
-            G = cg.gramian(k, torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
-            yd = torch.from_numpy(Y0.copy()).cuda()
-            if beta == 0.0:
-                yd.fill_(float("nan"))                                   # beta == 0 must not read y
-            cg.mul_(yd, G, torch.from_numpy(A).cuda(), alpha, beta)
-            ref = oracle.mul(Y0, ko, X, Y, A, alpha, beta, dt)
-            tol = 1e-5 if dt == np.float32 else 1e-12
-            e = relerr(yd.cpu().numpy(), ref)
-            assert e <= tol or np.linalg.norm(ref) < 1e-30, (name, dt.__name__, d, n, m, p, alpha, beta, variant, e)
+        for key, v in opts.items(): cg.set_option(key, v)
+        for rep in range(4):
+            name, k, terms = _kernels(cg, o, rng)
+            dtype = torch.float32 if rng.random() < 0.7 else torch.float64
+            d = int(rng.choice([1, 2, 3, 3, 4, 5, 6, 8, 11, 14, 16]))
+            n = int(rng.choice(SIZES)); same = rng.random() < 0.55
+            m = n if same else int(rng.choice(SIZES))
+            scale = float(rng.choice([0.3, 0.8, 1.5]))
+            npd = np.float32 if dtype == torch.float32 else np.float64
+            Xh = (scale * rng.standard_normal((n, d)) + 0.2).astype(npd); Yh = Xh if same else (scale * rng.standard_normal((m, d))).astype(npd)
+            ah = rng.standard_normal(m).astype(npd); y0 = rng.standard_normal(n).astype(npd)
+            alpha, beta = (1.0, 0.0) if rng.random() < 0.5 else (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)))
+            X = torch.from_numpy(Xh).cuda(); Y = X if same else torch.from_numpy(Yh).cuda()
+            G = cg.gramian(k, X) if same else cg.gramian(k, X, Y)
+            y = torch.from_numpy(y0.copy()).cuda() if beta != 0.0 else torch.full((n,), float("nan"), dtype=dtype, device="cuda")
+            cg.mul_(y, G, torch.from_numpy(ah).cuda(), alpha, beta)
+            Xd, Yd, ad = Xh.astype(np.float64), Yh.astype(np.float64), ah.astype(np.float64)
+            Gab = sum(c * o.mul(None, kk, Xd, Yd, ad) for c, kk in terms)
+            absG = sum(abs(c) * (np.abs(o.matrix(kk, Xd, Yd)) @ np.abs(ad)) for c, kk in terms)
+            ref = alpha * Gab + (beta * y0.astype(np.float64) if beta != 0.0 else 0.0)
+            scale_r = abs(alpha) * absG + (abs(beta) * np.abs(y0.astype(np.float64)) if beta != 0.0 else 0.0) + 1e-300
+            got = y.cpu().numpy().astype(np.float64)
+            tol = 1e-5 if dtype == torch.float32 else 1e-12
+            info = (seed, rep, name, str(dtype), d, n, m, same, alpha, beta, opts, cg.get_info("last_dense_path"), cg.get_info("last_mfma_sym"), cg.get_info("last_mfma_f16"))
+            assert np.isfinite(got).all(), info
+            assert np.linalg.norm(got - ref) <= tol * max(np.linalg.norm(ref), np.linalg.norm(scale_r) * 1e-2), info
+            assert float(np.max(np.abs(got - ref) / scale_r)) <= tol, info + (float(np.max(np.abs(got - ref) / scale_r)),)
     finally:
-        cg.set_option("dense_variant", 0)
+        for key, v in {"mfma_sym": -1, "mfma_sym_rt": -1, "mfma_f16": -1, "sum_fused": -1, "dense_variant": 0, "dense_sym": -1}.items(): cg.set_option(key, v)
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_random_symmetric_cases(cg, oracle, seed):
-    """gramian(k, x) with the symmetric upper-triangle kernels forced on (mfma_sym = 1, dense_sym = 1, dense_variant = 2 where the shape allows):
-    every kernel case, random n around the 32-row tiles / 256-row panels / 64-tile chunks, random chunk splits, alpha / beta, the
-    multi-GPU partial form for a random world size — whatever path the library ends up taking must match the fp64 oracle."""
-    rng = np.random.default_rng(5000 + seed)
-    cases = kernel_cases.cases(cg) + kernel_cases.composite_cases(cg)
+@pytest.mark.parametrize("seed", range(24))
+def test_random_gradient_cases_match_the_oracle(cg, oracle, seed):
+    """GradientKernel / ValueGradientKernel block MVMs (src/gramian.jl:241-253, src/gradient.jl:86-92, 319-351): family x precision x d x sizes x
+    one / two point sets x alpha, beta x expanded / direct form x broadcast kernels on or off, against the fp64 oracle."""
+    o = oracle
+    rng = np.random.default_rng(91000 + seed)
+    opts = {"grad_expand": int(rng.choice([-1, 0, 1])), "grad_bcast": int(rng.choice([-1, 0, 1])), "grad_keep_r": int(rng.choice([-1, -1, 0, 1]))}
     try:
-        for _ in range(14):
-            name, k, ko = cases[rng.integers(len(cases))]
-            dt = [np.float32, np.float32, np.float64][rng.integers(3)]
-            d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17, 24, 33, 48, 64]))      # (from 16: the fp64 broadcast kernels of round 4, symmetric form)
-            n = int(rng.choice([1, 2, 31, 33, 255, 256, 257, 511, 513, 1000, 2047, 2049, 2600]))
-            alpha, beta = [(1.0, 0.0), (-0.7, 1.3), (2.0, 0.0)][rng.integers(3)]
-            X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt)
-            a = rng.standard_normal(n).astype(dt); y0 = rng.standard_normal(n).astype(dt)
-            cg.set_option("mfma_sym", 1); cg.set_option("dense_variant", int(rng.choice([0, 2]))); cg.set_option("jsplit", int(rng.choice([0, 0, 2, 5])))
-            cg.set_option("dense_sym", 1)                     # the direct-difference symmetric kernels (fp64, fp32) wherever they are eligible
-            cg.set_option("mfma_f16", int(rng.choice([-1, 0, 1])))      # fp32 EQ on the matrix cores: fp16 two-way / bf16 three-way split of the coordinates
-            cg.set_option("dense_bcast", int(rng.choice([-1, 0, 1])))   # fp64: expanded distance with broadcast records — by rule, never, from d = 8
-            Xd = torch.from_numpy(X).cuda(); ad = torch.from_numpy(a).cuda()
-            G = cg.gramian(k, Xd)
-            yd = torch.from_numpy(y0.copy()).cuda()
-            if beta == 0.0:
-                yd.fill_(float("nan"))
-            cg.mul_(yd, G, ad, alpha, beta)
-            ref = oracle.mul(y0, ko, X, X, a, alpha, beta, dt)
-            tol = 1e-5 if dt == np.float32 else 1e-12
-            e = relerr(yd.cpu().numpy(), ref)
-            assert e <= tol or np.linalg.norm(ref) < 1e-30, (name, dt.__name__, d, n, alpha, beta, cg.get_info("last_mfma_sym"), e)
-            if hasattr(G, "sym_partial_supported") and G.sym_partial_supported():
-                world = int(rng.choice([2, 3, 5]))
-                tot = torch.zeros(n, dtype=Xd.dtype, device="cuda"); part = torch.empty_like(tot)   # (fp32 matrix-core panels or fp64 direct-difference blocks)
-                for r in range(world):
-                    G.sym_partial_(part, ad, r, world); tot += part
-                e = relerr(tot.cpu().numpy(), oracle.mul(None, ko, X, X, a, dtype=dt))
-                assert e <= tol, (name, d, n, world, e)
+        for key, v in opts.items(): cg.set_option(key, v)
+        for rep in range(3):
+            l = float(rng.uniform(0.8, 2.0)); al = float(rng.uniform(0.7, 2.0))
+            name, kin, ko = [("EQ", cg.Lengthscale(cg.EQ(), l), o.Kernel(o.EQ, lengthscale=l)), ("RQ", cg.RQ(al), o.Kernel(o.RQ, param=al)),
+                             ("MaternP2", cg.Lengthscale(cg.MaternP(2), l), o.Kernel(o.MATERNP, p=2, lengthscale=l)), ("MaternP3", cg.MaternP(3), o.Kernel(o.MATERNP, p=3)),
+                             ("Cauchy", cg.Cauchy(), o.Kernel(o.CAUCHY)), ("Dot^3", cg.Dot() ** 3, o.Kernel(o.DOT, power=3))][int(rng.integers(6))]
+            vg = rng.random() < 0.3
+            dtype = torch.float64 if rng.random() < 0.6 else torch.float32
+            npd = np.float64 if dtype == torch.float64 else np.float32
+            d = int(rng.choice([1, 2, 3, 5, 8, 16, 24, 32])); blk = d + 1 if vg else d
+            n = int(rng.choice([1, 2, 33, 64, 65, 130, 257])); same = rng.random() < 0.6; m = n if same else int(rng.choice([1, 17, 64, 100, 200]))
+            sc = 0.6 / np.sqrt(d) if name == "Dot^3" else 0.8
+            Xh = (sc * rng.standard_normal((n, d))).astype(npd); Yh = Xh if same else (sc * rng.standard_normal((m, d))).astype(npd)
+            ah = rng.standard_normal(m * blk).astype(npd); y0 = rng.standard_normal(n * blk).astype(npd)
+            alpha, beta = (1.0, 0.0) if rng.random() < 0.5 else (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)))
+            X = torch.from_numpy(Xh).cuda(); Y = X if same else torch.from_numpy(Yh).cuda()
+            K = cg.ValueGradientKernel(kin) if vg else cg.GradientKernel(kin)
+            G = cg.gramian(K, X) if same else cg.gramian(K, X, Y)
+            y = torch.from_numpy(y0.copy()).cuda() if beta != 0.0 else torch.full((n * blk,), float("nan"), dtype=dtype, device="cuda")
+            cg.mul_(y, G, torch.from_numpy(ah).cuda(), alpha, beta)
+            f = o.valgrad_mul if vg else o.grad_mul
+            ref = np.asarray(f(y0 if beta != 0.0 else None, ko, Xh, Yh, ah, alpha, beta)).reshape(-1)
+            got = y.cpu().numpy().astype(np.float64)
+            tol = 2e-5 if dtype == torch.float32 else 1e-11
+            info = (seed, rep, name, "valgrad" if vg else "grad", str(dtype), d, n, m, same, alpha, beta, opts)
+            assert np.isfinite(got).all(), info
+            assert np.linalg.norm(got - ref) <= tol * max(np.linalg.norm(ref), 1e-30) + (1e-6 if dtype == torch.float32 else 1e-13) * np.linalg.norm(ah), info + (np.linalg.norm(got - ref) / np.linalg.norm(ref),)
     finally:
-        cg.set_option("mfma_sym", -1); cg.set_option("dense_variant", 0); cg.set_option("jsplit", 0); cg.set_option("dense_sym", -1); cg.set_option("dense_bcast", -1); cg.set_option("mfma_f16", -1)
-
-
-@pytest.mark.parametrize("seed", range(4))
-def test_random_gradient_cases(cg, oracle, seed):
-    rng = np.random.default_rng(2000 + seed)
-    cases = kernel_cases.grad_cases(cg) + kernel_cases.composite_cases(cg)
-    for _ in range(10):
-        name, k, ko = cases[rng.integers(len(cases))]
-        dt = [np.float32, np.float64][rng.integers(2)]
-        d = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 31, 32, 48, 49, 64, 65, 80]))
-        n = int(rng.choice([1, 2, 33, 64, 65, 130]))
-        m = int(rng.choice([1, 2, 31, 64, 65, 200, 513]))
-        vg = bool(rng.integers(2))
-        bd = d + (1 if vg else 0)
-        alpha, beta = [(1.0, 0.0), (-0.7, 1.3), (0.5, 0.0)][rng.integers(3)]
-        X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dt); Y = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(dt)
-        a = rng.standard_normal(m * bd).astype(dt); y0 = rng.standard_normal(n * bd).astype(dt)
-        K = cg.gramian((cg.ValueGradientKernel if vg else cg.GradientKernel)(k), torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
-        cg.set_option("grad_bcast", int(rng.choice([-1, 0, 1, 4])))      # fp64 expanded form: scalar stream / broadcast records (round 4), by rule or forced
-        yd = torch.from_numpy(y0.copy()).cuda()
-        if beta == 0.0:
-            yd.fill_(float("nan"))
-        cg.mul_(yd, K, torch.from_numpy(a).cuda(), alpha, beta)
-        ref = (oracle.valgrad_mul if vg else oracle.grad_mul)(y0, ko, X, Y, a, alpha, beta, dt)
-        tol = 1e-5 if dt == np.float32 else 1e-12
-        e = relerr(yd.cpu().numpy(), ref)
-        cg.set_option("grad_bcast", -1)
-        assert e <= tol, (name, dt.__name__, d, n, m, vg, alpha, beta, e)
-
-
-@pytest.mark.parametrize("seed", range(3))
-def test_random_structured_cases(cg, oracle, seed):
-    """Toeplitz (rectangular, around the four-step / fused thresholds), circulant, Kronecker (ragged factor shapes), low rank."""
-    import ctypes as C
-    rng = np.random.default_rng(3000 + seed)
-    f = cg._ffi
-    for _ in range(6):
-        dt = [np.float32, np.float64][rng.integers(2)]
-        tdt = torch.float32 if dt == np.float32 else torch.float64
-        tol = 1e-5 if dt == np.float32 else 1e-10
-        n = int(rng.choice([1, 2, 5, 100, 4095, 4096, 8191, 8193, 16385, 40000, 70001]))
-        m = int(rng.choice([1, 3, 64, 4097, 8192, 30000, 65537]))
-        vc = rng.standard_normal(n).astype(dt); vr = rng.standard_normal(m).astype(dt); vr[0] = vc[0]
-        a = rng.standard_normal(m).astype(dt); y0 = rng.standard_normal(n).astype(dt)
-        T = cg.Toeplitz(torch.from_numpy(vc).cuda(), torch.from_numpy(vr).cuda())
-        yd = torch.from_numpy(y0.copy()).cuda()
-        cg.mul_(yd, T, torch.from_numpy(a).cuda(), 0.5, -1.5)
-        ref = oracle.toeplitz_mul(y0, vc, vr, a, 0.5, -1.5)
-        assert relerr(yd.cpu().numpy(), ref) <= tol, ("toeplitz", dt.__name__, n, m, relerr(yd.cpu().numpy(), ref))
-    for _ in range(3):
-        nc = int(rng.choice([1, 2, 33, 1000, 4099]))
-        vc = rng.standard_normal(nc); a = rng.standard_normal(nc)
-        Cc = cg.Circulant(torch.from_numpy(vc).cuda())
-        assert relerr((Cc @ torch.from_numpy(a).cuda()).cpu().numpy(), oracle.toeplitz_mul(None, vc, None, a, circulant=True)) <= 1e-10
-    for _ in range(4):
-        q = int(rng.integers(1, 5))
-        shapes = [(int(rng.integers(1, 9)), int(rng.integers(1, 9))) for _ in range(q)]
-        Fs = [rng.standard_normal(s) for s in shapes]
-        a = rng.standard_normal(int(np.prod([s[1] for s in shapes]))); y0 = rng.standard_normal(int(np.prod([s[0] for s in shapes])))
-        Kp = cg.kronecker(*[torch.from_numpy(Fm).cuda() for Fm in Fs])
-        yd = torch.from_numpy(y0.copy()).cuda()
-        cg.mul_(yd, Kp, torch.from_numpy(a).cuda(), -0.3, 0.9)
-        dense = Fs[0]
-        for Fm in Fs[1:]: dense = np.kron(dense, Fm)
-        assert relerr(yd.cpu().numpy(), -0.3 * dense @ a + 0.9 * y0) <= 1e-12, ("kron", shapes)
-    for _ in range(4):
-        n, m, r = int(rng.choice([1, 7, 1023, 1025, 5000])), int(rng.choice([1, 9, 1024, 3001])), int(rng.choice([1, 2, 31, 32, 33, 70]))
-        dt = [np.float32, np.float64][rng.integers(2)]
-        tdt = torch.float32 if dt == np.float32 else torch.float64
-        U = rng.standard_normal((n, r)).astype(dt); V = rng.standard_normal((m, r)).astype(dt)
-        a = rng.standard_normal(m).astype(dt); y0 = rng.standard_normal(n).astype(dt)
-        Lp = cg.LazyMatrixProduct(torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda())
-        yd = torch.from_numpy(y0.copy()).cuda()
-        cg.mul_(yd, Lp, torch.from_numpy(a).cuda(), 1.5, -0.5)
-        assert relerr(yd.cpu().numpy(), oracle.lowrank_mul(y0, U, V, a, 1.5, -0.5)) <= (1e-5 if dt == np.float32 else 1e-12), ("lowrank", n, m, r)
+        for key in opts: cg.set_option(key, -1)
