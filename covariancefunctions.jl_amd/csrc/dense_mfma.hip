@@ -216,7 +216,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
         typedef __attribute__((address_space(1))) const void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        float gw = 0.0f;
+        // (gw, ge): loaded with the tile's LDS-DMA, multiplied only where the weight is stored after the tile's arithmetic (as in the LDS == 1 form
+        // below; round 5: here the product sat right behind the loads — one exposed memory round trip per TILE for wave 0, and the barrier passes it on)
+        float gw = 0.0f, ge = 1.0f;
 #define CG_DMA2(tile, TF)                                                                       \
         {                                                                                       \
             const int ti_ = (tile);                                                             \
@@ -225,31 +227,37 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(LDS ==
                 const int mm = wv + q * WPB;                                                    \
                 if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
             }                                                                                   \
-            if (wv == 0) gw = ti_ < nt ? weight(tc_) : 0.0f;                                    \
+            if (wv == 0) {                                                                      \
+                if (EF == nullptr) gw = ti_ < nt ? wbase[tc_ * 32 + t] : 0.0f;                  \
+                else {                                                                          \
+                    const int64_t j_ = (T0 + tc_) * 32 + t;                                     \
+                    const bool in_ = ti_ < nt && j_ < mcols;                                    \
+                    gw = in_ ? W[j_] : 0.0f; ge = in_ ? EF[j_] : 0.0f;                          \
+                }                                                                               \
+            }                                                                                   \
         }
 #define CG_TILE2(TF, TW)                                                                        \
         {                                                                                       \
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
-            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
-                Frag f; f.u = TF[mm][l];                                                        \
-                D = eq_mma<FMT>(a[0][mm], f, D);                                                \
-            }                                                                                   \
+            Frag f_[K2];                                                                        \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f_[mm].u = TF[mm][l];             \
             const float w = TW[t];                                                              \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) D = eq_mma<FMT>(a[0][mm], f_[mm], D); \
             _Pragma("unroll") for (int v = 0; v < 16; ++v) D[v] = __builtin_amdgcn_exp2f(D[v]); \
             _Pragma("unroll") for (int v = 0; v < 8; ++v) { acc2[0][v][0] = __builtin_fmaf(w, D[2 * v], acc2[0][v][0]); acc2[0][v][1] = __builtin_fmaf(w, D[2 * v + 1], acc2[0][v][1]); } \
         }
         CG_DMA2(0, tfA)
-        if (wv == 0 && h == 0) twA[t] = gw;
+        if (wv == 0 && h == 0) twA[t] = gw * ge;
         __syncthreads();
         for (int ti = 0; ti < nt; ti += 2) {
             CG_DMA2(ti + 1, tfB)                                    // past the chunk: a re-fetch nobody reads
             CG_TILE2(tfA, twA)
-            if (wv == 0 && h == 0) twB[t] = gw;
+            if (wv == 0 && h == 0) twB[t] = gw * ge;
             __syncthreads();
             if (ti + 1 >= nt) break;
             CG_DMA2(ti + 2, tfA)
             CG_TILE2(tfB, twB)
-            if (wv == 0 && h == 0) twA[t] = gw;
+            if (wv == 0 && h == 0) twA[t] = gw * ge;
             __syncthreads();
         }
 #undef CG_DMA2
@@ -585,7 +593,8 @@ static void launch_mfma(int rt, bool lds4, dim3 grid, hipStream_t st, const floa
         *launched = dim3((grid.x + 3) / 4, grid.y);
         if constexpr (K2 == 3 || K2 == 4) { if (rt == 4) { *inst = enc(K2, 4, 4, 1, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 4, 4, 1, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols); return; } }
         if constexpr (K2 == 1 || K2 == 2 || K2 == 4) { if (stamps) { *inst = enc(K2, 2, 4, 1, 1); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, 2, 4, 1, 1, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, stamps, tickets, yfinal, EF, mcols); return; } }
-        *inst = enc(K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, (NARROW ? 1 : 2), 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
+        constexpr int LDSF = (NARROW || K2 == 6) ? 1 : 2;   // six MFMAs per tile: stages of four tiles too (round 5; one tile per stage before, as the longer fragments still are)
+        *inst = enc(K2, (NARROW ? 2 : 1), 4, LDSF, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<K2, (NARROW ? 2 : 1), 4, LDSF, 0, FMT>), *launched, dim3(256), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
     } else if (rt == 2 && K2 <= 8) {
         *launched = grid;
         *inst = enc((K2 <= 8 ? K2 : 1), 2, 1, 0, 0); hipLaunchKernelGGL((dense_mfma_eq_kernel<(K2 <= 8 ? K2 : 1), 2, 1, 0, 0, FMT>), grid, dim3(64), 0, st, X, n, d, PB, W, ntile, out, npad, tchunk, g, alpha, beta, final_store, Cn, ns, tickets, yfinal, EF, mcols);
@@ -898,7 +907,12 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // row tiles per panel: 8 waves x 1 tile, 6 for the heavy profiles' 3-waves-per-SIMD form, or 4 x 1 for long fragments (dense_mfma.hpp)
     // generic form at one or two MFMAs per tile: two row tiles per wave as the EQ form (dense_mfma_sym2.hpp; option "mfma_sym_rt" = 1: the one-row-tile panels)
     const int gen_rt = (!fast && ctx->mfma_sym_rt != 1 && K2 <= 2 && mfma_sym2_family(lfam)) ? 2 : 1;
-    const int tpp = fast ? (K2 > MFMA_NARROW_MAXK2 ? 4 : 8) : mfma_sym_tiles_per_panel(lfam, K2, gen_rt);
+    // Six MFMAs per tile (d = 17 .. 24 with the fp16 split, 11 .. 12 with bf16): the STAGED 8-wave kernel (four column tiles per stage and barrier, one
+    // tile at a time in registers) instead of the one-tile-per-stage 4-wave kernel — round 5, tools/wide_staged_ab.py: n = 131072, d = 24 2.19 -> 1.89 ms,
+    // d = 20 2.16 -> 1.82.  Eight MFMAs per tile need 169 registers there (two waves per SIMD): 2.55 -> 2.60 ms, so they keep the 4-wave kernel
+    // (option "mfma_sym_st" = 16 forces the staged form for measurements).
+    const bool staged_wide = fast && (K2 == 6 || (K2 == 8 && fmt == 1 && ctx->mfma_sym_st == 16));
+    const int tpp = fast ? ((K2 > MFMA_NARROW_MAXK2 && !staged_wide) ? 4 : 8) : mfma_sym_tiles_per_panel(lfam, K2, gen_rt);
     const int64_t ntile = (n + 31) / 32, panels = (ntile + tpp - 1) / tpp, npad = panels * 32 * tpp + 1088;
     const float g = (float)(sqrt(1.4426950408889634074) / hk.k.lengthscale);
     const float* Cn = (const float*)X->center;
@@ -1008,13 +1022,20 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     if (fast && fmt) {
         switch (K2) {
             CG_SYMH_CASE(1) CG_SYMH_CASE(2) CG_SYMH_CASE(3) CG_SYMH_CASE(4)
-            CG_SYMWH_CASE(6) CG_SYMWH_CASE(8)
+#define CG_SYMSW_CASE(K) case K: if (staged_wide) hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST_H, K>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, KParams<float>{}, EF); \
+                               else hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM_EQFAST_H, K>), grid, dim3(256), 0, ctx->stream, (const float*)X->dptr, n, d, \
+                                                   PBu, W, ntile, (float*)Rp, (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, KParams<float>{}, EF); break;
+            CG_SYMSW_CASE(6) CG_SYMSW_CASE(8)
+#undef CG_SYMSW_CASE
             default: set_error("dense_mfma_sym: K2 = %d not compiled for the fp16 split", K2); return COVGRAM_EUNSUPPORTED;
         }
     } else if (fast) {
         switch (K2) {
             CG_SYM_CASE(1) CG_SYM_CASE(2) CG_SYM_CASE(3) CG_SYM_CASE(4)
-            CG_SYMW_CASE(6) CG_SYMW_CASE(8) CG_SYMW_CASE(12) CG_SYMW_CASE(16)
+            case 6: hipLaunchKernelGGL((dense_mfma_sym_kernel<FAM_EQFAST, 6>), grid, dim3(512), 0, ctx->stream, (const float*)X->dptr, n, d, PBu, W, ntile, (float*)Rp,
+                                       (float*)Sp, npad, (int)tchunk, g, Cn, pfirst, pstride, ctx->sym_map, KParams<float>{}, EF); break;
+            CG_SYMW_CASE(8) CG_SYMW_CASE(12) CG_SYMW_CASE(16)
             default: set_error("dense_mfma_sym: K2 = %d not compiled", K2); return COVGRAM_EUNSUPPORTED;
         }
     } else {

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ ==
         }
     /* the one-pass Sum takes the stage's tiles one at a time: a short loop body the register allocator handles without scratch (two at a time: 36-52 B) */ \
 #define CG_STAGE_M(M_, st_, SF, SW, CS)                                                         \
-        if constexpr (FAM == FAM_SUM_ISO) {                                                     \
+        if constexpr (FAM == FAM_SUM_ISO || K2 > 4) {   /* (long fragments: two tiles' worth would not fit 128 registers) */ \
             _Pragma("unroll 1") for (int k = 0; k < ST; ++k) {                                  \
                 Frag f0[K2];                                                                    \
                 _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f0[mm].u = SF[k][mm][l];      \
@@ -950,7 +950,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float csA[NW][64], csB[NW][64];
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    float gw = 0.0f;
+    float gw = 0.0f, ge = 1.0f, gmask = 0.0f;
+#define CG_GW (FAST ? gw * ge * gmask : gw * gmask)
 #define CG_DMA2(tile, TF)                                                                       \
         {                                                                                       \
             const int ti_ = (tile);                                                             \
@@ -959,17 +960,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int mm = wv + q * NW;                                                     \
                 if (mm < K2) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (tc_ * K2 + mm) * 64 + l), (lptr_t)&TF[mm][0], 16, 0, 0); \
             }                                                                                   \
-            if (wv == 0) gw = wt((T0 + tc_) * 32 + t) * (ti_ < nt ? 1.0f : 0.0f);               \
+            /* the next tile's column weights are LOADED here and combined (a_j e_j, masks) only where they are stored, after the tile's arithmetic: any \
+               use here puts the s_waitcnt vmcnt(0) for them — and for the LDS-DMA beside them — in front of the tile, once per TILE in this kernel */ \
+            if (wv == 0) {                                                                      \
+                const int64_t j_ = (T0 + tc_) * 32 + t;                                         \
+                gmask = (ti_ < nt && (!FAST || j_ < n)) ? 1.0f : 0.0f;                          \
+                if constexpr (FAST) { const int64_t jc_ = j_ < n ? j_ : n - 1; gw = W[jc_]; ge = EF[jc_]; } \
+                else gw = W[j_];                                                                \
+            }                                                                                   \
         }
 #define CG_TILE2(ti_, TF, TW, CS)                                                               \
         {                                                                                       \
             const int64_t J = T0 + (ti_);                                                       \
             f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
-            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) {                                 \
-                Frag f; f.u = TF[mm][l];                                                        \
-                D = eq_mma<FMT>(a[mm], f, D);                                                   \
-            }                                                                                   \
+            Frag f_[K2];                                                                        \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) f_[mm].u = TF[mm][l];             \
             const float w = TW[t];                                                              \
+            _Pragma("unroll") for (int mm = 0; mm < K2; ++mm) D = eq_mma<FMT>(a[mm], f_[mm], D); \
             if constexpr (fam_is_expr<FAM>) {                                                   \
                 float sv[16], kv[16];                                                           \
                 _Pragma("unroll") for (int v = 0; v < 16; ++v) sv[v] = ISO ? fmaxf(D[v], 0.0f) : D[v]; \
@@ -1014,25 +1021,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             S[lp * npad + 32 * (T0 + (ti_)) + t] = s_;                                          \
         }
     CG_DMA2(0, tfA)
-    if (wv == 0 && h == 0) twA[t] = gw;
+    if (wv == 0 && h == 0) twA[t] = CG_GW;
     __syncthreads();
     for (int ti = 0; ti < nt; ti += 2) {
         CG_DMA2(ti + 1, tfB)
         if (ti > 0) CG_FLUSH2(ti - 1, csB)
         CG_TILE2(ti, tfA, twA, csA)
-        if (wv == 0 && h == 0) twB[t] = gw;
+        if (wv == 0 && h == 0) twB[t] = CG_GW;
         __syncthreads();
         if (ti + 1 >= nt) { CG_FLUSH2(ti, csA) break; }
         CG_DMA2(ti + 2, tfA)
         CG_FLUSH2(ti, csA)
         CG_TILE2(ti + 1, tfB, twB, csB)
-        if (wv == 0 && h == 0) twA[t] = gw;
+        if (wv == 0 && h == 0) twA[t] = CG_GW;
         __syncthreads();
         if (ti + 2 >= nt) { CG_FLUSH2(ti + 1, csB) }
     }
 #undef CG_DMA2
 #undef CG_TILE2
 #undef CG_FLUSH2
+#undef CG_GW
 
     const int vsel = (t & 3) + 4 * (t >> 3);
     float tot = 0.0f;

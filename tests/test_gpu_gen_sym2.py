@@ -81,3 +81,33 @@ def test_two_row_tile_generic_partials_add_up(cg, oracle, n, d, world):
             assert relerr(tot, ref) <= 1e-5 and rowwise(tot, ref, absref) <= 1e-5, (name, relerr(tot, ref))
     finally:
         cg.set_option("mfma_sym", -1)
+
+
+@pytest.mark.parametrize("n,d,f16", [(1500, 20, -1), (2049, 24, -1), (777, 17, -1), (1300, 12, 0), (1025, 11, 0), (600, 32, 16)])
+def test_eq_symmetric_six_mfmas_per_tile_staged_kernel(cg, oracle, n, d, f16):
+    """gramian(EQ, x) at six MFMAs per tile (d = 17 .. 24 with the fp16 split, 11 .. 12 with bf16): the staged 8-wave symmetric kernel (round 5; the
+    one-tile-per-stage 4-wave kernel before) — against the oracle, as cyclic partials, and (f16 = 16: option mfma_sym_st = 16) the diagnostic
+    eight-MFMA form."""
+    o = oracle
+    rng = np.random.default_rng(7300 + n + d)
+    Xh = (2.0 / np.sqrt(d) * rng.standard_normal((n, d))).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda(); Xd, ad = Xh.astype(np.float64), ah.astype(np.float64)
+    ko = o.Kernel(o.EQ)
+    ref = o.mul(None, ko, Xd, Xd, ad); absref = np.abs(o.matrix(ko, Xd, Xd)) @ np.abs(ad)
+    try:
+        cg.set_option("mfma_sym", 1)
+        if f16 == 16: cg.set_option("mfma_sym_st", 16)
+        else: cg.set_option("mfma_f16", f16)
+        G = cg.gramian(cg.EQ(), X)
+        y = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda"); G.mul_(y, a)
+        assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_sym") == 1
+        b = y.cpu().numpy()
+        assert relerr(b, ref) <= 1e-5 and rowwise(b, ref, absref) <= 1e-5, (n, d, relerr(b, ref), rowwise(b, ref, absref))
+        y2 = torch.from_numpy(ah[::-1].copy()).cuda(); G.mul_(y2, a, -0.7, 1.3)
+        assert relerr(y2.cpu().numpy(), -0.7 * ref + 1.3 * ad[::-1]) <= 1e-5
+        tot = np.zeros(n); part = torch.empty(n, dtype=torch.float32, device="cuda")
+        for r in range(3):
+            part.fill_(float("nan")); G.sym_partial_(part, a, r, 3); tot += part.cpu().numpy().astype(np.float64)
+        assert relerr(tot, ref) <= 1e-5 and rowwise(tot, ref, absref) <= 1e-5
+    finally:
+        cg.set_option("mfma_sym", -1); cg.set_option("mfma_f16", -1); cg.set_option("mfma_sym_st", 0)

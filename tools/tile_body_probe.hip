@@ -65,7 +65,7 @@ __device__ __forceinline__ void tile(f32x16& D, float h0, float h1, float h2, fl
     }
 }
 
-template <int FORM, int NP, bool SYM, int W>
+template <int FORM, int NP, bool SYM, int W, int NM = 2>
 __global__ __launch_bounds__(256 * W) void probe(float* out, long long* stamps, int iters, float seed, const float* hc) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     bf8 a0, a1, b0, b1;
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256 * W) void probe(float* out, long long* stamps, 
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, D, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NM / 2; ++q) {
+            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, D, 0, 0, 0);
+        }
         tile<FORM, NP, SYM>(D, h0, h1, h2, w, u, acc, c01, c23);
         if constexpr (SYM) { cs += (c01[0] + c01[1]) + (c23[0] + c23[1]); c01 = (f32x2){0.f, 0.f}; c23 = (f32x2){0.f, 0.f}; }
         // the next tile's operands differ (nothing hoists): rotate the B fragments by the running sum's low bits
@@ -95,14 +98,14 @@ __global__ __launch_bounds__(256 * W) void probe(float* out, long long* stamps, 
     if (l == 0) stamps[blockIdx.x * 4 * W + wv] = t1 - t0;
 }
 
-template <int FORM, int NP, bool SYM, int W>
+template <int FORM, int NP, bool SYM, int W, int NM = 2>
 static double run1() {
     const int iters = 4000, blocks = 256;
     float* out; (void)hipMalloc(&out, (size_t)blocks * 256 * W * sizeof(float));
     long long* st; (void)hipMalloc(&st, (size_t)blocks * 4 * W * sizeof(long long));
     float hh[3] = {1.0f, 0.693f, 0.16f};
     float* hc; (void)hipMalloc(&hc, sizeof(hh)); (void)hipMemcpy(hc, hh, sizeof(hh), hipMemcpyHostToDevice);
-    for (int k = 0; k < 2; ++k) probe<FORM, NP, SYM, W><<<blocks, 256 * W>>>(out, st, iters, 1.0f, hc);
+    for (int k = 0; k < 2; ++k) probe<FORM, NP, SYM, W, NM><<<blocks, 256 * W>>>(out, st, iters, 1.0f, hc);
     (void)hipDeviceSynchronize();
     std::vector<long long> h((size_t)blocks * 4 * W);
     (void)hipMemcpy(h.data(), st, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -112,14 +115,18 @@ static double run1() {
     (void)hipFree(out); (void)hipFree(st); (void)hipFree(hc);
     return a[a.size() / 2];
 }
-template <int FORM, int NP, bool SYM>
+template <int FORM, int NP, bool SYM, int NM = 2>
 static void run(const char* name) {
-    printf("%-78s W=1 %6.2f | W=2 %6.2f | W=3 %6.2f | W=4 %6.2f   cycles per 64 entries per SIMD\n", name, run1<FORM, NP, SYM, 1>(), run1<FORM, NP, SYM, 2>(), run1<FORM, NP, SYM, 3>(),
-           run1<FORM, NP, SYM, 4>());
+    printf("%-78s W=1 %6.2f | W=2 %6.2f | W=3 %6.2f | W=4 %6.2f   cycles per 64 entries per SIMD\n", name, run1<FORM, NP, SYM, 1, NM>(), run1<FORM, NP, SYM, 2, NM>(), run1<FORM, NP, SYM, 3, NM>(),
+           run1<FORM, NP, SYM, 4, NM>());
 }
 
 int main() {
     run<3, 8, false>("EQ: 16 exp2 + 8 pk_fma (the general EQ kernel's tile body)");
+    run<3, 8, false, 4>("EQ, FOUR MFMAs per tile (a dependent chain; 128 matrix-pipe cycles = 8 per 64 entries)");
+    run<3, 8, false, 8>("EQ, EIGHT MFMAs per tile (256 matrix-pipe cycles = 16 per 64 entries)");
+    run<3, 8, true, 8>("EQ symmetric, EIGHT MFMAs per tile");
+    run<3, 8, false, 16>("EQ, SIXTEEN MFMAs per tile (512 matrix-pipe cycles = 32 per 64 entries)");
     run<3, 8, true>("EQ symmetric: 16 exp2 + 16 pk_fma");
     run<0, 8, false>("MaternP(2) entry by entry: max, sqrt, exp2, 2 fma, mul, fma (round 4)");
     run<0, 8, true>("MaternP(2) entry by entry, symmetric (+ fma)");
