@@ -897,7 +897,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     int gfmt = 0;
     if (!fast) {
         int k2h = 0;
-        gfmt = mfma_gen_fmt(ctx, hku, lfam, X, X, lfam == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2, &k2h);
+        gfmt = mfma_gen_fmt(ctx, hku, lfam, X, X, lfam == FAM_SUM_ISO ? 2 : 8, &k2h);   // (the Sum: its staged kernel only)
         if (gfmt) K2 = k2h;
         ctx->last_mfma_f16 = gfmt;
     }
@@ -1095,8 +1095,9 @@ static int mfma_gen_fmt(const covgram_ctx* ctx, const HostKernel& hk, int lfam, 
     const int d = X->d;
     *K2 = mfma_k2_for(d + (iso ? 1 : 0));
     if (ctx->mfma_f16 == 0 || !iso || lfam == FAM_EXPR_ISO || lfam == FAM_EXPR_DOT) return 0;
-    const int k2h = (d + 2 + 3) / 4;
-    if (k2h > maxk2 || k2h > 4) return 0;
+    int k2h = (d + 2 + 3) / 4;                                   // d + 2 positions, four per MFMA; compiled: 1, 2, 3, 4, 6, 8 (d <= 30)
+    if (k2h == 5) k2h = 6; else if (k2h == 7) k2h = 8;
+    if (k2h > maxk2 || k2h > 8) return 0;
     const double frac = mfma_gen_gate_frac(hk, X, Y);
     if (!(frac <= 0.01 * (double)ctx->mfma_gate_pct * (ctx->mfma_f16 == 2 ? 1.0 : MFMA_F16_GATE / MFMA_GATE))) return 0;
     *K2 = k2h;
@@ -1234,7 +1235,7 @@ int mvm_mfma_gen(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points
     float gam;
     const int lfam = mfma_family_of(ctx, hk, &gam);
     int K2bf = 0;
-    const int gfmt_all = mfma_gen_fmt(ctx, hk, lfam, X, Y, 4, &K2bf);   // the VALU forms (up to four right-hand sides); the many-column GEMM form keeps bf16
+    const int gfmt_all = mfma_gen_fmt(ctx, hk, lfam, X, Y, 8, &K2bf);   // the VALU forms (up to four right-hand sides); the many-column GEMM form keeps bf16
     const int K2m = mfma_k2_for(d + (iso ? 1 : 0));                      // ... with this many MFMAs per tile
     int K2 = K2m;
     ctx->last_sum_fused = lfam == FAM_SUM_ISO ? 1 : 0;

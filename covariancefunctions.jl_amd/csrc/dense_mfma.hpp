@@ -874,7 +874,7 @@ __global__ __launch_bounds__(64 * NW_) __attribute__((amdgpu_waves_per_eu(NW_ ==
 // ---- symmetric form, long fragments (K2 > 4: d = 9 .. 32): 4 waves x ONE row tile = a 128-row panel; ONE column tile per stage,
 // its K2 fragment slices fetched by the four waves in turn (the split-tile staging of dense_mfma_eq_kernel<.., LDS = 2>), one
 // barrier per tile.  Same chunks / slabs / masks / workgroup list as dense_mfma_sym_kernel, with 4 tiles per panel.
-template <int FAM, int K2>
+template <int FAM, int K2, int GFMT = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dense_mfma_sym_wide_kernel(
     const float* __restrict__ X, int64_t n, int32_t d, const uint4* __restrict__ PB, const float* __restrict__ W, int64_t ntile,
     float* __restrict__ R, float* __restrict__ S, int64_t npad, int32_t tchunk, float g, const float* __restrict__ Cn,
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // (the guarded form measured 4-5 % faster than a clamped unconditional load here: tools/eq_k2_ab.py, gpurun r2c/r2d vs r2e/r2f)
     auto wt = [&](int64_t j) { return EF ? (j < n ? W[j] * EF[j] : 0.0f) : W[j]; };
     constexpr bool FAST = (FAM == FAM_EQFAST || FAM == FAM_EQFAST_H);
-    constexpr int FMT = FAM == FAM_EQFAST_H ? 1 : 0;
+    constexpr int FMT = (FAM == FAM_EQFAST_H || (!FAST && GFMT == 1)) ? 1 : 0;   // fp16 operands: the EQ form's split / the generic form's (gen_row_fragments)
     constexpr bool ISO = FAST || fam_is_iso<FAM>;
     constexpr int NW = 4;
     const int32_t wm = wgmap[blockIdx.x];
@@ -913,24 +913,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if constexpr (FAST) {
             er = eq_row_fragments_fmt<K2, FMT>(xr, Cn, d, g, h, a);
         } else {
-            const float gg = kp.gamma;
-            if constexpr (ISO)
-                for (int cc = 0; cc < d; ++cc) { const float xc = gg * (xr[cc] - Cn[cc]); part = __builtin_fmaf(xc, xc, part); }
-#pragma unroll
-            for (int mm = 0; mm < K2; ++mm) {
-                const int c = 2 * mm + h;
-                uint4 f = make_uint4(0, 0, 0, 0);
-                if (c < d) {
-                    unsigned x1, x2, x3;
-                    split3(ISO ? gg * (xr[c] - Cn[c]) : gg * xr[c], x1, x2, x3);
-                    f = make_uint4(x1 | (x1 << 16), x2 | (x1 << 16), x2 | (x3 << 16), x2 | (x3 << 16));
-                } else if (ISO && c == d) {
-                    unsigned n1, n2, n3;
-                    split3(part, n1, n2, n3);
-                    f = make_uint4(n1 | (n2 << 16), n3 | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0);
-                }
-                a[mm].u = f;
-            }
+            gen_row_fragments<K2, GFMT, ISO>(xr, Cn, d, kp.gamma, h, a);
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
@@ -1091,8 +1074,8 @@ static void mfma_gen_launch_f(const MfmaArgs& a) {
         hipLaunchKernelGGL((dense_mfma_gen_kernel<FAM, K2, RT, NR, 0, ORD, GFMT>), a.grid, dim3(64), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.out,
                            a.npad, a.ldy, a.nrhs, a.tchunk, a.alpha, a.beta, a.final_store, a.Cn, make_params<FAM, float>(*a.hk));
 }
-// the fp16 split's instances exist for the isotropic families up to four MFMAs per tile (d <= 14) — the host asks for nothing else
-template <int FAM, int K2> constexpr bool mfma_gen_has_f16 = fam_is_iso<FAM> && !fam_is_expr<FAM> && K2 <= 4;
+// the fp16 split's instances exist for the isotropic families up to eight MFMAs per tile (d <= 30) — the host asks for nothing else
+template <int FAM, int K2> constexpr bool mfma_gen_has_f16 = fam_is_iso<FAM> && !fam_is_expr<FAM> && K2 <= 8;   // d + 2 positions of four per MFMA: d <= 30
 template <int FAM, int K2, int RT, int NR, int ORD>
 static void mfma_gen_launch(const MfmaArgs& a) {
     if constexpr (mfma_gen_has_f16<FAM, K2>) { if (a.fmt == 1) { mfma_gen_launch_f<FAM, K2, RT, NR, ORD, 1>(a); return; } }
@@ -1178,9 +1161,17 @@ static int mfma_sym_one(const MfmaArgs& a) {
         } else if constexpr (FAM == FAM_SUM_ISO) {         // ... and so is a Sum's number of terms
             if (a.hk->nterms == 2) mfma_sym_narrow<FAM, K2, 2>(a); else mfma_sym_narrow<FAM, K2, 3>(a);
         } else mfma_sym_narrow<FAM, K2, 0>(a);
-    } else
-        hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
+    } else {
+        if constexpr (mfma_gen_has_f16<FAM, K2>) {
+            if (a.fmt == 1) {
+                hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2, 1>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
+                                   a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+                return COVGRAM_OK;
+            }
+        }
+        hipLaunchKernelGGL((dense_mfma_sym_wide_kernel<FAM, K2, 0>), a.grid, dim3(256), 0, a.stream, a.X, a.n, a.d, a.PB, a.W, a.ntile, a.R, a.S,
                            a.npad, (int32_t)a.tchunk, 0.0f, a.Cn, a.pfirst, a.pstride, a.wgmap, make_params<FAM, float>(*a.hk), (const float*)nullptr);
+    }
     return COVGRAM_OK;
 }
 

@@ -54,7 +54,7 @@ def _cloud(rng, n, d, rho):
     return X
 
 
-@pytest.mark.parametrize("d", [1, 3, 5, 6, 8, 10, 12, 14])
+@pytest.mark.parametrize("d", [1, 3, 5, 6, 8, 10, 12, 14, 16, 22, 30])
 def test_fp16_split_at_its_gate_symmetric_and_general(cg, oracle, d):
     o = oracle
     n = 1536
@@ -97,7 +97,7 @@ def test_fp16_split_at_its_gate_symmetric_and_general(cg, oracle, d):
         cg.set_option("mfma_sym", -1); cg.set_option("mfma_f16", -1); cg.set_option("mfma_gate_pct", 100)
 
 
-@pytest.mark.parametrize("d", [2, 4, 7, 9, 13])
+@pytest.mark.parametrize("d", [2, 4, 7, 9, 13, 18, 27])
 def test_fp16_split_radius_scan_maternp_and_sum(cg, oracle, d):
     """MaternP(p) and Sums: whatever split the library's gates pick at each radius (both occur over the scan), the result holds 1e-5 norm-wise and
     the row-wise bound of the module docstring; inside 40 % of the gates (option "mfma_gate_pct") 1e-5 row-wise"""
@@ -141,9 +141,9 @@ def test_fp16_split_radius_scan_maternp_and_sum(cg, oracle, d):
 
 
 def test_fp16_split_refused_where_it_has_no_instance(cg):
-    """d + 2 positions must fit four MFMAs of four (d <= 14); beyond that, and for the dot-product kernels, the bf16 split serves"""
+    """d + 2 positions must fit eight MFMAs of four (d <= 30); beyond that, and for the dot-product kernels, the bf16 split serves"""
     rng = np.random.default_rng(77)
-    for d, want in ((14, 1), (15, 0), (24, 0)):
+    for d, want in ((14, 1), (15, 1), (24, 1), (30, 1), (31, 0)):
         X = torch.from_numpy((0.3 * rng.standard_normal((1024, d))).astype(np.float32)).cuda(); a = torch.ones(1024, dtype=torch.float32, device="cuda")
         y = torch.empty_like(a); cg.gramian(cg.RQ(1.0), X[:512].contiguous(), X).mul_(y[:512], a)
         assert cg.get_info("last_dense_path") == 2 and cg.get_info("last_mfma_f16") == want, d

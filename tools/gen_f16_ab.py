@@ -14,7 +14,7 @@ def timeit(fn, reps=10):
         e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / reps)
     return float(np.median(ts)) * 1e3
 L = cg.Lengthscale
-for n, d in ((131072, 3), (65536, 3), (65536, 5), (65536, 8), (65536, 12)):
+for n, d in ((131072, 3), (65536, 3), (65536, 5), (65536, 8), (65536, 12), (65536, 16), (65536, 24), (65536, 30)):
     rng = np.random.default_rng(40 + d)
     Xh = (rng.standard_normal((n, d)) * (0.9 if n > 65536 else 1.0 if d <= 5 else 0.7)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
     X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda(); y = torch.empty_like(a)
