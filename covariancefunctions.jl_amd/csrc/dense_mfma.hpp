@@ -1138,11 +1138,13 @@ static void mfma_sym_narrow(const MfmaArgs& a) {
 }
 // which symmetric form serves (family, K2): the 8- or 6-wave panels with stages of four tiles (narrow), or four waves and one tile per stage
 // (wide).  The one-pass Sum takes the wide form from K2 = 3 on (its 6-wave instances spill 12-40 B at K2 = 3, 4) and has no instance beyond K2 = 8.
-template <int FAM> constexpr int mfma_sym_narrow_maxk2 = FAM == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
+// (round 5: six MFMAs per tile too for the 8-wave families — Cauchy, IMQ, EQ^p, dot products —, one tile at a time in registers; as the EQ form, dense_mfma.hip)
+template <int FAM> constexpr int mfma_sym_narrow_maxk2 = FAM == FAM_SUM_ISO ? 2 : ((mfma_sym_nw<FAM> == 8 && !fam_is_expr<FAM>) ? 6 : MFMA_NARROW_MAXK2);
 inline int mfma_sym_tiles_per_panel(int launcher_family, int k2, int sym_rt = 1) {
     if (sym_rt == 2 && k2 <= 2 && mfma_sym2_family(launcher_family)) return 8;   // dense_mfma_sym2_kernel: 4 waves x 2 row tiles
     const bool heavy = launcher_family == COVGRAM_MATERNP || launcher_family == COVGRAM_RQ || launcher_family == FAM_SUM_ISO;
-    const int narrow_max = launcher_family == FAM_SUM_ISO ? 2 : MFMA_NARROW_MAXK2;
+    const bool expr = launcher_family == FAM_EXPR_ISO || launcher_family == FAM_EXPR_DOT;
+    const int narrow_max = launcher_family == FAM_SUM_ISO ? 2 : ((heavy || expr) ? MFMA_NARROW_MAXK2 : 6);
     return (k2 > narrow_max || heavy) ? 4 : 8;
 }
 template <int FAM, int K2>
