@@ -4,9 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
 import covgram as cg
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-for (kern, d) in ((cg.EQ(), 3), (cg.EQ(), 8), (cg.MaternP(2), 3), (cg.RQ(1.5), 3)):
+for (kern, d) in ((cg.EQ(), 3), (cg.EQ(), 8), (cg.MaternP(2), 3), (cg.RQ(1.5), 3), (cg.Cauchy(), 3), (cg.MaternP(2), 8)):
     line = []
-    for n in (8192, 12000, 16384, 20000, 24000, 28000, 32768, 40000):
+    for n in (6144, 8192, 10000, 12000, 14000, 16384, 20000, 24000):
         rng = np.random.default_rng(n)
         X = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
         y = torch.empty_like(a); G = cg.gramian(kern, X)
