@@ -865,7 +865,9 @@ bool mfma_gen_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const c
     const int64_t ntile = (X->n + 31) / 32, panels = (ntile + tpp - 1) / tpp;
     if ((size_t)panels * (size_t)(panels * 32 * tpp) * sizeof(float) > ((size_t)16 << 30)) return false;
     const bool heavy = hk.tu_family == COVGRAM_MATERNP || hk.tu_family == COVGRAM_RQ || hk.tu_family >= COVGRAM_NFAMILY;   // profile costs several exponentials
-    return ctx->mfma_sym == 1 || X->n >= (heavy ? MFMA_SYM_MIN_N_HEAVY : MFMA_SYM_MIN_N_EQ_WIDE);
+    // (heavy profiles at d > 4: the all-entries kernel's cost grows with the fragment length, the symmetric kernel's floor does not — tools/sym_threshold_sweep.py,
+    //  MaternP(2) d = 8: n = 10000 60.0 / 59.8 us, 12000 77.4 / 66.7)
+    return ctx->mfma_sym == 1 || X->n >= (heavy ? (X->d > 4 ? 10000 : MFMA_SYM_MIN_N_HEAVY) : MFMA_SYM_MIN_N_EQ_WIDE);
 }
 
 // y <- alpha * scale * G_part a + beta * y for the symmetric Gramian of ONE point set and one right-hand side, where G_part
@@ -1119,7 +1121,7 @@ bool sum_fused_applies(const covgram_ctx* ctx, const covgram_kernel* k, const co
     if (!sum_fusable(hk) || !mfma_gen_eligible(ctx, hk, X, Y, nrhs)) return false;
     // gramian(k, x) at d >= 16: the one-pass symmetric kernel has no instance (K2 > 8), and one symmetric MVM per term evaluates half the pairs
     // of the one-pass general kernel
-    const bool same = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= MFMA_SYM_MIN_N_HEAVY);
+    const bool same = nrhs == 1 && ctx->mfma_sym != 0 && X->dptr == Y->dptr && X->n == Y->n && (ctx->mfma_sym == 1 || X->n >= (X->d > 4 ? 10000 : MFMA_SYM_MIN_N_HEAVY));
     if (same && mfma_k2_for(X->d + 1) > 8) return false;
     // Measured (d = 3, n = 131072; profiles/r05_sum_fused_ab.txt, r05_sum_general_ab.txt): what one pass shares is the matrix-core work, the weighted
     // sums and the slabs — every term's transcendentals remain, and they are what the kernels are bound by.  Three terms: 4.07 against 4.83 ms for one
