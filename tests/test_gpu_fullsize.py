@@ -153,3 +153,35 @@ def test_fp64_symmetric_direct_kernel_at_readme_and_large_sizes(cg, oracle):
         finally:
             cg.set_option("dense_sym", -1)
         assert relerr(got, ball) <= 1e-13
+
+
+def test_matern_class_gramians_at_contract_size_f32(cg, oracle):
+    """gramian(k, x), d = 3, n = 131072, fp32 (the contract cloud) for the Matérn-class profiles the round-5 kernels serve — MaternP(2), MaternP(1), RQ,
+    Cauchy on the two-row-tile symmetric matrix-core kernel (csrc/dense_mfma_sym2.hpp), the composite of bench.py's F2 line one MVM per term, a Sum of
+    three in one pass — against 256 fp64 rows of the C oracle, norm-wise and row-wise at 1e-5; the instance that ran is pinned."""
+    import c_oracle
+    o = oracle
+    n, d = 131072, 3
+    rng = np.random.default_rng(SEED0 + 1)
+    Xh = rng.standard_normal((n, d)).astype(np.float32); ah = rng.standard_normal(n).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda(); a = torch.from_numpy(ah).cuda(); y = torch.empty_like(a)
+    rows = np.sort(np.random.default_rng(11).choice(n, 256, replace=False))
+    Xr = Xh[rows].astype(np.float64); Xd = Xh.astype(np.float64); ad = ah.astype(np.float64)
+    L = cg.Lengthscale
+    cases = [("MaternP(2)", cg.MaternP(2), [(1.0, o.Kernel(o.MATERNP, p=2))], 2), ("MaternP(1)", cg.MaternP(1), [(1.0, o.Kernel(o.MATERNP, p=1))], 2),
+             ("RQ(1.5)", cg.RQ(1.5), [(1.0, o.Kernel(o.RQ, param=1.5))], 2), ("Cauchy", cg.Cauchy(), [(1.0, o.Kernel(o.CAUCHY))], 2),
+             ("F2", 1.5 * L(cg.MaternP(2), 0.7) + 0.5 * L(cg.EQ(), 2.0), [(1.5, o.Kernel(o.MATERNP, p=2, lengthscale=0.7)), (0.5, o.Kernel(o.EQ, lengthscale=2.0))], None),
+             ("three", L(cg.EQ(), 1.4) + 0.7 * L(cg.RQ(0.8), 0.9) + 0.2 * cg.MaternP(1),
+              [(1.0, o.Kernel(o.EQ, lengthscale=1.4)), (0.7, o.Kernel(o.RQ, param=0.8, lengthscale=0.9)), (0.2, o.Kernel(o.MATERNP, p=1))], 1)]
+    for name, k, terms, rt in cases:
+        G = cg.gramian(k, X)
+        G.mul_(y, a)
+        assert cg.get_info("last_mfma_sym") == 1, name
+        if rt is not None: assert cg.get_info("last_mfma_sym_rt") == rt, (name, cg.get_info("last_mfma_sym_rt"))
+        if name == "three": assert cg.get_info("last_sum_fused") == 1
+        if name == "F2": assert cg.get_info("last_sum_fused") == 0
+        ref = sum(c * c_oracle.mvm(kk, Xr, Xd, ad) for c, kk in terms)
+        absref = sum(abs(c) * c_oracle.mvm(kk, Xr, Xd, np.abs(ad)) for c, kk in terms)
+        got = y.cpu().numpy()[rows].astype(np.float64)
+        assert relerr(got, ref) <= 1e-5, (name, relerr(got, ref))
+        assert float(np.max(np.abs(got - ref) / absref)) <= 1e-5, (name, float(np.max(np.abs(got - ref) / absref)))
