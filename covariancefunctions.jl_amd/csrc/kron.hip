@@ -128,6 +128,10 @@ static int kron_run(covgram_ctx* ctx, const void* const* factors, const int64_t*
     bool pair = q >= 2 && !big(q - 1) && !big(q - 2) && pair_ok(cols[q - 2], cols[q - 1], lds[q - 2], lds[q - 1]);
     // the pair first when it shrinks the tensor, last otherwise (fewer bytes through the other modes)
     const bool pair_first = pair && q > 2 && rows[q - 2] * rows[q - 1] < cols[q - 2] * cols[q - 1];
+    if (ctx->kron_fill == 3) pair = false;               // (measurements: every mode on its own kernel)
+    // fp32 slabs up to 64 x 64: the fused pass is a latency chain of eight barrier-separated steps per 16 KB slab (64^4: 225 us for what the two
+    // single-mode kernels do in 2 x 51; tools/kron_fill_ab.py nopair: 64^4 304 -> 170 us, 48^4 152 -> 80) — in fp64 the fused pass still wins (271 / 311)
+    if (sizeof(T) == 4 && q >= 2 && std::max(std::max(rows[q - 2], cols[q - 2]), std::max(rows[q - 1], cols[q - 1])) <= 64) pair = false;
     if (pair) {
         const int64_t units = (pair_first ? pre2_first : pre2) * ((rows[q - 2] + 63) / 64);   // workgroups of the fused pass
         if (units < ctx->num_cus / 2) pair = false;   // a handful of slabs: the two modes one after the other spread wider
