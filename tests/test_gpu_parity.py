@@ -945,10 +945,10 @@ def test_eq_symmetric_kernel_at_size(cg, oracle):
     rows = np.r_[0:50, n // 2:n // 2 + 50, n - 50:n]
     assert relerr(b[rows], oracle.mul(None, oracle.Kernel(oracle.EQ), X[rows], X, a, dtype=np.float32)) <= 1e-5
     assert np.isfinite(b).all()
-    # the thresholds by profile cost (csrc/common.hpp MFMA_SYM_MIN_N_*): EQ d <= 4 from 18000, wider EQ from 15000, MaternP / RQ from 12500
+    # the thresholds by profile cost (csrc/common.hpp MFMA_SYM_MIN_N_*): EQ d <= 4 from 18000, wider EQ from 15000, MaternP / RQ from 12500 (d <= 4) / 10000 (wider points, round 5)
     for kern, ko, nn, dd, want in ((cg.EQ(), oracle.Kernel(oracle.EQ), 17000, 3, 0), (cg.EQ(), oracle.Kernel(oracle.EQ), 19000, 3, 1),
-                                   (cg.EQ(), oracle.Kernel(oracle.EQ), 16000, 8, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 12000, 12, 0),
-                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 12, 1),
+                                   (cg.EQ(), oracle.Kernel(oracle.EQ), 16000, 8, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 9000, 12, 0),
+                                   (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 11000, 12, 1),
                                    # (MaternP at d <= 4: gramian(k, x) from the threshold on the symmetric matrix-core kernel — its order is decided once per tile since late
                                    # round 4 —, below it and for two point sets packed on the lane-per-row kernels)
                                    (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 13000, 3, 1), (cg.MaternP(2), oracle.Kernel(oracle.MATERNP, p=2), 12000, 3, 0),
