@@ -1,4 +1,4 @@
-"""One named case, a few calls (for rocprofv3 --kernel-trace --stats): python tools/trace_case.py <c1|c5|c5f32|kron128|dotfac|c4|readme16k> [reps]"""
+"""One named case, a few calls (for rocprofv3 --kernel-trace --stats): python tools/trace_case.py <c1|c5|c5f32|kron128|dotfac|c4|readme16k|toep64k|cg131k|matrix16k|valgrad|c4f32|circ1m> [reps]"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "covariancefunctions.jl_amd"))
@@ -19,6 +19,24 @@ elif case == "dotfac":
     X = torch.from_numpy(rng.standard_normal((1 << 20, 8)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(1 << 20).astype(np.float32)).cuda(); G = cg.gramian(cg.Dot(), X)
 elif case == "c4":
     X = torch.from_numpy(rng.standard_normal((16384, 32))).cuda(); a = torch.from_numpy(rng.standard_normal(16384 * 32)).cuda(); G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
+elif case == "toep64k":
+    G = cg.gramian(cg.EQ(), cg.srange(-1, 1, 65536)); a = torch.randn(65536, dtype=torch.float64, device="cuda")
+elif case == "circ1m":
+    G = cg.gramian(cg.Cosine(2.0) if hasattr(cg, "Cosine") else cg.EQ(), cg.srange(0, 1, 1 << 20)); a = torch.randn(1 << 20, dtype=torch.float64, device="cuda")
+elif case == "valgrad":
+    X = torch.from_numpy(rng.standard_normal((16384, 32))).cuda(); a = torch.from_numpy(rng.standard_normal(16384 * 33)).cuda(); G = cg.gramian(cg.ValueGradientKernel(cg.EQ()), X)
+elif case == "c4f32":
+    X = torch.from_numpy(rng.standard_normal((16384, 32)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(16384 * 32).astype(np.float32)).cuda(); G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
+elif case == "matrix16k":
+    X = torch.from_numpy(rng.standard_normal((16384, 3)).astype(np.float32)).cuda(); G = cg.gramian(cg.EQ(), X)
+    for _ in range(reps): M = G.to_dense()
+    torch.cuda.synchronize(); sys.exit(0)
+elif case == "cg131k":
+    X = torch.from_numpy(rng.standard_normal((131072, 3)).astype(np.float32)).cuda(); b = torch.from_numpy(rng.standard_normal(131072).astype(np.float32)).cuda()
+    from covgram import solve
+    A = cg.gramian(cg.EQ(), X) + torch.full((131072,), 0.1, dtype=torch.float32, device="cuda")     # G + sigma^2 I (src/gramian.jl:55-60)
+    x, info = solve.cg(A, b, reltol=1e-30, maxiter=reps)
+    torch.cuda.synchronize(); print(info); sys.exit(0)
 y = torch.empty_like(a)
 for _ in range(reps): G.mul_(y, a)
 torch.cuda.synchronize()
