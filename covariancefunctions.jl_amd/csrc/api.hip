@@ -360,48 +360,67 @@ __global__ __launch_bounds__(256) void matrix_kernel(const T* __restrict__ X, in
 // x_i from memory for every entry — at d = 32 that is 32 vector loads per entry (62 GB/s written for a 16384^2 fp32 tile, against
 // 1.8 TB/s at d = 3).  Same arithmetic in the same order (entries are bit-identical); y_j is wave-uniform (scalar loads).
 // EXPR: composite kernels (ExprParams), else one profile through phi_any.
-template <typename T, int DM, bool EXPR, typename PT>
+template <typename T, int DM, bool EXPR, typename PT, int VR = 1>
 __global__ __launch_bounds__(256) void matrix_reg_kernel(const T* __restrict__ X, int64_t n, const T* __restrict__ Y, int64_t m,
                                                          int32_t d, T* __restrict__ out, int64_t ldo, int family_or_iso, T scale, const PT kp) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // VR consecutive rows per thread (round 5): one 16-byte streaming store per column instead of VR narrow ones — Matrix(G) is a gigabyte written once
+    // (fp32, n = 16384: 3.7 -> TB/s figures in profiles/r05_matrix_bench.txt); VR > 1 needs n, ldo multiples of VR and a 16-byte aligned out
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VR;
     const int64_t jb = (int64_t)blockIdx.y * 64;
     if (i >= n) return;
     const bool iso = EXPR ? (family_or_iso != 0)
                           : (family_or_iso != COVGRAM_DOT && family_or_iso != COVGRAM_EXPDOT && family_or_iso != COVGRAM_ASINDOT);
-    T x[DM];
+    T x[VR][DM];
 #pragma unroll
-    for (int l = 0; l < DM; ++l) x[l] = (l < d) ? X[i * (int64_t)d + l] : (T)0;
+    for (int r = 0; r < VR; ++r)
+#pragma unroll
+        for (int l = 0; l < DM; ++l) x[r][l] = (l < d) ? X[(i + r) * (int64_t)d + l] : (T)0;
     const int64_t jend = (jb + 64 < m) ? jb + 64 : m;
     T gam = (T)1;
     if constexpr (!EXPR) gam = kp.gamma;
     // the padded dimensions l >= d contribute exact zeros (x = y = 0: r = 0, fma(0, 0, s) = s): no branch inside the entry loop;
     // their y is a scalar select after an in-bounds (clamped) load
-    auto entry = [&](const T* __restrict__ yj, auto full) {
-        T s = (T)0;
+    auto entry = [&](const T* __restrict__ yj, auto full, T (&s)[VR]) {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) s[r] = (T)0;
 #pragma unroll
         for (int l = 0; l < DM; ++l) {
             T yl;
             if constexpr (decltype(full)::value) yl = yj[l];
             else { const int lc = l < d ? l : d - 1; const T yv = yj[lc]; yl = l < d ? yv : (T)0; }
-            if (iso) { T r = x[l] - yl; if constexpr (!EXPR) r *= gam; s = cg_fma(r, r, s); }
-            else s = cg_fma(x[l], yl, s);
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+                if (iso) { T q = x[r][l] - yl; if constexpr (!EXPR) q *= gam; s[r] = cg_fma(q, q, s[r]); }
+                else s[r] = cg_fma(x[r][l], yl, s[r]);
+            }
         }
-        return s;
     };
+    typedef T VT __attribute__((ext_vector_type(VR)));
     // the family switch sits OUTSIDE the column loop: each case is a short loop with one profile inlined (the switch inside — phi_any per
     // entry — put every profile, the Bessel series included, into one loop body: 180 SGPR spills, y fetched a dword at a time)
     auto strip = [&](auto famc, auto full) {
         constexpr int F = decltype(famc)::value;
         for (int64_t j = jb; j < jend; ++j) {
-            const T s = entry(Y + j * (int64_t)d, full);
-            if constexpr (EXPR) out[i + j * ldo] = scale * (iso ? expr_value<T, true>(s, kp) : expr_value<T, false>(s, kp));
+            T s[VR], v[VR];
+            entry(Y + j * (int64_t)d, full, s);
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+                if constexpr (EXPR) v[r] = scale * (iso ? expr_value<T, true>(s[r], kp) : expr_value<T, false>(s[r], kp));
+                else {
+                    T w;
+                    if constexpr (F == COVGRAM_DOT) w = s[r];
+                    else if constexpr (F == COVGRAM_CONSTANT) w = (T)1;
+                    else w = Phi<F, T, false>::eval(s[r], kp);
+                    if (kp.power != 1) w = ipow(w, kp.power);
+                    v[r] = scale * w;
+                }
+            }
+            if constexpr (VR == 1) __builtin_nontemporal_store(v[0], out + i + j * ldo);
             else {
-                T v;
-                if constexpr (F == COVGRAM_DOT) v = s;
-                else if constexpr (F == COVGRAM_CONSTANT) v = (T)1;
-                else v = Phi<F, T, false>::eval(s, kp);
-                if (kp.power != 1) v = ipow(v, kp.power);
-                out[i + j * ldo] = scale * v;
+                VT vv;
+#pragma unroll
+                for (int r = 0; r < VR; ++r) vv[r] = v[r];
+                __builtin_nontemporal_store(vv, reinterpret_cast<VT*>(out + i + j * ldo));
             }
         }
     };
@@ -412,7 +431,6 @@ __global__ __launch_bounds__(256) void matrix_reg_kernel(const T* __restrict__ X
         CG_FAMCASE(COVGRAM_EQ) CG_FAMCASE(COVGRAM_EXP) CG_FAMCASE(COVGRAM_RQ) CG_FAMCASE(COVGRAM_GAMMAEXP) CG_FAMCASE(COVGRAM_CAUCHY)
         CG_FAMCASE(COVGRAM_IMQ) CG_FAMCASE(COVGRAM_MATERNP) CG_FAMCASE(COVGRAM_DOT) CG_FAMCASE(COVGRAM_EXPDOT) CG_FAMCASE(COVGRAM_MATERN)
         CG_FAMCASE(COVGRAM_ASINDOT)
-        default: run(std::integral_constant<int, COVGRAM_CONSTANT>()); break;
 #undef CG_FAMCASE
     }
 }
@@ -1141,10 +1159,17 @@ int covgram_matrix(covgram_ctx* ctx, const covgram_kernel* k, const covgram_poin
         const int dd = X->d;
         const bool expr = hk.tu_family >= COVGRAM_NFAMILY;
         const int fam_or_iso = expr ? (hk.tu_family == FAM_EXPR_ISO ? 1 : 0) : k->family;
+        // rows per thread: 16-byte streaming stores (4 fp32 / 2 fp64 rows) when the points are short (registers), n and the leading dimension are
+        // multiples of it and the output is 16-byte aligned; a single profile only (the composite interpreter keeps one row per thread)
 #define CG_MAT(TT, DMV)                                                                                                                   \
         do {                                                                                                                              \
+            constexpr int VRV = 16 / (int)sizeof(TT);                                                                                     \
+            const bool vr = !expr && DMV <= 16 && n % VRV == 0 && ld % VRV == 0 && ((uintptr_t)o % 16) == 0;                                \
+            const dim3 g3((unsigned)((n / VRV + 255) / 256), (unsigned)((m + 63) / 64));                                                  \
             if (expr) hipLaunchKernelGGL((matrix_reg_kernel<TT, DMV, true, ExprParams<TT>>), g2, dim3(256), 0, ctx->stream, (const TT*)X->dptr, n, \
                                          (const TT*)Y->dptr, m, dd, (TT*)o, ld, fam_or_iso, (TT)hk.kp.scale, make_params<FAM_EXPR_ISO, TT>(hk)); \
+            else if (vr) hipLaunchKernelGGL((matrix_reg_kernel<TT, (DMV <= 16 ? DMV : 16), false, KParams<TT>, VRV>), g3, dim3(256), 0, ctx->stream, (const TT*)X->dptr, n,  \
+                                    (const TT*)Y->dptr, m, dd, (TT*)o, ld, fam_or_iso, (TT)hk.kp.scale, cast_params<TT>(hk.kp));              \
             else hipLaunchKernelGGL((matrix_reg_kernel<TT, DMV, false, KParams<TT>>), g2, dim3(256), 0, ctx->stream, (const TT*)X->dptr, n,  \
                                     (const TT*)Y->dptr, m, dd, (TT*)o, ld, fam_or_iso, (TT)hk.kp.scale, cast_params<TT>(hk.kp));              \
         } while (0)
