@@ -811,32 +811,40 @@ int mvm_eq_mfma(covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X,
 __global__ __launch_bounds__(1024) void dense_mfma_sym_reduce_kernel(int64_t n, const float* __restrict__ R, const float* __restrict__ S, int64_t npad,
                                                                     int64_t ntile, int32_t tchunk, const float* __restrict__ EF, float* __restrict__ y,
                                                                     float alpha, float beta, int32_t pfirst, int32_t pstride, int32_t tpp) {
-    // 64 rows per workgroup, the panel index strided over 16 waves (hundreds of panels per row: many independent loads in flight)
+    // 256 rows per workgroup — FOUR consecutive rows per lane (16-byte loads: the slab is hundreds of MB read once; round 5, 4-byte loads before:
+    // 3.1 TB/s) —, the panel index strided over 16 waves (hundreds of panels per row: many independent loads in flight).  Per row the sums are formed
+    // in the same order as before (panels part, part + 16, ...; then the 16 parts; then the chunks): bit-identical results.
+    // (npad is a multiple of 4 and the slabs are 256-byte aligned; rows >= n of a lane's four are read — the slabs are padded — and not stored)
+    typedef float f4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    __shared__ float red[16][64];
-    float s = 0.0f;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    __shared__ f4 red[16][64];
+    f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
-        const int64_t pi = i / (32 * tpp);                                           // the row's panel (tpp row tiles: 256 or 128 rows)
+        const int64_t pi = i / (32 * tpp);                                           // the rows' panel (tpp row tiles: 256 or 128 rows — four rows share it)
         // local panels lp (global pfirst + pstride lp) up to the row's own panel
         const int64_t nlp = pi >= pfirst ? (pi - pfirst) / pstride + 1 : 0;
 #pragma unroll 4
-        for (int64_t lp = part; lp < nlp; lp += 16) s += S[lp * npad + i];
+        for (int64_t lp = part; lp < nlp; lp += 16) s += *reinterpret_cast<const f4*>(S + lp * npad + i);
     }
     red[part][lane] = s;
     __syncthreads();
     if (part != 0 || i >= n) return;
-    float cs = 0.0f;
+    f4 cs = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int q = 0; q < 16; ++q) cs += red[q][lane];                                  // fixed order
     const int64_t pi = i / (32 * tpp);
     const int64_t cfirst = (tpp * pi) / tchunk, cend = (ntile + tchunk - 1) / tchunk;   // the absolute chunks the row's panel visited
-    float rs = 0.0f;
+    f4 rs = {0.0f, 0.0f, 0.0f, 0.0f};
     if (pi >= pfirst && (pi - pfirst) % pstride == 0)                                 // the row sums exist only where this rank owns the panel
-        for (int64_t c = cfirst; c < cend; ++c) rs += R[c * npad + i];
-    float v = alpha * (EF ? __builtin_fmaf(EF[i], cs, rs) : cs + rs);
-    if (beta != 0.0f) v = __builtin_fmaf(beta, y[i], v);
-    y[i] = v;
+        for (int64_t c = cfirst; c < cend; ++c) rs += *reinterpret_cast<const f4*>(R + c * npad + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i + e >= n) break;
+        float v = alpha * (EF ? __builtin_fmaf(EF[i + e], cs[e], rs[e]) : cs[e] + rs[e]);
+        if (beta != 0.0f) v = __builtin_fmaf(beta, y[i + e], v);
+        y[i + e] = v;
+    }
 }
 
 bool mfma_eq_sym_eligible(const covgram_ctx* ctx, const HostKernel& hk, const covgram_points* X, const covgram_points* Y, int nrhs) {
@@ -1057,7 +1065,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
 #undef CG_SYMH_CASE
 #undef CG_SYMWH_CASE
     if (tm) (void)hipEventRecord(tm->second, ctx->stream);
-    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ctx->stream, n, (const float*)Rp,
+    hipLaunchKernelGGL(dense_mfma_sym_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(1024), 0, ctx->stream, n, (const float*)Rp,
                        (const float*)Sp, npad, ntile, (int)tchunk, EF, y, (float)alpha_eff, (float)beta, pfirst, pstride, tpp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense_mfma_sym launch failed: %s", hipGetErrorString(e)); return COVGRAM_EHIP; }
