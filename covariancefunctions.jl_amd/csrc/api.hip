@@ -1380,12 +1380,15 @@ static int grad_mvm_impl(covgram_ctx* ctx, const covgram_kernel* k, const covgra
         else
             hipLaunchKernelGGL(grad_pack_kernel<double>, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double*)Y->dptr, m, d, (const double*)a_dev, (double*)P, D, hk.kp.gamma, vg, (double*)A0, (const double*)Cn, nr, lda_d);
-        if (expd && dtype == COVGRAM_F64)
-            hipLaunchKernelGGL(grad_pack_extra_kernel<double>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, d,
-                               (const double*)a_dev, hk.kp.gamma, vg, (const double*)Cn, (double*)Ex, nr, lda_d);
-        else if (expd)
-            hipLaunchKernelGGL(grad_pack_extra_kernel<float>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const float*)Y->dptr, m, d,
-                               (const float*)a_dev, (float)hk.kp.gamma, vg, (const float*)Cn, (float*)Ex, nr, lda_d);
+#define CG_PEL(TT, DLV) hipLaunchKernelGGL((grad_pack_extra_lanes_kernel<TT, DLV>), dim3((unsigned)(((m + 1) * DLV + 255) / 256)), dim3(256), 0, ctx->stream, (const TT*)Y->dptr, m, \
+                                           (const TT*)a_dev, (TT)hk.kp.gamma, vg, (const TT*)Cn, (TT*)Ex, nr, lda_d)
+#define CG_PE(TT) do { if (d == 8) CG_PEL(TT, 8); else if (d == 16) CG_PEL(TT, 16); else if (d == 32) CG_PEL(TT, 32); else if (d == 64) CG_PEL(TT, 64); \
+                       else hipLaunchKernelGGL(grad_pack_extra_kernel<TT>, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, ctx->stream, (const TT*)Y->dptr, m, d, \
+                                               (const TT*)a_dev, (TT)hk.kp.gamma, vg, (const TT*)Cn, (TT*)Ex, nr, lda_d); } while (0)
+        if (expd && dtype == COVGRAM_F64) CG_PE(double);
+        else if (expd) CG_PE(float);
+#undef CG_PE
+#undef CG_PEL
         int64_t jchunk; int jsplit;
         // partial slabs cost jsplit * n * d * sizeof(T) bytes, but several rounds of workgroups balance the tail
         // (C4: 2.47 ms at CUs*8, 2.08 at CUs*32, 2.01 at CUs*64, 2.05 at CUs*96, 2.15 at CUs*128 — interleaved A/B, tools/c4_ab.py)
