@@ -974,8 +974,13 @@ int covgram_mvm(covgram_ctx* ctx, const covgram_kernel* k, const covgram_points*
         void* Pb;
         rc = ws_reserve(ctx, 0, (size_t)mpad * (D + 2) * ts, &Pb); if (rc) return rc;
         double* Exb = (double*)Pb + (size_t)mpad * D;
+#define CG_BPL(DLV) hipLaunchKernelGGL((dense_bcast_pack_lanes_kernel<DLV>), dim3((unsigned)((mpad * DLV + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, Y->d, \
+                                       (const double*)a_dev, (double*)Pb, Exb, hk.kp.gamma, (const double*)Cn, mpad)
+        if (D == 16) CG_BPL(16); else if (D == 32) CG_BPL(32); else if (D == 64) CG_BPL(64);
+        else
         hipLaunchKernelGGL(dense_bcast_pack_kernel<double>, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)Y->dptr, m, Y->d,
                            (const double*)a_dev, (double*)Pb, Exb, D, hk.kp.gamma, (const double*)Cn, mpad);
+#undef CG_BPL
         DenseArgs da;
         da.C = Cn; da.X = X->dptr; da.n = n; da.d = X->d; da.P = Pb; da.Ex = Exb; da.m = m; da.ldy = ldy_d; da.nrhs = 1;
         da.Dpad = D; da.NRpad = 1; da.rows_per_lane = 1; da.variant = 0; da.bcast = 1;

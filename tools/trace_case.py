@@ -19,6 +19,10 @@ elif case == "dotfac":
     X = torch.from_numpy(rng.standard_normal((1 << 20, 8)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(1 << 20).astype(np.float32)).cuda(); G = cg.gramian(cg.Dot(), X)
 elif case == "c4":
     X = torch.from_numpy(rng.standard_normal((16384, 32))).cuda(); a = torch.from_numpy(rng.standard_normal(16384 * 32)).cuda(); G = cg.gramian(cg.GradientKernel(cg.EQ()), X)
+elif case == "wide64":
+    X = torch.from_numpy(rng.standard_normal((16384, 32)) / 4).cuda(); a = torch.from_numpy(rng.standard_normal(16384)).cuda(); G = cg.gramian(cg.EQ(), X)
+elif case == "mp32k":
+    X = torch.from_numpy(rng.standard_normal((32768, 3))).cuda(); a = torch.from_numpy(rng.standard_normal(32768)).cuda(); G = cg.gramian(cg.MaternP(2), X)
 elif case == "toep64k":
     G = cg.gramian(cg.EQ(), cg.srange(-1, 1, 65536)); a = torch.randn(65536, dtype=torch.float64, device="cuda")
 elif case == "circ1m":
