@@ -468,29 +468,36 @@ template <typename T /* double */>
 __global__ __launch_bounds__(1024) void dense_sym_reduce_kernel(const double* __restrict__ out, const double* __restrict__ colslab,
                                                                 int64_t npad, int32_t jsplit, double* __restrict__ y, int64_t n,
                                                                 double alpha, double beta, int32_t rb_first, int32_t rb_stride) {
-    // 64 rows per workgroup, the terms strided over 16 waves (the last row blocks add n / 64 column-sum rows each: with 4 waves the
-    // kernel ran at 1.6 TB/s of slab reads, 42 us at n = 32768)
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    __shared__ double red[16][64];
-    double s = 0.0;
+    // 64 rows per workgroup = one row block; TWO consecutive rows per lane (16-byte loads — round 5; 8-byte loads read the slabs at 1.5 TB/s: 11.7 us of the
+    // README case's 224), the terms strided over 32 half-waves (the last row blocks add n / 64 column-sum rows each: many independent loads in flight).
+    // Per row: terms part, part + 32, ... in order, then the 32 parts in a fixed tree — deterministic.  (npad is a multiple of 64; slabs are 256-byte aligned.)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 64 + 2 * lane;
+    __shared__ d2 red[32][32];
+    d2 s = {0.0, 0.0};
     if (i < n) {
         const int64_t B = blockIdx.x;
         if (B >= rb_first && (B - rb_first) % rb_stride == 0)          // this launch evaluated the block's own rows
-            for (int sp = part; sp < jsplit; sp += 16) s += out[(int64_t)sp * npad + i];
+            for (int sp = part; sp < jsplit; sp += 32) s += *reinterpret_cast<const d2*>(out + (int64_t)sp * npad + i);
         // evaluated row blocks above this one hold column sums for these rows: first + x stride < B
         const int64_t nb = B > rb_first ? (B - rb_first + rb_stride - 1) / rb_stride : 0;
-        for (int64_t rb = part; rb < nb; rb += 16) s += colslab[rb * npad + i];
+#pragma unroll 4
+        for (int64_t rb = part; rb < nb; rb += 32) s += *reinterpret_cast<const d2*>(colslab + rb * npad + i);
     }
     red[part][lane] = s;
     __syncthreads();
     if (part != 0 || i >= n) return;
-    double t = 0.0;
+    d2 t = {0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 16; q += 4) t += (red[q][lane] + red[q + 1][lane]) + (red[q + 2][lane] + red[q + 3][lane]);
-    double v = alpha * t;
-    if (beta != 0.0) v = cg_fma(beta, y[i], v);
-    y[i] = v;
+    for (int q = 0; q < 32; q += 4) t += (red[q][lane] + red[q + 1][lane]) + (red[q + 2][lane] + red[q + 3][lane]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (i + e >= n) break;
+        double v = alpha * t[e];
+        if (beta != 0.0) v = cg_fma(beta, y[i + e], v);
+        y[i + e] = v;
+    }
 }
 
 template <int FAM, int D>
