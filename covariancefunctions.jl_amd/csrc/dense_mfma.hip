@@ -955,7 +955,7 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // weights, first stage) —, >= 128 for a rank's share (tools/sym_tchunk_sweep.py, tools/sym_shard_probe.py: rank r of 8 at
     // C2 size 170-185 us with 128-tile chunks, 183-201 with 64)
     const bool rt2_plan = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;     // 4-wave workgroups: three per CU
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * ((tpp == 4 || rt2_plan) ? 3 : 2) * (pstride > 1 ? 4 : 8);
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * ((tpp == 4 || rt2_plan || gen_rt == 2) ? 3 : 2) * (pstride > 1 ? 4 : 8);   // (4-wave workgroups: three per CU)
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     tchunk = std::max<int64_t>(pstride > 1 ? 128 : 64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
