@@ -955,7 +955,10 @@ int mvm_eq_mfma_sym(covgram_ctx* ctx, const HostKernel& hk, const covgram_points
     // weights, first stage) —, >= 128 for a rank's share (tools/sym_tchunk_sweep.py, tools/sym_shard_probe.py: rank r of 8 at
     // C2 size 170-185 us with 128-tile chunks, 183-201 with 64)
     const bool rt2_plan = fast && K2 <= (ctx->mfma_sym_rt == 2 ? MFMA_NARROW_MAXK2 : 2) && ctx->mfma_sym_rt != 1;     // 4-wave workgroups: three per CU
-    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * ((tpp == 4 || rt2_plan || gen_rt == 2) ? 3 : 2) * (pstride > 1 ? 4 : 8);   // (4-wave workgroups: three per CU)
+    // (4-wave workgroups: three per CU.  The two-row-tile kernels — heavier prologue: two sets of row fragments and weights per wave — take ~5 rounds:
+    //  tools/sym_rounds_ab.py, interleaved, n = 131072: EQ d = 3 980 / 962 / 958 us at 8 / 5 / 4 rounds, d = 8 1154 / 1131 / 1117; n = 262144 level)
+    const bool two_row = rt2_plan || gen_rt == 2;
+    int64_t target = ctx->target_wgs > 0 ? ctx->target_wgs : (int64_t)ctx->num_cus * ((tpp == 4 || two_row) ? 3 : 2) * (pstride > 1 ? 4 : (two_row ? 5 : 8));
     int64_t tchunk = ctx->jsplit > 0 ? (ntile + ctx->jsplit - 1) / ctx->jsplit : (tileops + target - 1) / target;
     tchunk = std::max<int64_t>(pstride > 1 ? 128 : 64, std::min<int64_t>(((tchunk + 3) / 4) * 4, 1024));
     const int64_t maxc = (ntile + tchunk - 1) / tchunk;
