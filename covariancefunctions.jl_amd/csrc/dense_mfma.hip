@@ -443,16 +443,27 @@ __global__ __launch_bounds__(256) void mfma_pack_rhs_kernel(const float* __restr
 }
 
 // max_i |x_i|^2 of a point set (fp32 or fp64 points), via atomicMax on the bit pattern of a non-negative float
-template <typename T>
+// DL > 1 (d == DL, a power of two 8 .. 64): DL lanes share a point, one coordinate each — consecutive lanes read consecutive memory (round 5: a thread per
+// point put every lane of a load on its own cache line once rows were long: 373 us for n = 2^20, d = 32 fp64 at handle creation)
+template <typename T, int DL = 1>
 __global__ __launch_bounds__(256) void max_norm2_kernel(const T* __restrict__ X, int64_t n, int32_t d, unsigned* __restrict__ outbits,
                                                         const T* __restrict__ Cn) {
     // outbits[0]: max |x_i|^2 (dot-product kernels), outbits[1]: max |x_i - c|^2 (isotropic kernels, c = the handle's centre)
     float v = 0.0f, vc = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // grid-stride
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+    const int cl = (int)(g0 % DL);                               // (DL divides the block: a lane keeps its coordinate across the stride)
+    for (int64_t i = g0 / DL; i < (n + 63) / 64 * 64; i += gs / DL) {   // grid-stride; whole waves stay in the loop for the shuffles below
         double s = 0, sc = 0;
-        for (int c = 0; c < d; ++c) {
-            const double xc = (double)X[i * (int64_t)d + c], xd = xc - (double)Cn[c];
-            s += xc * xc; sc += xd * xd;
+        if constexpr (DL == 1) {
+            if (i >= n) continue;
+            for (int c = 0; c < d; ++c) {
+                const double xc = (double)X[i * (int64_t)d + c], xd = xc - (double)Cn[c];
+                s += xc * xc; sc += xd * xd;
+            }
+        } else {
+            if (i < n) { const double xc = (double)X[i * (int64_t)DL + cl], xd = xc - (double)Cn[cl]; s = xc * xc; sc = xd * xd; }
+#pragma unroll
+            for (int o = DL / 2; o > 0; o >>= 1) { s += __shfl_xor(s, o); sc += __shfl_xor(sc, o); }
         }
         float f = (float)s, fc = (float)sc;
         if (!(f >= 0.0f)) f = __builtin_inff();                  // NaN / overflow: never eligible
@@ -508,10 +519,13 @@ int points_max_norm2(covgram_points* p) {
     if (e == hipSuccess) e = hipMemsetAsync(dbits, 0, 2 * sizeof(unsigned), st);
     if (e == hipSuccess) {
         const unsigned grid = (unsigned)std::min<int64_t>((p->n + 255) / 256, 2048);
-        if (p->dtype == COVGRAM_F32)
-            hipLaunchKernelGGL(max_norm2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)p->dptr, p->n, p->d, dbits, (const float*)p->center);
-        else
-            hipLaunchKernelGGL(max_norm2_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)p->dptr, p->n, p->d, dbits, (const double*)p->center);
+#define CG_MN(TT, DLV) hipLaunchKernelGGL((max_norm2_kernel<TT, DLV>), dim3((unsigned)std::min<int64_t>((p->n * DLV + 255) / 256, 512)), dim3(256), 0, st, (const TT*)p->dptr, p->n, p->d, dbits, (const TT*)p->center)
+#define CG_MND(TT) do { const bool big = p->n * (int64_t)p->d >= ((int64_t)1 << 22);   /* (small sets: the thread-per-point form's 64 atomics beat 512) */ \
+                        if (big && p->d == 8) CG_MN(TT, 8); else if (big && p->d == 16) CG_MN(TT, 16); else if (big && p->d == 32) CG_MN(TT, 32); else if (big && p->d == 64) CG_MN(TT, 64); \
+                        else hipLaunchKernelGGL((max_norm2_kernel<TT, 1>), dim3(grid), dim3(256), 0, st, (const TT*)p->dptr, p->n, p->d, dbits, (const TT*)p->center); } while (0)
+        if (p->dtype == COVGRAM_F32) CG_MND(float); else CG_MND(double);
+#undef CG_MND
+#undef CG_MN
         e = hipGetLastError();
     }
     unsigned bits[2] = {0, 0};

@@ -3,9 +3,11 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "covariancefunctions.jl_amd"))
 import covgram as cg
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-for n, d, kern in ((131072, 3, cg.EQ()), (131072, 8, cg.EQ()), (65536, 3, cg.EQ()), (131072, 3, cg.MaternP(2)), (262144, 3, cg.EQ())):
+CASES = ((131072, 3, cg.EQ()), (131072, 8, cg.EQ()), (65536, 3, cg.EQ()), (131072, 3, cg.MaternP(2)), (262144, 3, cg.EQ()))
+if len(sys.argv) > 1: CASES = ((131072, 8, cg.MaternP(2)), (65536, 8, cg.MaternP(2)), (131072, 12, cg.EQ()), (131072, 16, cg.EQ()), (65536, 12, cg.Cauchy()), (131072, 24, cg.EQ()))
+for n, d, kern in CASES:
     rng = np.random.default_rng(1)
-    X = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    X = torch.from_numpy((rng.standard_normal((n, d)) * min(1.0, 2.0 / np.sqrt(d))).astype(np.float32)).cuda(); a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
     G = cg.gramian(kern, X); y = torch.empty(n, dtype=torch.float32, device="cuda")
     res = {}
     for rep in range(3):
