@@ -173,7 +173,8 @@ int covgram_ctx_get_stream(covgram_ctx* ctx, void** hip_stream);
  * FOUR coordinates, half the matrix-core work of the bf16 three-way split — while both clouds lie within g^2 R^2 <= 72 and the bf16 split beyond,
  * 0 = always the bf16 split, 2 = the fp16 split up to the matrix-core gate of 126: measurements only.  EQ kernels (general and symmetric) and,
  * since round 5, the generic ones — MaternP(p >= 1), RQ, Cauchy, IMQ, EQ^p, one-pass Sums; isotropic, d <= 30 — inside the same 72 / 126 of their gate),
- * "kron_fill" (1 / 2: workgroups per CU the Kronecker mode kernel's column tiling aims at; 2 measured slower, profiles/r05_kron_fill_ab.txt),
+ * "kron_fill" (1 / 2: workgroups per CU the Kronecker mode kernel's column tiling aims at; 2 measured slower, profiles/r05_kron_fill_ab.txt; 3 = never
+ * fuse the last two modes: measurements, profiles/r05_kron_nopair_ab.txt),
  * "mfma_gate_pct" (1..100, default 100: both radius gates in percent.  BASELINE's 1e-5 is held NORM-wise at the full gates (<= 7.3e-6 measured);
  * the ROW-wise error |err_i| / (|K| |a|)_i of an adversarial cloud — points ON the gate's sphere, isolated rows, d >= 5 — reaches 1.5e-5 (bf16) /
  * 2.5e-5 (fp16) at the edge and scales with the gate: 40 holds 1e-5 row-wise on it.  Clouds outside run the direct-difference kernels),
